@@ -1,0 +1,244 @@
+/*
+ * rfhip.h -- C ABI of librfhip.so: the MI355X (gfx950) HIP runtime that replaces
+ * reforge's `vulkan::*` backend and its GLSL compute shaders for the
+ * render-graph execution path.
+ *
+ * The reference has no FFI in code; the seam this ABI replaces is the set of calls
+ * `src/render.rs` / `src/main.rs` make into the `src/vulkan` modules.
+ * Every entry point below cites the reference call it stands in for.  The
+ * reference-side binding a maintainer would add (Rust `extern "C"` block) is in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; opaque handles; the library owns handles, the caller owns
+ *     host buffers.
+ *   - every function returns an rf_status (0 = ok).  Nothing aborts or throws
+ *     across the boundary.  rf_last_error() returns the message of the calling
+ *     thread's most recent failure (the reference prints it with warnln!,
+ *     src/utils.rs:13-18, or panics for device errors).
+ *   - one host thread per rf_ctx (the reference is single-threaded, Rc<RefCell>).
+ *   - functions marked [host] touch no GPU and work on a machine without one.
+ *   - there is NO CPU fallback: any device entry point fails with
+ *     RF_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef RFHIP_H
+#define RFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RF_ABI_VERSION 1
+
+typedef enum rf_status {
+    RF_OK              = 0,
+    RF_ERR_INVALID     = 1,   /* bad argument / null handle */
+    RF_ERR_CONFIG      = 2,   /* config DSL rejected (reference: parse -> None + warnln!) */
+    RF_ERR_GRAPH       = 3,   /* graph cannot be built (unknown type/binding, cycle)     */
+    RF_ERR_NO_DEVICE   = 4,   /* no usable gfx950 device                                  */
+    RF_ERR_DEVICE      = 5,   /* HIP / RCCL runtime error (reference: unwrap()/panic!)    */
+    RF_ERR_UNSUPPORTED = 6,
+    RF_WARN_UNKNOWN_PARAM = 16 /* set_param on a name the node type lacks: ignored,
+                                  like an unmatched UBO member (render.rs:197-203)       */
+} rf_status;
+
+/* --shader-format (src/main.rs:27-41) */
+typedef enum rf_format {
+    RF_FORMAT_RGBA8   = 0,    /* VK_FORMAT_R8G8B8A8_UNORM      */
+    RF_FORMAT_RGBA32F = 1     /* VK_FORMAT_R32G32B32A32_SFLOAT */
+} rf_format;
+
+typedef enum rf_param_type { RF_PARAM_F32 = 0, RF_PARAM_I32 = 1, RF_PARAM_BOOL = 2 } rf_param_type;
+
+/* rf_graph_options.flags */
+#define RF_GRAPH_TIMERS      0x1u  /* per-node hipEvent timers (GpuTimer, vkutils.rs:47-135)   */
+#define RF_GRAPH_NO_FUSION   0x2u  /* one kernel launch per node, exactly as command.rs:220-240 */
+#define RF_GRAPH_HIPGRAPH    0x4u  /* replay the recorded frame as one hipGraph                 */
+#define RF_GRAPH_NO_HALO_XCHG 0x8u /* multi-rank: over-fetch the cumulative halo at upload
+                                      instead of a per-node RCCL exchange                      */
+
+typedef struct rf_ctx    rf_ctx;     /* VkCore            src/vulkan/core.rs:47-64   */
+typedef struct rf_config rf_config;  /* config::Config    src/config/config.rs:35-38 */
+typedef struct rf_plan   rf_plan;    /* layers + aliasing src/vulkan/pipeline_graph.rs:358-497 */
+typedef struct rf_graph  rf_graph;   /* PipelineGraph + its frames  pipeline_graph.rs:43-57    */
+
+typedef struct rf_graph_options {
+    int       width;        /* RenderInfo.width   src/render.rs:40 */
+    int       height;       /* RenderInfo.height  (the FULL frame height on every rank) */
+    rf_format format;       /* RenderInfo.format  */
+    int       num_frames;   /* frames in flight   src/main.rs:69-70; >= 1 */
+    uint32_t  flags;        /* RF_GRAPH_* */
+} rf_graph_options;
+
+/* ------------------------------------------------------------------------- */
+/* Errors                                                                      */
+/* ------------------------------------------------------------------------- */
+/* [host] message of this thread's last failing call ("" if none) */
+const char* rf_last_error(void);
+/* [host] RF_ABI_VERSION the library was built with */
+int rf_abi_version(void);
+
+/* ------------------------------------------------------------------------- */
+/* Config DSL  (src/config/config.rs, config_grammar.lalrpop)                  */
+/* ------------------------------------------------------------------------- */
+/* [host] config::parse            src/config/config.rs:98-205
+ *        expects_input = an input image exists (has_input_image, render.rs:46) */
+rf_status rf_config_parse(const char* text, int expects_input, rf_config** out);
+/* [host] config::single_shader_parse  src/config/config.rs:77-90
+ *        `type_name` = the shader's file stem */
+rf_status rf_config_single(const char* type_name, int expects_input, rf_config** out);
+void      rf_config_destroy(rf_config* cfg);
+/* [host] enumeration of Config.graph_pipelines (name-sorted) */
+int         rf_config_num_nodes(const rf_config* cfg);
+const char* rf_config_node_name(const rf_config* cfg, int node);
+/* node type: the instance's pipeline_type, else the node name (config.rs:59-75) */
+const char* rf_config_node_type(const rf_config* cfg, int node);
+int         rf_config_node_num_inputs(const rf_config* cfg, int node);
+int         rf_config_node_num_outputs(const rf_config* cfg, int node);
+/* ConfigDescriptor {resource_name, descriptor_name}  config.rs:17-21 */
+const char* rf_config_node_input_resource(const rf_config* cfg, int node, int i);
+const char* rf_config_node_input_descriptor(const rf_config* cfg, int node, int i);
+const char* rf_config_node_output_resource(const rf_config* cfg, int node, int i);
+const char* rf_config_node_output_descriptor(const rf_config* cfg, int node, int i);
+/* PipelineInstance.parameters (config.rs:30-33), key-sorted; value in string form */
+int         rf_config_node_num_params(const rf_config* cfg, int node);
+const char* rf_config_node_param_key(const rf_config* cfg, int node, int i);
+const char* rf_config_node_param_value(const rf_config* cfg, int node, int i);
+
+/* ------------------------------------------------------------------------- */
+/* Plan: layering + image aliasing (+ this build's fusion groups)             */
+/* ------------------------------------------------------------------------- */
+/* [host] vkutils::synthesize_config (vkutils.rs:140-196) +
+ *        PipelineGraph::order_by_execution (pipeline_graph.rs:429-497) +
+ *        PipelineGraph::reusable_image_remapping (pipeline_graph.rs:358-427) */
+rf_status rf_plan_create(const rf_config* cfg, uint32_t flags, rf_plan** out);
+void      rf_plan_destroy(rf_plan* plan);
+int         rf_plan_num_layers(const rf_plan* plan);
+int         rf_plan_layer_size(const rf_plan* plan, int layer);
+const char* rf_plan_layer_node(const rf_plan* plan, int layer, int i);   /* name-sorted */
+/* image_reuse_remapping entries, key-sorted (pipeline_graph.rs:31,:358) */
+int         rf_plan_num_aliases(const rf_plan* plan);
+const char* rf_plan_alias_from(const rf_plan* plan, int i);
+const char* rf_plan_alias_to(const rf_plan* plan, int i);
+/* images actually allocated per frame, name-sorted (pipeline_graph.rs:205-224) */
+int         rf_plan_num_images(const rf_plan* plan);
+const char* rf_plan_image_name(const rf_plan* plan, int i);
+/* remap_resource_name (pipeline_graph.rs:75-79) */
+const char* rf_plan_resolve(const rf_plan* plan, const char* resource);
+/* kernel launches per frame after fusion, and the nodes each one covers
+ * ("a+b+c"); with RF_GRAPH_NO_FUSION one launch per node */
+int         rf_plan_num_launches(const rf_plan* plan);
+const char* rf_plan_launch_label(const rf_plan* plan, int i);
+
+/* ------------------------------------------------------------------------- */
+/* Node-type registry: what SPIR-V reflection gives the reference             */
+/* (src/vulkan/shader.rs:106-160)                                              */
+/* ------------------------------------------------------------------------- */
+/* [host] */
+int         rf_registry_num_types(void);
+const char* rf_registry_type_name(int t);
+/* binding index of an image variable name, -1 if the type has none */
+int         rf_registry_binding(const char* type_name, const char* descriptor);
+/* vertical / horizontal stencil radius a node of this type reads (0 = point op);
+ * radius-parameterised types report their maximum */
+int         rf_registry_radius(const char* type_name);
+
+/* ------------------------------------------------------------------------- */
+/* Row-strip partition (new: the reference is single-device)                   */
+/* ------------------------------------------------------------------------- */
+/* [host] rows [*y0, *y1) of a frame of `height` rows owned by `rank` of `world` */
+rf_status rf_strip_rows(int height, int world, int rank, int* y0, int* y1);
+
+/* ------------------------------------------------------------------------- */
+/* Context  (VkCore::new src/vulkan/core.rs:66-146; Drop :266-286)             */
+/* ------------------------------------------------------------------------- */
+/* single device, single process */
+rf_status rf_ctx_create(int device, rf_ctx** out);
+/* [host] fills a 128-byte RCCL unique id on the calling rank (rank 0) for
+ * rf_ctx_create_dist; the caller broadcasts the bytes to the other ranks */
+rf_status rf_comm_unique_id(void* id128);
+/* one process per GPU: rank `rank` of `world` ranks on one node, neighbour halo
+ * exchange over RCCL.  `id128` = the bytes produced by rf_comm_unique_id on rank 0 */
+rf_status rf_ctx_create_dist(int device, int rank, int world, const void* id128, rf_ctx** out);
+void      rf_ctx_destroy(rf_ctx* ctx);
+/* vkDeviceWaitIdle (render.rs:123, pipeline_graph.rs:610) */
+rf_status rf_ctx_synchronize(rf_ctx* ctx);
+int       rf_ctx_rank(const rf_ctx* ctx);
+int       rf_ctx_world(const rf_ctx* ctx);
+/* device name, e.g. "gfx950" */
+const char* rf_ctx_device_arch(const rf_ctx* ctx);
+
+/* ------------------------------------------------------------------------- */
+/* Graph  (Render::create_graph src/render.rs:80-98)                           */
+/* ------------------------------------------------------------------------- */
+/* synthesize_config + PipelineGraph::new (pipeline_graph.rs:499-592) + per-frame
+ * image allocation (pipeline_graph.rs:133-323) + initialize_ubos from the
+ * config's instance parameters (render.rs:167-210) */
+rf_status rf_graph_create(rf_ctx* ctx, const rf_config* cfg, const rf_graph_options* opt, rf_graph** out);
+/* Drop for PipelineGraph (pipeline_graph.rs:605-620); hot reload = destroy + create
+ * (recreate_graph render.rs:121-136) */
+void      rf_graph_destroy(rf_graph* g);
+/* [host view] the plan the graph was built from (owned by the graph) */
+const rf_plan* rf_graph_plan(const rf_graph* g);
+/* rows [y0,y1) of the frame this rank holds (whole frame when world == 1) */
+rf_status rf_graph_strip(const rf_graph* g, int* y0, int* y1);
+
+/* initialize_ubos / update_ubos (render.rs:167-223): writes one uniform member of
+ * node `node`.  Unknown name -> RF_WARN_UNKNOWN_PARAM (nothing written). */
+rf_status rf_graph_set_param(rf_graph* g, const char* node, const char* name,
+                             rf_param_type type, const void* value);
+/* conv2d weights, row-major [K][K] f32 with K = the node's resolved ksize
+ * (no reference counterpart: SSBO contents are written by other nodes there) */
+rf_status rf_graph_set_weights(rf_graph* g, const char* node, const float* weights, int count);
+/* update_ubos (render.rs:212-223): every member whose name ends in `_rf_time` */
+rf_status rf_graph_set_time(rf_graph* g, float seconds);
+
+/* record_initial_image_load (render.rs:264-313): RGBA8 sRGB rows of the rank's strip
+ * (strip_rows x width) -> sRGB decode -> the graph's linear input image */
+rf_status rf_graph_upload_srgb8(rf_graph* g, const uint8_t* rgba, size_t row_stride);
+/* raw texels of the graph format (u8x4 or f32x4), no colour conversion */
+rf_status rf_graph_upload_raw(rf_graph* g, const void* texels, size_t row_stride);
+/* on-device synthetic input: hash32(seed, y*W+x, c) */
+rf_status rf_graph_fill_synthetic(rf_graph* g, uint32_t seed);
+/* ramps + impulse at (W/2, H/2) */
+rf_status rf_graph_fill_structured(rf_graph* g);
+
+/* Render::record + submit (render.rs:359-404, :441-495) ->
+ * command::execute_pipeline_graph (command.rs:166-242).  Asynchronous. */
+rf_status rf_graph_execute(rf_graph* g, int frame_slot);
+/* wait_for_frame_fence (render.rs:328-337) */
+rf_status rf_graph_wait(rf_graph* g, int frame_slot);
+
+/* write_output_to_buffer (render.rs:406-433): linear -> sRGB8 of the rank's strip */
+rf_status rf_graph_download_srgb8(rf_graph* g, int frame_slot, uint8_t* rgba, size_t row_stride);
+rf_status rf_graph_download_raw(rf_graph* g, int frame_slot, void* texels, size_t row_stride);
+/* raw texels of any allocated image (debug / tests), by resource name */
+rf_status rf_graph_download_image(rf_graph* g, int frame_slot, const char* resource,
+                                  void* texels, size_t row_stride);
+
+/* last_frame_gpu_times (render.rs:521-523, vkutils.rs:104-134): per-launch GPU
+ * milliseconds of the slot's last completed frame, name-sorted.  Needs
+ * RF_GRAPH_TIMERS.  *n in = capacity, out = count. */
+rf_status rf_graph_node_times(rf_graph* g, int frame_slot, const char** names, float* ms, int* n);
+/* the same as the reference's status string "name: 0.123ms, name2: ..." */
+rf_status rf_graph_times_string(rf_graph* g, int frame_slot, char* buf, size_t cap);
+
+/* ------------------------------------------------------------------------- */
+/* Measurement helpers (bench.py): HIP-event timing on the graph's own stream  */
+/* ------------------------------------------------------------------------- */
+/* runs `iters` frames back to back on slot 0 and returns the total elapsed GPU
+ * milliseconds between a hipEvent recorded before the first and after the last */
+rf_status rf_graph_time_frames(rf_graph* g, int iters, float* total_ms);
+/* same, but one launch only (index into rf_plan_launch_label): average ms */
+rf_status rf_graph_time_launch(rf_graph* g, int launch, int iters, float* avg_ms);
+/* float4 copy of `bytes` device bytes, `iters` times: achieved GB/s (the
+ * practical HBM ceiling on this box) */
+rf_status rf_ctx_copy_bandwidth(rf_ctx* ctx, size_t bytes, int iters, float* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,337 @@
+// reforge_main.cpp -- the C++ host over librfhip.so: counterpart of the reference's
+// src/main.rs (CLI + one headless frame) and the frame half of src/render.rs.  It only
+// speaks the C ABI of include/rfhip.h, exactly as a Rust host would through FFI
+// (INTEGRATION.md).
+//
+// Kept from the reference: the flags of `Args` (main.rs:43-71), the config/shader
+// exclusivity check (main.rs:80-83), get_dim (utils.rs:56-74), the default graph
+// (render.rs:115), single-shader mode (config.rs:77-90), headless = one frame then
+// encode (main.rs:220-224), the status line (main.rs:157).
+// Out of scope: the winit/swapchain window (no display on an MI355X box) and the
+// ffmpeg codecs -- images are read as binary PPM (P6) or raw RGBA8 and written as
+// PNG (stored deflate), PPM or raw RGBA8, chosen by file extension.
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "rfhip.h"
+
+namespace {
+
+// utils.rs:13-18
+void warnln(const std::string& msg) { std::fprintf(stderr, "\r\x1b[2K\x1b[33m%s\x1b[0m\n", msg.c_str()); }
+
+struct Args {   // main.rs:43-71
+    std::string shader_file_path, input_file, output_file, config, shader_path = "shaders";
+    int width = -1, height = -1;
+    std::string shader_format = "rgba32f";
+    int num_frames = 2;
+    // additions for headless benchmarking
+    long synthetic_seed = -1;
+    int frames = 1;
+    bool no_fusion = false, hipgraph = false;
+};
+
+void usage()
+{
+    std::fputs(
+        "Usage: reforge [OPTIONS] [shader]\n\n"
+        "Arguments:\n  [shader]  A single filter type to execute instead of a config\n\n"
+        "Options:\n"
+        "  -i, --input-file <INPUT_FILE>      File to read from (.ppm P6 or .rgba raw)\n"
+        "  -o, --output-file <OUTPUT_FILE>    File to write to (.png, .ppm or .rgba)\n"
+        "      --width <WIDTH>\n"
+        "      --height <HEIGHT>\n"
+        "      --shader-format <rgba8|rgba32f>  Shader image format [default: rgba32f]\n"
+        "      --config <config>              Path to the pipeline configuration file\n"
+        "      --shader-path <shader-path>    Kept for compatibility; filter types are compiled in [default: shaders]\n"
+        "      --num-frames <NUM_FRAMES>      Frames in flight when displaying (headless forces 1) [default: 2]\n"
+        "      --synthetic <SEED>             Generate the input on the GPU instead of reading a file\n"
+        "      --frames <N>                   Execute the graph N times and report the mean frame time\n"
+        "      --no-fusion                    One kernel launch per node, as the reference dispatches\n"
+        "      --hipgraph                     Replay the frame as one hipGraph\n"
+        "  -h, --help                         Print help\n",
+        stderr);
+}
+
+bool parse_args(int argc, char** argv, Args& a)
+{
+    for (int i = 1; i < argc; ++i) {
+        std::string s = argv[i];
+        auto val = [&](std::string& dst) {
+            if (i + 1 >= argc) { warnln("error: a value is required for '" + s + "'"); return false; }
+            dst = argv[++i];
+            return true;
+        };
+        std::string v;
+        if (s == "-h" || s == "--help") { usage(); std::exit(0); }
+        else if (s == "-i" || s == "--input-file") { if (!val(a.input_file)) return false; }
+        else if (s == "-o" || s == "--output-file") { if (!val(a.output_file)) return false; }
+        else if (s == "--width") { if (!val(v)) return false; a.width = std::atoi(v.c_str()); }
+        else if (s == "--height") { if (!val(v)) return false; a.height = std::atoi(v.c_str()); }
+        else if (s == "--shader-format") { if (!val(a.shader_format)) return false; }
+        else if (s == "--config") { if (!val(a.config)) return false; }
+        else if (s == "--shader-path") { if (!val(a.shader_path)) return false; }
+        else if (s == "--num-frames") { if (!val(v)) return false; a.num_frames = std::atoi(v.c_str()); }
+        else if (s == "--synthetic") { if (!val(v)) return false; a.synthetic_seed = std::strtol(v.c_str(), nullptr, 0); }
+        else if (s == "--frames") { if (!val(v)) return false; a.frames = std::atoi(v.c_str()); }
+        else if (s == "--no-fusion") a.no_fusion = true;
+        else if (s == "--hipgraph") a.hipgraph = true;
+        else if (!s.empty() && s[0] == '-') { warnln("error: unexpected argument '" + s + "'"); return false; }
+        else if (a.shader_file_path.empty()) a.shader_file_path = s;
+        else { warnln("error: unexpected argument '" + s + "'"); return false; }
+    }
+    return true;
+}
+
+// utils::get_dim, utils.rs:56-74
+void get_dim(int width, int height, int new_w, int new_h, int& w, int& h)
+{
+    w = width;
+    h = height;
+    if (new_w >= 0 && new_h >= 0) { w = new_w; h = new_h; return; }
+    if (new_w >= 0) { w = new_w; h = (int)(((float)w / (float)width) * (float)height); }
+    else if (new_h >= 0) { h = new_h; w = (int)(((float)h / (float)height) * (float)width); }
+}
+
+bool ends_with(const std::string& s, const char* suf)
+{
+    size_t n = std::strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+// ---- minimal image I/O (imagefileio.rs is ffmpeg; codecs are out of scope) ---------
+bool read_ppm(const std::string& path, int& w, int& h, std::vector<uint8_t>& rgba)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::string magic;
+    f >> magic;
+    if (magic != "P6") return false;
+    auto next_int = [&](int& v) {
+        for (;;) {
+            int c = f.peek();
+            if (c == '#') { std::string line; std::getline(f, line); }
+            else if (std::isspace(c)) f.get();
+            else break;
+        }
+        f >> v;
+        return (bool)f;
+    };
+    int maxv = 0;
+    if (!next_int(w) || !next_int(h) || !next_int(maxv) || maxv != 255 || w < 1 || h < 1) return false;
+    f.get();
+    std::vector<uint8_t> rgb((size_t)w * h * 3);
+    f.read((char*)rgb.data(), (std::streamsize)rgb.size());
+    if (!f) return false;
+    rgba.resize((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        rgba[i * 4 + 0] = rgb[i * 3 + 0];
+        rgba[i * 4 + 1] = rgb[i * 3 + 1];
+        rgba[i * 4 + 2] = rgb[i * 3 + 2];
+        rgba[i * 4 + 3] = 255;
+    }
+    return true;
+}
+
+uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n)
+{
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+    return crc;
+}
+
+void put_be32(std::vector<uint8_t>& v, uint32_t x)
+{
+    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+
+void png_chunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_t>& data)
+{
+    put_be32(out, (uint32_t)data.size());
+    size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), data.begin(), data.end());
+    put_be32(out, crc32_update(0xFFFFFFFFu, out.data() + start, out.size() - start) ^ 0xFFFFFFFFu);
+}
+
+// RGBA8 PNG with stored (uncompressed) deflate blocks: valid for every decoder
+bool write_png(const std::string& path, int w, int h, const uint8_t* rgba)
+{
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)h * ((size_t)w * 4 + 1));
+    for (int y = 0; y < h; ++y) {
+        raw.push_back(0);   // filter: none
+        raw.insert(raw.end(), rgba + (size_t)y * w * 4, rgba + (size_t)(y + 1) * w * 4);
+    }
+    std::vector<uint8_t> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0;
+    for (uint8_t c : raw) { a = (a + c) % 65521; b = (b + a) % 65521; }
+    size_t pos = 0;
+    do {
+        size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xFF)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xFF)); z.push_back((uint8_t)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + (long)pos, raw.begin() + (long)(pos + n));
+        pos += n;
+    } while (pos < raw.size());
+    put_be32(z, (b << 16) | a);
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, (uint32_t)w); put_be32(ihdr, (uint32_t)h);
+    ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    png_chunk(out, "IHDR", ihdr);
+    png_chunk(out, "IDAT", z);
+    png_chunk(out, "IEND", {});
+    std::ofstream f(path, std::ios::binary);
+    f.write((const char*)out.data(), (std::streamsize)out.size());
+    return (bool)f;
+}
+
+bool write_image(const std::string& path, int w, int h, const uint8_t* rgba)
+{
+    if (ends_with(path, ".ppm")) {
+        std::ofstream f(path, std::ios::binary);
+        f << "P6\n" << w << " " << h << "\n255\n";
+        for (size_t i = 0; i < (size_t)w * h; ++i) f.write((const char*)rgba + i * 4, 3);
+        return (bool)f;
+    }
+    if (ends_with(path, ".rgba")) {
+        std::ofstream f(path, std::ios::binary);
+        f.write((const char*)rgba, (std::streamsize)((size_t)w * h * 4));
+        return (bool)f;
+    }
+    return write_png(path, w, h, rgba);   // the reference always writes PNG (imagefileio.rs:221)
+}
+
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+#define RF_CHECK(expr)                                                                          \
+    do {                                                                                        \
+        rf_status st_ = (expr);                                                                 \
+        if (st_ != RF_OK) {                                                                     \
+            warnln(std::string(#expr) + " -> " + std::to_string((int)st_) + ": " + rf_last_error()); \
+            return 1;                                                                           \
+        }                                                                                       \
+    } while (0)
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    Args args;
+    if (!parse_args(argc, argv, args)) { usage(); return 2; }
+    if (args.output_file.empty()) {
+        warnln("No output file given: window/swapchain presentation is out of scope on an MI355X box; pass -o <file>");
+        return 1;
+    }
+    const int num_frames = 1;   // main.rs:77-78: headless uses one frame in flight
+    if (!args.config.empty() && !args.shader_file_path.empty()) {   // main.rs:80-83
+        warnln("Cannot specify both a config and shader file");
+        return 1;
+    }
+    rf_format format;
+    if (args.shader_format == "rgba8") format = RF_FORMAT_RGBA8;
+    else if (args.shader_format == "rgba32f") format = RF_FORMAT_RGBA32F;
+    else { warnln("error: invalid value '" + args.shader_format + "' for '--shader-format' [possible values: rgba8, rgba32f]"); return 2; }
+
+    // decode (main.rs:85-100,:126-132)
+    double t0 = now_ms();
+    int in_w = 800, in_h = 600;   // main.rs:99
+    std::vector<uint8_t> staging;
+    const bool has_file = !args.input_file.empty();
+    const bool has_input = has_file || args.synthetic_seed >= 0;
+    if (has_file) {
+        if (ends_with(args.input_file, ".rgba")) {
+            if (args.width < 1 || args.height < 1) { warnln("a raw .rgba input needs --width and --height"); return 1; }
+            in_w = args.width; in_h = args.height;
+            std::ifstream f(args.input_file, std::ios::binary);
+            staging.resize((size_t)in_w * in_h * 4);
+            f.read((char*)staging.data(), (std::streamsize)staging.size());
+            if (!f) { warnln("Error reading file '" + args.input_file + "'"); return 1; }
+        } else if (!read_ppm(args.input_file, in_w, in_h, staging)) {
+            warnln("Error reading file '" + args.input_file + "': only binary PPM (P6, maxval 255) and raw .rgba are decoded");
+            return 1;
+        }
+    }
+    int width, height;
+    get_dim(in_w, in_h, args.width, args.height, width, height);
+    if (has_file && (width != in_w || height != in_h)) {
+        warnln("resizing on load (swscale in the reference, imagefileio.rs:150-176) is out of scope: drop --width/--height");
+        return 1;
+    }
+    if (has_file) std::printf("File Decode and resize: %.2fms\n", now_ms() - t0);
+
+    // create_config, render.rs:100-119
+    rf_config* cfg = nullptr;
+    if (!args.config.empty()) {
+        std::ifstream f(args.config);
+        std::stringstream ss;
+        ss << f.rdbuf();
+        if (!f) { warnln("Error reading file '" + args.config + "'"); warnln("Unable to create config"); return 1; }
+        if (ss.str().empty()) { warnln("File was empty: " + args.config); warnln("Unable to create config"); return 1; }
+        if (rf_config_parse(ss.str().c_str(), has_input, &cfg) != RF_OK) { warnln(rf_last_error()); warnln("Unable to create config"); return 1; }
+    } else if (!args.shader_file_path.empty()) {
+        std::string stem = args.shader_file_path;   // config.rs:79: file stem
+        size_t slash = stem.find_last_of('/');
+        if (slash != std::string::npos) stem = stem.substr(slash + 1);
+        size_t dot = stem.find_last_of('.');
+        if (dot != std::string::npos) stem = stem.substr(0, dot);
+        if (rf_config_single(stem.c_str(), has_input, &cfg) != RF_OK) { warnln(rf_last_error()); return 1; }
+    } else {
+        if (rf_config_parse("input -> passthrough -> output", has_input, &cfg) != RF_OK) { warnln(rf_last_error()); return 1; }
+    }
+
+    rf_ctx* ctx = nullptr;
+    RF_CHECK(rf_ctx_create(0, &ctx));
+    rf_graph_options opt{};
+    opt.width = width;
+    opt.height = height;
+    opt.format = format;
+    opt.num_frames = num_frames;
+    opt.flags = RF_GRAPH_TIMERS | (args.no_fusion ? RF_GRAPH_NO_FUSION : 0u);
+    if (args.hipgraph) opt.flags = (opt.flags & ~RF_GRAPH_TIMERS) | RF_GRAPH_HIPGRAPH;
+    rf_graph* graph = nullptr;
+    RF_CHECK(rf_graph_create(ctx, cfg, &opt, &graph));
+
+    // render_fn, main.rs:134-182, headless
+    if (has_file) RF_CHECK(rf_graph_upload_srgb8(graph, staging.data(), (size_t)width * 4));
+    else if (args.synthetic_seed >= 0) RF_CHECK(rf_graph_fill_synthetic(graph, (uint32_t)args.synthetic_seed));
+    RF_CHECK(rf_graph_wait(graph, 0));
+    double t_frame = now_ms();
+    for (int i = 0; i < (args.frames < 1 ? 1 : args.frames); ++i) RF_CHECK(rf_graph_execute(graph, 0));
+    RF_CHECK(rf_graph_wait(graph, 0));
+    double frame_ms = (now_ms() - t_frame) / (double)(args.frames < 1 ? 1 : args.frames);
+    char times[4096] = "";
+    if (opt.flags & RF_GRAPH_TIMERS) RF_CHECK(rf_graph_times_string(graph, 0, times, sizeof(times)));
+    std::fprintf(stderr, "\rFrame: %5.2fms, Frame-Avg: %5.2fms, GPU: {%s}\n", frame_ms, frame_ms, times);   // main.rs:157
+
+    staging.resize((size_t)width * height * 4);
+    RF_CHECK(rf_graph_download_srgb8(graph, 0, staging.data(), (size_t)width * 4));
+    if (!write_image(args.output_file, width, height, staging.data())) { warnln("Encoding error: cannot write " + args.output_file); return 1; }
+
+    rf_graph_destroy(graph);
+    rf_ctx_destroy(ctx);
+    rf_config_destroy(cfg);
+    return 0;
+}

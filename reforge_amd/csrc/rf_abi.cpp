@@ -1,0 +1,243 @@
+// rf_abi.cpp -- host-only half of the C ABI (include/rfhip.h): errors, the config DSL,
+// the planner views and the node-type registry.  Nothing here touches a GPU.
+#include <algorithm>
+#include <cstring>
+
+#include "rf_runtime.h"
+
+namespace rf {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+const char* last_error() { return g_last_error.c_str(); }
+
+}  // namespace rf
+
+using namespace rf;
+
+static rf_status fail(rf_status st, const std::string& msg)
+{
+    set_error(msg);
+    return st;
+}
+
+extern "C" const char* rf_last_error(void) { return last_error(); }
+extern "C" int rf_abi_version(void) { return RF_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------
+// Config
+// ---------------------------------------------------------------------------------
+static void index_config(rf_config* c)
+{
+    c->node_names.clear();
+    for (const auto& kv : c->cfg.graph_pipelines) c->node_names.push_back(kv.first);
+}
+
+extern "C" rf_status rf_config_parse(const char* text, int expects_input, rf_config** out)
+{
+    if (!text || !out) return fail(RF_ERR_INVALID, "rf_config_parse: null argument");
+    *out = nullptr;
+    rf_config* c = new rf_config();
+    std::string err;
+    if (!parse_config(text, expects_input != 0, c->cfg, err)) {
+        delete c;
+        return fail(RF_ERR_CONFIG, err);
+    }
+    index_config(c);
+    *out = c;
+    return RF_OK;
+}
+
+extern "C" rf_status rf_config_single(const char* type_name, int expects_input, rf_config** out)
+{
+    if (!type_name || !out) return fail(RF_ERR_INVALID, "rf_config_single: null argument");
+    *out = nullptr;
+    rf_config* c = new rf_config();
+    std::string err;
+    if (!single_node_config(type_name, expects_input != 0, c->cfg, err)) {
+        delete c;
+        return fail(RF_ERR_CONFIG, err);
+    }
+    index_config(c);
+    *out = c;
+    return RF_OK;
+}
+
+extern "C" void rf_config_destroy(rf_config* cfg) { delete cfg; }
+
+extern "C" int rf_config_num_nodes(const rf_config* cfg) { return cfg ? (int)cfg->node_names.size() : 0; }
+
+static const GraphPipeline* node_at(const rf_config* cfg, int node)
+{
+    if (!cfg || node < 0 || node >= (int)cfg->node_names.size()) return nullptr;
+    return &cfg->cfg.graph_pipelines.at(cfg->node_names[(size_t)node]);
+}
+
+extern "C" const char* rf_config_node_name(const rf_config* cfg, int node)
+{
+    return node_at(cfg, node) ? cfg->node_names[(size_t)node].c_str() : nullptr;
+}
+
+extern "C" const char* rf_config_node_type(const rf_config* cfg, int node)
+{
+    return node_at(cfg, node) ? cfg->cfg.type_of(cfg->node_names[(size_t)node]).c_str() : nullptr;
+}
+
+extern "C" int rf_config_node_num_inputs(const rf_config* cfg, int node)
+{
+    const GraphPipeline* p = node_at(cfg, node);
+    return p ? (int)p->inputs.size() : 0;
+}
+
+extern "C" int rf_config_node_num_outputs(const rf_config* cfg, int node)
+{
+    const GraphPipeline* p = node_at(cfg, node);
+    return p ? (int)p->outputs.size() : 0;
+}
+
+static const ConfigDescriptor* desc_at(const rf_config* cfg, int node, int i, bool input)
+{
+    const GraphPipeline* p = node_at(cfg, node);
+    if (!p) return nullptr;
+    const auto& v = input ? p->inputs : p->outputs;
+    return (i >= 0 && i < (int)v.size()) ? &v[(size_t)i] : nullptr;
+}
+
+extern "C" const char* rf_config_node_input_resource(const rf_config* cfg, int node, int i)
+{
+    const ConfigDescriptor* d = desc_at(cfg, node, i, true);
+    return d ? d->resource_name.c_str() : nullptr;
+}
+extern "C" const char* rf_config_node_input_descriptor(const rf_config* cfg, int node, int i)
+{
+    const ConfigDescriptor* d = desc_at(cfg, node, i, true);
+    return d ? d->descriptor_name.c_str() : nullptr;
+}
+extern "C" const char* rf_config_node_output_resource(const rf_config* cfg, int node, int i)
+{
+    const ConfigDescriptor* d = desc_at(cfg, node, i, false);
+    return d ? d->resource_name.c_str() : nullptr;
+}
+extern "C" const char* rf_config_node_output_descriptor(const rf_config* cfg, int node, int i)
+{
+    const ConfigDescriptor* d = desc_at(cfg, node, i, false);
+    return d ? d->descriptor_name.c_str() : nullptr;
+}
+
+extern "C" int rf_config_node_num_params(const rf_config* cfg, int node)
+{
+    return node_at(cfg, node) ? (int)cfg->cfg.params_of(cfg->node_names[(size_t)node]).size() : 0;
+}
+
+static const std::pair<const std::string, std::string>* param_at(const rf_config* cfg, int node, int i)
+{
+    if (!node_at(cfg, node)) return nullptr;
+    const auto& m = cfg->cfg.params_of(cfg->node_names[(size_t)node]);
+    if (i < 0 || i >= (int)m.size()) return nullptr;
+    auto it = m.begin();
+    std::advance(it, i);
+    return &*it;
+}
+
+extern "C" const char* rf_config_node_param_key(const rf_config* cfg, int node, int i)
+{
+    auto* p = param_at(cfg, node, i);
+    return p ? p->first.c_str() : nullptr;
+}
+extern "C" const char* rf_config_node_param_value(const rf_config* cfg, int node, int i)
+{
+    auto* p = param_at(cfg, node, i);
+    return p ? p->second.c_str() : nullptr;
+}
+
+// ---------------------------------------------------------------------------------
+// Plan
+// ---------------------------------------------------------------------------------
+extern "C" rf_status rf_plan_create(const rf_config* cfg, uint32_t flags, rf_plan** out)
+{
+    if (!cfg || !out) return fail(RF_ERR_INVALID, "rf_plan_create: null argument");
+    *out = nullptr;
+    rf_plan* p = new rf_plan();
+    std::string err;
+    if (!build_plan(cfg->cfg, flags, p->plan, err)) {
+        delete p;
+        return fail(RF_ERR_GRAPH, err);
+    }
+    p->launch_labels = p->plan.launch_order();
+    p->aliases.assign(p->plan.reuse.begin(), p->plan.reuse.end());
+    *out = p;
+    return RF_OK;
+}
+
+extern "C" void rf_plan_destroy(rf_plan* plan) { delete plan; }
+
+extern "C" int rf_plan_num_layers(const rf_plan* p) { return p ? (int)p->plan.layers.size() : 0; }
+extern "C" int rf_plan_layer_size(const rf_plan* p, int layer)
+{
+    return (p && layer >= 0 && layer < (int)p->plan.layers.size()) ? (int)p->plan.layers[(size_t)layer].size() : 0;
+}
+extern "C" const char* rf_plan_layer_node(const rf_plan* p, int layer, int i)
+{
+    if (!p || layer < 0 || layer >= (int)p->plan.layers.size()) return nullptr;
+    const auto& l = p->plan.layers[(size_t)layer];
+    return (i >= 0 && i < (int)l.size()) ? l[(size_t)i].c_str() : nullptr;
+}
+extern "C" int rf_plan_num_aliases(const rf_plan* p) { return p ? (int)p->aliases.size() : 0; }
+extern "C" const char* rf_plan_alias_from(const rf_plan* p, int i)
+{
+    return (p && i >= 0 && i < (int)p->aliases.size()) ? p->aliases[(size_t)i].first.c_str() : nullptr;
+}
+extern "C" const char* rf_plan_alias_to(const rf_plan* p, int i)
+{
+    return (p && i >= 0 && i < (int)p->aliases.size()) ? p->aliases[(size_t)i].second.c_str() : nullptr;
+}
+extern "C" int rf_plan_num_images(const rf_plan* p) { return p ? (int)p->plan.images.size() : 0; }
+extern "C" const char* rf_plan_image_name(const rf_plan* p, int i)
+{
+    return (p && i >= 0 && i < (int)p->plan.images.size()) ? p->plan.images[(size_t)i].c_str() : nullptr;
+}
+extern "C" const char* rf_plan_resolve(const rf_plan* p, const char* resource)
+{
+    if (!p || !resource) return nullptr;
+    // the returned pointer must outlive the call: it is a key/value of the plan's own
+    // maps, or the caller's string when nothing remaps it
+    std::string r = resource;
+    auto it = p->plan.reuse.find(r);
+    if (it == p->plan.reuse.end()) return resource;
+    return p->plan.resolve(it->second).c_str();
+}
+extern "C" int rf_plan_num_launches(const rf_plan* p) { return p ? (int)p->launch_labels.size() : 0; }
+extern "C" const char* rf_plan_launch_label(const rf_plan* p, int i)
+{
+    return (p && i >= 0 && i < (int)p->launch_labels.size()) ? p->launch_labels[(size_t)i].c_str() : nullptr;
+}
+
+// ---------------------------------------------------------------------------------
+// Registry
+// ---------------------------------------------------------------------------------
+extern "C" int rf_registry_num_types(void) { return (int)registry().size(); }
+extern "C" const char* rf_registry_type_name(int t)
+{
+    return (t >= 0 && t < (int)registry().size()) ? registry()[(size_t)t].name : nullptr;
+}
+extern "C" int rf_registry_binding(const char* type_name, const char* descriptor)
+{
+    if (!type_name || !descriptor) return -1;
+    const NodeType* t = find_type(type_name);
+    return t ? t->binding(descriptor) : -1;
+}
+extern "C" int rf_registry_radius(const char* type_name)
+{
+    if (!type_name) return -1;
+    const NodeType* t = find_type(type_name);
+    if (!t) return -1;
+    return t->fixed_radius >= 0 ? t->fixed_radius : kMaxRadius;
+}
+
+extern "C" rf_status rf_strip_rows(int height, int world, int rank, int* y0, int* y1)
+{
+    if (!y0 || !y1 || height < 1 || world < 1 || rank < 0 || rank >= world) return fail(RF_ERR_INVALID, "rf_strip_rows: bad argument");
+    strip_rows(height, world, rank, *y0, *y1);
+    return RF_OK;
+}

@@ -1,0 +1,949 @@
+// rf_graph.cpp -- device half of the C ABI (see include/rfhip.h, rf_runtime.h).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "rf_runtime.h"
+
+using namespace rf;
+
+// ---------------------------------------------------------------------------------
+// RCCL, loaded on first use: a single-GPU context never touches it, and the library
+// stays loadable on machines without it.
+// ---------------------------------------------------------------------------------
+namespace {
+
+struct NcclId { char internal[128]; };
+typedef int (*InitRankFn)(void**, int, NcclId, int);
+
+struct RcclLib {
+    void* handle = nullptr;
+    int (*GetUniqueId)(NcclId*) = nullptr;
+    InitRankFn CommInitRank = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+constexpr int kNcclChar = 0;   // ncclInt8 / ncclChar
+
+RcclLib* rccl_lib(std::string& err)
+{
+    static RcclLib lib;
+    static bool tried = false;
+    if (lib.handle) return &lib;
+    if (tried) { err = "librccl.so could not be loaded"; return nullptr; }
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        lib.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (lib.handle) break;
+    }
+    if (!lib.handle) { err = std::string("dlopen(librccl): ") + dlerror(); return nullptr; }
+    bool ok = true;
+    auto sym = [&](const char* name) {
+        void* p = dlsym(lib.handle, name);
+        if (!p) ok = false;
+        return p;
+    };
+    lib.GetUniqueId = (int (*)(NcclId*))sym("ncclGetUniqueId");
+    lib.CommInitRank = (InitRankFn)sym("ncclCommInitRank");
+    lib.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+    lib.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
+    lib.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
+    lib.GroupStart = (int (*)())sym("ncclGroupStart");
+    lib.GroupEnd = (int (*)())sym("ncclGroupEnd");
+    lib.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    if (!ok) {
+        err = "librccl.so lacks a required symbol";
+        dlclose(lib.handle);
+        lib.handle = nullptr;
+        return nullptr;
+    }
+    return &lib;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+            return RF_ERR_DEVICE;                                                          \
+        }                                                                                  \
+    } while (0)
+
+#define NCCL_TRY(lib, expr)                                                                \
+    do {                                                                                   \
+        int r_ = (expr);                                                                   \
+        if (r_ != 0) {                                                                     \
+            set_error(std::string(#expr) + ": " + (lib)->GetErrorString(r_));              \
+            return RF_ERR_DEVICE;                                                          \
+        }                                                                                  \
+    } while (0)
+
+rf_status fail(rf_status st, const std::string& msg)
+{
+    set_error(msg);
+    return st;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+bool is_point_kind(int kind) { return kind == OP_PASSTHROUGH || kind == OP_GRADE; }
+
+RcclLib* ctx_rccl(const rf_ctx* ctx) { return (RcclLib*)ctx->rccl; }
+
+int strip_rows_of(const rf_graph* g) { return g->strip_y1 - g->strip_y0; }
+
+// clamp bounds / output rows of a launch in local rows
+Geom launch_geom(const rf_graph* g, const Launch& L)
+{
+    const int Hs = strip_rows_of(g), H = g->opt.height;
+    Geom geo;
+    geo.W = g->opt.width;
+    geo.row_lo = std::max(-L.need_src, -g->strip_y0);
+    geo.row_hi = std::min(Hs - 1 + L.need_src, H - 1 - g->strip_y0);
+    geo.y0 = std::max(-L.need_dst, -g->strip_y0);
+    geo.y1 = std::min(Hs + L.need_dst, H - g->strip_y0);
+    return geo;
+}
+
+// neighbour exchange of `r` rows of `img` above and below the strip:
+// my top r rows -> rank-1's bottom ghost, my bottom r rows -> rank+1's top ghost.
+rf_status exchange_rows(rf_graph* g, const DeviceImage& img, int r, hipStream_t stream)
+{
+    rf_ctx* ctx = g->ctx;
+    if (ctx->world <= 1 || r <= 0) return RF_OK;
+    RcclLib* lib = ctx_rccl(ctx);
+    const int Hs = strip_rows_of(g);
+    const size_t bytes = (size_t)r * img.pitch;
+    NCCL_TRY(lib, lib->GroupStart());
+    if (ctx->rank > 0) {
+        NCCL_TRY(lib, lib->Send(img.base, bytes, kNcclChar, ctx->rank - 1, ctx->comm, stream));
+        NCCL_TRY(lib, lib->Recv(img.base - (ptrdiff_t)bytes, bytes, kNcclChar, ctx->rank - 1, ctx->comm, stream));
+    }
+    if (ctx->rank < ctx->world - 1) {
+        NCCL_TRY(lib, lib->Send(img.base + (size_t)(Hs - r) * img.pitch, bytes, kNcclChar, ctx->rank + 1, ctx->comm, stream));
+        NCCL_TRY(lib, lib->Recv(img.base + (size_t)Hs * img.pitch, bytes, kNcclChar, ctx->rank + 1, ctx->comm, stream));
+    }
+    NCCL_TRY(lib, lib->GroupEnd());
+    return RF_OK;
+}
+
+bool exchange_mode(const rf_graph* g) { return g->ctx->world > 1 && !(g->opt.flags & RF_GRAPH_NO_HALO_XCHG); }
+
+rf_status run_launch(rf_graph* g, FrameSlot& f, size_t li, hipStream_t stream, bool timers)
+{
+    const Launch& L = g->launches[li];
+    if (exchange_mode(g) && L.radius > 0) {
+        for (const auto& s : L.src) {
+            rf_status st = exchange_rows(g, f.images.at(s), L.radius, stream);
+            if (st != RF_OK) return st;
+        }
+    }
+    if (timers) HIP_TRY(hipEventRecord(f.t0[li], stream));
+    const Geom geo = launch_geom(g, L);
+    const DeviceImage& dst = f.images.at(L.dst);
+    if (L.ops.size() == 1 && L.ops[0].kind == OP_MIX) {
+        HIP_TRY(launch_mix(g->opt.format, f.images.at(L.src[0]).view(), f.images.at(L.src[1]).view(), dst.view(), geo,
+                           L.ops[0].slope, stream));
+    } else {
+        HIP_TRY(launch_ops(g->opt.format, L.ops.data(), (int)L.ops.size(), f.images.at(L.src[0]).view(), dst.view(), geo,
+                           g->tune, stream));
+    }
+    if (timers) HIP_TRY(hipEventRecord(f.t1[li], stream));
+    return RF_OK;
+}
+
+// command::execute_pipeline_graph, command.rs:166-242: layer by layer; the nodes of a
+// layer are independent and run on side streams; the per-layer barrier
+// (command.rs:226-240) is the fork/join event pair.
+rf_status issue_frame(rf_graph* g, FrameSlot& f, bool timers)
+{
+    size_t li = 0;
+    while (li < g->launches.size()) {
+        size_t end = li;
+        while (end < g->launches.size() && g->launches[end].layer == g->launches[li].layer) ++end;
+        const size_t m = end - li;
+        if (m == 1) {
+            rf_status st = run_launch(g, f, li, f.stream, timers);
+            if (st != RF_OK) return st;
+        } else {
+            HIP_TRY(hipEventRecord(f.fork, f.stream));
+            for (size_t j = 0; j < m; ++j) {
+                hipStream_t s = j == 0 ? f.stream : f.aux[j - 1];
+                if (j > 0) HIP_TRY(hipStreamWaitEvent(s, f.fork, 0));
+                rf_status st = run_launch(g, f, li + j, s, timers);
+                if (st != RF_OK) return st;
+                if (j > 0) {
+                    HIP_TRY(hipEventRecord(f.join[j - 1], s));
+                    HIP_TRY(hipStreamWaitEvent(f.stream, f.join[j - 1], 0));
+                }
+            }
+        }
+        li = end;
+    }
+    return RF_OK;
+}
+
+void rebuild_ops(rf_graph* g)
+{
+    for (auto& L : g->launches) {
+        L.ops.clear();
+        for (const auto& m : L.members) {
+            const NodeParams& np = g->plan.plan.nodes.at(m);
+            auto it = g->dev_weights.find(m);
+            L.ops.push_back(np.to_op(it == g->dev_weights.end() ? nullptr : it->second));
+        }
+        L.radius = ops_radius(L.ops.data(), (int)L.ops.size());
+    }
+}
+
+void destroy_graph_exec(FrameSlot& f)
+{
+    if (f.graph_exec) { (void)hipGraphExecDestroy(f.graph_exec); f.graph_exec = nullptr; }
+    if (f.graph) { (void)hipGraphDestroy(f.graph); f.graph = nullptr; }
+}
+
+void fill_plan_views(rf_plan& p)
+{
+    p.launch_labels = p.plan.launch_order();
+    p.aliases.assign(p.plan.reuse.begin(), p.plan.reuse.end());
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// Context
+// ---------------------------------------------------------------------------------
+static rf_status ctx_create_common(int device, rf_ctx** out)
+{
+    if (!out) return fail(RF_ERR_INVALID, "rf_ctx_create: null out pointer");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(RF_ERR_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                                          " (librfhip has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(RF_ERR_INVALID, "rf_ctx_create: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    std::string arch = prop.gcnArchName;
+    if (arch.compare(0, 6, "gfx950") != 0)
+        return fail(RF_ERR_NO_DEVICE, "device " + std::to_string(device) + " is " + arch + "; librfhip is built for gfx950 (MI355X) only");
+    rf_ctx* ctx = new rf_ctx();
+    ctx->device = device;
+    ctx->arch = arch.substr(0, arch.find(':'));
+    if (hipStreamCreateWithFlags(&ctx->util_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return fail(RF_ERR_DEVICE, "hipStreamCreate failed");
+    }
+    float tables[256 + 255];
+    srgb_tables(tables, tables + 256);
+    if (hipMalloc((void**)&ctx->d_tables, sizeof(tables)) != hipSuccess ||
+        hipMemcpy(ctx->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess) {
+        rf_ctx_destroy(ctx);
+        return fail(RF_ERR_DEVICE, "sRGB table upload failed");
+    }
+    *out = ctx;
+    return RF_OK;
+}
+
+extern "C" rf_status rf_ctx_create(int device, rf_ctx** out) { return ctx_create_common(device, out); }
+
+extern "C" rf_status rf_comm_unique_id(void* id128)
+{
+    if (!id128) return fail(RF_ERR_INVALID, "rf_comm_unique_id: null buffer");
+    std::string err;
+    RcclLib* lib = rccl_lib(err);
+    if (!lib) return fail(RF_ERR_DEVICE, err);
+    NcclId id;
+    NCCL_TRY(lib, lib->GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+    return RF_OK;
+}
+
+extern "C" rf_status rf_ctx_create_dist(int device, int rank, int world, const void* id128, rf_ctx** out)
+{
+    if (world < 1 || rank < 0 || rank >= world) return fail(RF_ERR_INVALID, "rf_ctx_create_dist: bad rank/world");
+    rf_status st = ctx_create_common(device, out);
+    if (st != RF_OK) return st;
+    rf_ctx* ctx = *out;
+    ctx->rank = rank;
+    ctx->world = world;
+    if (world == 1) return RF_OK;
+    if (!id128) { rf_ctx_destroy(ctx); *out = nullptr; return fail(RF_ERR_INVALID, "rf_ctx_create_dist: null unique id"); }
+    std::string err;
+    RcclLib* lib = rccl_lib(err);
+    if (!lib) { rf_ctx_destroy(ctx); *out = nullptr; return fail(RF_ERR_DEVICE, err); }
+    ctx->rccl = (const RcclApi*)lib;
+    NcclId id;
+    std::memcpy(&id, id128, sizeof(id));
+    int r = lib->CommInitRank(&ctx->comm, world, id, rank);
+    if (r != 0) {
+        std::string msg = std::string("ncclCommInitRank: ") + lib->GetErrorString(r);
+        ctx->comm = nullptr;
+        rf_ctx_destroy(ctx);
+        *out = nullptr;
+        return fail(RF_ERR_DEVICE, msg);
+    }
+    return RF_OK;
+}
+
+extern "C" void rf_ctx_destroy(rf_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->comm && ctx->rccl) ctx_rccl(ctx)->CommDestroy(ctx->comm);
+    if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->util_stream) (void)hipStreamDestroy(ctx->util_stream);
+    delete ctx;
+}
+
+extern "C" rf_status rf_ctx_synchronize(rf_ctx* ctx)
+{
+    if (!ctx) return fail(RF_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return RF_OK;
+}
+
+extern "C" int rf_ctx_rank(const rf_ctx* ctx) { return ctx ? ctx->rank : -1; }
+extern "C" int rf_ctx_world(const rf_ctx* ctx) { return ctx ? ctx->world : -1; }
+extern "C" const char* rf_ctx_device_arch(const rf_ctx* ctx) { return ctx ? ctx->arch.c_str() : ""; }
+
+extern "C" rf_status rf_ctx_copy_bandwidth(rf_ctx* ctx, size_t bytes, int iters, float* gbps)
+{
+    if (!ctx || !gbps || iters < 1 || bytes < 16) return fail(RF_ERR_INVALID, "rf_ctx_copy_bandwidth: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    rf_status st = RF_OK;
+    float ms = 0.f;
+    auto body = [&]() -> rf_status {
+        HIP_TRY(hipMalloc(&a, bytes));
+        HIP_TRY(hipMalloc(&b, bytes));
+        HIP_TRY(hipMemsetAsync(a, 0x3c, bytes, ctx->util_stream));
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        for (int i = 0; i < 3; ++i) HIP_TRY(launch_copy(a, b, bytes, ctx->util_stream));
+        HIP_TRY(hipEventRecord(e0, ctx->util_stream));
+        for (int i = 0; i < iters; ++i) HIP_TRY(launch_copy(a, b, bytes, ctx->util_stream));
+        HIP_TRY(hipEventRecord(e1, ctx->util_stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        return RF_OK;
+    };
+    st = body();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (st != RF_OK) return st;
+    *gbps = (float)(2.0 * (double)(bytes / 16 * 16) * iters / ((double)ms * 1e-3) / 1e9);
+    return RF_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// Graph
+// ---------------------------------------------------------------------------------
+static rf_status graph_build(rf_graph* g, const rf_config* cfg)
+{
+    rf_ctx* ctx = g->ctx;
+    const rf_graph_options& opt = g->opt;
+    std::string err;
+    if (!build_plan(cfg->cfg, opt.flags, g->plan.plan, err)) return fail(RF_ERR_GRAPH, err);
+    fill_plan_views(g->plan);
+    const Plan& plan = g->plan.plan;
+
+    strip_rows(opt.height, ctx->world, ctx->rank, g->strip_y0, g->strip_y1);
+    const int Hs = strip_rows_of(g);
+    if (Hs < 1) return fail(RF_ERR_INVALID, "frame has fewer rows than ranks");
+
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    // conv2d weight buffers (default weights; rf_graph_set_weights overrides)
+    for (const auto& kv : plan.nodes) {
+        if (kv.second.type->kind != OP_CONV2D) continue;
+        const int K = kv.second.conv_ksize();
+        std::vector<float> w((size_t)K * K);
+        auto it = kv.second.values.find("sigma");
+        default_conv_weights(K, it == kv.second.values.end() ? 0.f : it->second.f, w.data());
+        float* d = nullptr;
+        HIP_TRY(hipMalloc((void**)&d, w.size() * sizeof(float)));
+        g->dev_weights[kv.first] = d;
+        HIP_TRY(hipMemcpy(d, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+
+    // launches in execution order
+    for (size_t layer = 0; layer < plan.layers.size(); ++layer) {
+        for (const auto& unit : plan.layers[layer]) {
+            const PipelineInfo& info = plan.infos.at(unit);
+            if (info.output_images.empty()) continue;   // nothing observable is written
+            Launch L;
+            L.label = unit;
+            L.members = info.members;
+            L.layer = (int)layer;
+            const int kind0 = plan.nodes.at(info.members[0]).type->kind;
+            if (info.input_images.empty())
+                return fail(RF_ERR_GRAPH, "node '" + unit + "' has no input image (a graph must start at 'input')");
+            if (kind0 == OP_MIX) {
+                std::string a, b;
+                for (const auto& in : info.input_images) {
+                    if (in.second == 0) a = in.first;
+                    if (in.second == 1) b = in.first;
+                }
+                if (a.empty() || b.empty() || info.input_images.size() != 2)
+                    return fail(RF_ERR_GRAPH, "node '" + unit + "' needs exactly input_image0 and input_image1");
+                L.src = {plan.resolve(a), plan.resolve(b)};
+            } else {
+                if (info.input_images.size() != 1)
+                    return fail(RF_ERR_GRAPH, "node '" + unit + "' takes one input image, the graph wires " +
+                                                  std::to_string(info.input_images.size()));
+                L.src = {plan.resolve(info.input_images[0].first)};
+            }
+            if (info.output_images.size() != 1)
+                return fail(RF_ERR_GRAPH, "node '" + unit + "' writes one output image, the graph wires " +
+                                              std::to_string(info.output_images.size()));
+            L.dst = plan.resolve(info.output_images[0].first);
+            for (const auto& s : L.src)
+                if (std::find(plan.images.begin(), plan.images.end(), s) == plan.images.end())
+                    return fail(RF_ERR_GRAPH, "No image found for input " + s);   // pipeline_graph.rs:236
+            g->launches.push_back(L);
+        }
+    }
+    rebuild_ops(g);
+    for (const auto& L : g->launches) {
+        bool all_point = true;
+        for (const auto& op : L.ops) all_point = all_point && is_point_kind(op.kind);
+        if (L.ops.size() == 1 && L.ops[0].kind == OP_MIX) continue;
+        if (L.src[0] == L.dst && !all_point)
+            return fail(RF_ERR_GRAPH, "node '" + L.label + "' would run a stencil in place");
+    }
+
+    // ghost rows: what each launch reads beyond the strip
+    g->ghost = 0;
+    g->need_input = 0;
+    g->input_image = std::find(plan.images.begin(), plan.images.end(), kFileInput) != plan.images.end() ? kFileInput : "";
+    g->output_image = plan.resolve(kFinalOutput);
+    if (std::find(plan.images.begin(), plan.images.end(), g->output_image) == plan.images.end())
+        return fail(RF_ERR_GRAPH, "the graph never writes rf:final-output");
+    if (ctx->world > 1) {
+        if (exchange_mode(g)) {
+            for (auto& L : g->launches) {
+                L.need_src = L.radius;
+                L.need_dst = 0;
+                g->ghost = std::max(g->ghost, L.radius);
+            }
+        } else {
+            std::map<std::string, int> need;
+            for (size_t k = g->launches.size(); k-- > 0;) {
+                Launch& L = g->launches[k];
+                int nd = 0;
+                auto it = need.find(L.dst);
+                if (it != need.end()) { nd = it->second; need.erase(it); }
+                L.need_dst = nd;
+                L.need_src = nd + L.radius;
+                for (const auto& s : L.src) need[s] = std::max(need.count(s) ? need[s] : 0, L.need_src);
+                g->ghost = std::max(g->ghost, L.need_src);
+            }
+            if (!g->input_image.empty() && need.count(g->input_image)) g->need_input = need[g->input_image];
+        }
+        int min_rows = opt.height / ctx->world;
+        if (g->ghost > min_rows)
+            return fail(RF_ERR_UNSUPPORTED, "strip height " + std::to_string(min_rows) + " is smaller than the halo " + std::to_string(g->ghost));
+    } else {
+        for (auto& L : g->launches) { L.need_src = L.radius; L.need_dst = 0; }
+    }
+
+    if (const char* e = std::getenv("RF_ROWS_PER_CHUNK")) g->tune.rows_per_chunk = std::atoi(e);
+
+    // per-frame images, streams, events (PipelineGraphFrame::new, Frame::new)
+    const size_t pitch = align_up((size_t)opt.width * bytes_per_pixel(opt.format), 256);
+    size_t max_layer = 1;
+    {
+        std::map<int, size_t> per_layer;
+        for (const auto& L : g->launches) max_layer = std::max(max_layer, ++per_layer[L.layer]);
+    }
+    const bool timers = (opt.flags & RF_GRAPH_TIMERS) != 0;
+    g->frames.resize((size_t)opt.num_frames);
+    for (auto& f : g->frames) {
+        for (const auto& name : plan.images) {
+            DeviceImage img;
+            img.pitch = pitch;
+            const size_t rows = (size_t)Hs + 2 * (size_t)g->ghost;
+            HIP_TRY(hipMalloc(&img.alloc, rows * pitch));
+            img.base = (char*)img.alloc + (size_t)g->ghost * pitch;
+            f.images[name] = img;
+        }
+        HIP_TRY(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
+        for (size_t j = 1; j < max_layer; ++j) {
+            hipStream_t s;
+            hipEvent_t e;
+            HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            f.aux.push_back(s);
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            f.join.push_back(e);
+        }
+        HIP_TRY(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(f.done, f.stream));   // fences are created SIGNALED (frame.rs:47)
+        if (timers) {
+            for (size_t k = 0; k < g->launches.size(); ++k) {
+                hipEvent_t a, b;
+                HIP_TRY(hipEventCreate(&a));
+                HIP_TRY(hipEventCreate(&b));
+                f.t0.push_back(a);
+                f.t1.push_back(b);
+            }
+        }
+    }
+    return RF_OK;
+}
+
+extern "C" rf_status rf_graph_create(rf_ctx* ctx, const rf_config* cfg, const rf_graph_options* opt, rf_graph** out)
+{
+    if (!ctx || !cfg || !opt || !out) return fail(RF_ERR_INVALID, "rf_graph_create: null argument");
+    *out = nullptr;
+    if (opt->width < 1 || opt->height < 1) return fail(RF_ERR_INVALID, "rf_graph_create: width and height must be >= 1");
+    if (opt->format != RF_FORMAT_RGBA8 && opt->format != RF_FORMAT_RGBA32F) return fail(RF_ERR_INVALID, "rf_graph_create: unknown format");
+    if (opt->num_frames < 1) return fail(RF_ERR_INVALID, "rf_graph_create: num_frames must be >= 1");
+    rf_graph* g = new rf_graph();
+    g->ctx = ctx;
+    g->opt = *opt;
+    rf_status st = graph_build(g, cfg);
+    if (st != RF_OK) {
+        std::string keep = last_error();
+        rf_graph_destroy(g);
+        set_error(keep);
+        return st;
+    }
+    *out = g;
+    return RF_OK;
+}
+
+extern "C" void rf_graph_destroy(rf_graph* g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipDeviceSynchronize();   // pipeline_graph.rs:610
+    for (auto& f : g->frames) {
+        destroy_graph_exec(f);
+        for (auto& kv : f.images)
+            if (kv.second.alloc) (void)hipFree(kv.second.alloc);
+        for (auto e : f.t0) (void)hipEventDestroy(e);
+        for (auto e : f.t1) (void)hipEventDestroy(e);
+        for (auto e : f.join) (void)hipEventDestroy(e);
+        if (f.fork) (void)hipEventDestroy(f.fork);
+        if (f.done) (void)hipEventDestroy(f.done);
+        for (auto s : f.aux) (void)hipStreamDestroy(s);
+        if (f.stream) (void)hipStreamDestroy(f.stream);
+    }
+    for (auto& kv : g->dev_weights) (void)hipFree(kv.second);
+    if (g->d_staging) (void)hipFree(g->d_staging);
+    delete g;
+}
+
+extern "C" const rf_plan* rf_graph_plan(const rf_graph* g) { return g ? &g->plan : nullptr; }
+
+extern "C" rf_status rf_graph_strip(const rf_graph* g, int* y0, int* y1)
+{
+    if (!g || !y0 || !y1) return fail(RF_ERR_INVALID, "rf_graph_strip: null argument");
+    *y0 = g->strip_y0;
+    *y1 = g->strip_y1;
+    return RF_OK;
+}
+
+static void invalidate_captures(rf_graph* g)
+{
+    for (auto& f : g->frames) {
+        (void)hipStreamSynchronize(f.stream);
+        destroy_graph_exec(f);
+    }
+}
+
+extern "C" rf_status rf_graph_set_param(rf_graph* g, const char* node, const char* name, rf_param_type type, const void* value)
+{
+    if (!g || !node || !name || !value) return fail(RF_ERR_INVALID, "rf_graph_set_param: null argument");
+    auto it = g->plan.plan.nodes.find(node);
+    if (it == g->plan.plan.nodes.end()) return fail(RF_ERR_INVALID, std::string("no node named '") + node + "'");
+    NodeParams& np = it->second;
+    const ParamDef* pd = np.type->param(name);
+    if (!pd) return fail(RF_WARN_UNKNOWN_PARAM, std::string("node type '") + np.type->name + "' has no parameter '" + name + "'");
+    double v = 0.0;
+    switch (type) {
+        case RF_PARAM_F32: v = *(const float*)value; break;
+        case RF_PARAM_I32: v = *(const int32_t*)value; break;
+        case RF_PARAM_BOOL: v = *(const int32_t*)value ? 1.0 : 0.0; break;
+        default: return fail(RF_ERR_INVALID, "rf_graph_set_param: bad type");
+    }
+    ParamValue nv;
+    nv.i = 0;
+    if (pd->type == PARAM_F32) nv.f = (type == RF_PARAM_F32) ? *(const float*)value : (float)v;
+    else if (pd->type == PARAM_I32) nv.i = (int32_t)v;
+    else nv.b = v != 0.0 ? 1 : 0;
+    const ParamValue old = np.values[name];
+    const Op before = np.to_op(nullptr);
+    np.values[name] = nv;
+    const Op after = np.to_op(nullptr);
+    if (before.radius != after.radius) {
+        // changes the halo, the fusion pattern and possibly the allocation: the reference
+        // rebuilds the whole graph on such edits (recreate_graph, render.rs:121-136)
+        np.values[name] = old;
+        return fail(RF_ERR_UNSUPPORTED, std::string("parameter '") + name + "' changes the stencil radius: destroy and re-create the graph");
+    }
+    invalidate_captures(g);
+    rebuild_ops(g);
+    return RF_OK;
+}
+
+extern "C" rf_status rf_graph_set_weights(rf_graph* g, const char* node, const float* weights, int count)
+{
+    if (!g || !node || !weights) return fail(RF_ERR_INVALID, "rf_graph_set_weights: null argument");
+    auto it = g->dev_weights.find(node);
+    if (it == g->dev_weights.end()) return fail(RF_ERR_INVALID, std::string("node '") + node + "' is not a conv2d node");
+    const int K = g->plan.plan.nodes.at(node).conv_ksize();
+    if (count != K * K) return fail(RF_ERR_INVALID, "rf_graph_set_weights: expected " + std::to_string(K * K) + " weights");
+    HIP_TRY(hipSetDevice(g->ctx->device));
+    for (auto& f : g->frames) HIP_TRY(hipStreamSynchronize(f.stream));
+    HIP_TRY(hipMemcpy(it->second, weights, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
+    return RF_OK;
+}
+
+extern "C" rf_status rf_graph_set_time(rf_graph* g, float seconds)
+{
+    if (!g) return fail(RF_ERR_INVALID, "null graph");
+    bool any = false;
+    for (auto& kv : g->plan.plan.nodes) {
+        for (auto& pv : kv.second.values) {
+            const std::string& n = pv.first;
+            if (n.size() >= 8 && n.compare(n.size() - 8, 8, "_rf_time") == 0) { pv.second.f = seconds; any = true; }
+        }
+    }
+    if (any) { invalidate_captures(g); rebuild_ops(g); }
+    return RF_OK;
+}
+
+// ---- input -----------------------------------------------------------------------
+static rf_status after_input_write(rf_graph* g, FrameSlot& f, hipStream_t stream)
+{
+    // over-fetch mode: the neighbours' rows the whole frame will read, exchanged once
+    if (g->ctx->world > 1 && !exchange_mode(g) && g->need_input > 0)
+        return exchange_rows(g, f.images.at(g->input_image), g->need_input, stream);
+    return RF_OK;
+}
+
+static rf_status need_input(rf_graph* g, const char* who)
+{
+    if (!g) return fail(RF_ERR_INVALID, std::string(who) + ": null graph");
+    if (g->input_image.empty()) return fail(RF_ERR_INVALID, std::string(who) + ": the graph has no 'input'");
+    HIP_TRY(hipSetDevice(g->ctx->device));
+    return RF_OK;
+}
+
+extern "C" rf_status rf_graph_upload_raw(rf_graph* g, const void* texels, size_t row_stride)
+{
+    rf_status st = need_input(g, "rf_graph_upload_raw");
+    if (st != RF_OK) return st;
+    if (!texels) return fail(RF_ERR_INVALID, "rf_graph_upload_raw: null buffer");
+    const size_t row_bytes = (size_t)g->opt.width * bytes_per_pixel(g->opt.format);
+    if (row_stride < row_bytes) return fail(RF_ERR_INVALID, "rf_graph_upload_raw: row_stride smaller than a row");
+    for (auto& f : g->frames) {
+        const DeviceImage& img = f.images.at(g->input_image);
+        HIP_TRY(hipMemcpy2DAsync(img.base, img.pitch, texels, row_stride, row_bytes, (size_t)strip_rows_of(g), hipMemcpyHostToDevice, f.stream));
+        st = after_input_write(g, f, f.stream);
+        if (st != RF_OK) return st;
+        HIP_TRY(hipStreamSynchronize(f.stream));   // the caller's buffer is free on return
+    }
+    return RF_OK;
+}
+
+extern "C" rf_status rf_graph_upload_srgb8(rf_graph* g, const uint8_t* rgba, size_t row_stride)
+{
+    rf_status st = need_input(g, "rf_graph_upload_srgb8");
+    if (st != RF_OK) return st;
+    if (!rgba) return fail(RF_ERR_INVALID, "rf_graph_upload_srgb8: null buffer");
+    const size_t row_bytes = (size_t)g->opt.width * 4;
+    if (row_stride < row_bytes) return fail(RF_ERR_INVALID, "rf_graph_upload_srgb8: row_stride smaller than a row");
+    const int Hs = strip_rows_of(g);
+    const size_t need = row_bytes * (size_t)Hs;   // staging buffer, render.rs:552
+    if (g->staging_bytes < need) {
+        if (g->d_staging) (void)hipFree(g->d_staging);
+        g->d_staging = nullptr;
+        g->staging_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&g->d_staging, need));
+        g->staging_bytes = need;
+    }
+    for (auto& f : g->frames) {
+        HIP_TRY(hipMemcpy2DAsync(g->d_staging, row_bytes, rgba, row_stride, row_bytes, (size_t)Hs, hipMemcpyHostToDevice, f.stream));
+        HIP_TRY(launch_upload_srgb8(g->opt.format, g->d_staging, row_bytes, f.images.at(g->input_image).view(), g->opt.width, Hs,
+                                    g->ctx->d_tables, f.stream));
+        st = after_input_write(g, f, f.stream);
+        if (st != RF_OK) return st;
+        HIP_TRY(hipStreamSynchronize(f.stream));
+    }
+    return RF_OK;
+}
+
+static void fill_rows(const rf_graph* g, int& lo, int& hi)
+{
+    // generated fills can write the ghost rows directly: no exchange needed
+    const int Hs = g->strip_y1 - g->strip_y0, need = g->ctx->world > 1 ? g->ghost : 0;
+    lo = std::max(-need, -g->strip_y0);
+    hi = std::min(Hs + need, g->opt.height - g->strip_y0);
+}
+
+extern "C" rf_status rf_graph_fill_synthetic(rf_graph* g, uint32_t seed)
+{
+    rf_status st = need_input(g, "rf_graph_fill_synthetic");
+    if (st != RF_OK) return st;
+    int lo, hi;
+    fill_rows(g, lo, hi);
+    for (auto& f : g->frames) {
+        HIP_TRY(launch_fill_synthetic(g->opt.format, f.images.at(g->input_image).view(), g->opt.width, lo, hi, g->strip_y0, seed, f.stream));
+        HIP_TRY(hipStreamSynchronize(f.stream));
+    }
+    return RF_OK;
+}
+
+extern "C" rf_status rf_graph_fill_structured(rf_graph* g)
+{
+    rf_status st = need_input(g, "rf_graph_fill_structured");
+    if (st != RF_OK) return st;
+    int lo, hi;
+    fill_rows(g, lo, hi);
+    for (auto& f : g->frames) {
+        HIP_TRY(launch_fill_structured(g->opt.format, f.images.at(g->input_image).view(), g->opt.width, lo, hi, g->strip_y0, g->opt.height, f.stream));
+        HIP_TRY(hipStreamSynchronize(f.stream));
+    }
+    return RF_OK;
+}
+
+// ---- execute -----------------------------------------------------------------------
+static rf_status slot_of(rf_graph* g, int slot, FrameSlot** out, const char* who)
+{
+    if (!g) return fail(RF_ERR_INVALID, std::string(who) + ": null graph");
+    if (slot < 0 || slot >= (int)g->frames.size()) return fail(RF_ERR_INVALID, std::string(who) + ": frame slot out of range");
+    HIP_TRY(hipSetDevice(g->ctx->device));
+    *out = &g->frames[(size_t)slot];
+    return RF_OK;
+}
+
+static bool use_hipgraph(const rf_graph* g)
+{
+    return (g->opt.flags & RF_GRAPH_HIPGRAPH) && !(g->opt.flags & RF_GRAPH_TIMERS) && g->ctx->world == 1;
+}
+
+static rf_status submit_frame(rf_graph* g, FrameSlot& f)
+{
+    const bool timers = (g->opt.flags & RF_GRAPH_TIMERS) != 0;
+    if (use_hipgraph(g)) {
+        if (!f.graph_exec) {
+            HIP_TRY(hipStreamBeginCapture(f.stream, hipStreamCaptureModeThreadLocal));
+            rf_status st = issue_frame(g, f, false);
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamEndCapture(f.stream, &graph);
+            if (st != RF_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+            if (e != hipSuccess) return fail(RF_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            f.graph = graph;
+            HIP_TRY(hipGraphInstantiate(&f.graph_exec, graph, nullptr, nullptr, 0));
+        }
+        HIP_TRY(hipGraphLaunch(f.graph_exec, f.stream));
+        return RF_OK;
+    }
+    rf_status st = issue_frame(g, f, timers);
+    if (st == RF_OK && timers) f.timed_once = true;
+    return st;
+}
+
+extern "C" rf_status rf_graph_execute(rf_graph* g, int frame_slot)
+{
+    FrameSlot* f;
+    rf_status st = slot_of(g, frame_slot, &f, "rf_graph_execute");
+    if (st != RF_OK) return st;
+    st = submit_frame(g, *f);
+    if (st != RF_OK) return st;
+    HIP_TRY(hipEventRecord(f->done, f->stream));
+    return RF_OK;
+}
+
+extern "C" rf_status rf_graph_wait(rf_graph* g, int frame_slot)
+{
+    FrameSlot* f;
+    rf_status st = slot_of(g, frame_slot, &f, "rf_graph_wait");
+    if (st != RF_OK) return st;
+    HIP_TRY(hipEventSynchronize(f->done));
+    return RF_OK;
+}
+
+// ---- output ------------------------------------------------------------------------
+static rf_status download_image(rf_graph* g, FrameSlot& f, const std::string& name, void* texels, size_t row_stride)
+{
+    const size_t row_bytes = (size_t)g->opt.width * bytes_per_pixel(g->opt.format);
+    if (!texels) return fail(RF_ERR_INVALID, "download: null buffer");
+    if (row_stride < row_bytes) return fail(RF_ERR_INVALID, "download: row_stride smaller than a row");
+    auto it = f.images.find(name);
+    if (it == f.images.end()) return fail(RF_ERR_INVALID, "no image named '" + name + "'");
+    HIP_TRY(hipStreamSynchronize(f.stream));
+    HIP_TRY(hipMemcpy2D(texels, row_stride, it->second.base, it->second.pitch, row_bytes, (size_t)strip_rows_of(g), hipMemcpyDeviceToHost));
+    return RF_OK;
+}
+
+extern "C" rf_status rf_graph_download_raw(rf_graph* g, int frame_slot, void* texels, size_t row_stride)
+{
+    FrameSlot* f;
+    rf_status st = slot_of(g, frame_slot, &f, "rf_graph_download_raw");
+    if (st != RF_OK) return st;
+    return download_image(g, *f, g->output_image, texels, row_stride);
+}
+
+extern "C" rf_status rf_graph_download_image(rf_graph* g, int frame_slot, const char* resource, void* texels, size_t row_stride)
+{
+    FrameSlot* f;
+    rf_status st = slot_of(g, frame_slot, &f, "rf_graph_download_image");
+    if (st != RF_OK) return st;
+    if (!resource) return fail(RF_ERR_INVALID, "rf_graph_download_image: null resource name");
+    return download_image(g, *f, g->plan.plan.resolve(resource), texels, row_stride);
+}
+
+extern "C" rf_status rf_graph_download_srgb8(rf_graph* g, int frame_slot, uint8_t* rgba, size_t row_stride)
+{
+    FrameSlot* f;
+    rf_status st = slot_of(g, frame_slot, &f, "rf_graph_download_srgb8");
+    if (st != RF_OK) return st;
+    if (!rgba) return fail(RF_ERR_INVALID, "rf_graph_download_srgb8: null buffer");
+    const size_t row_bytes = (size_t)g->opt.width * 4;
+    if (row_stride < row_bytes) return fail(RF_ERR_INVALID, "rf_graph_download_srgb8: row_stride smaller than a row");
+    const int Hs = strip_rows_of(g);
+    const size_t need = row_bytes * (size_t)Hs;
+    if (g->staging_bytes < need) {
+        if (g->d_staging) (void)hipFree(g->d_staging);
+        g->d_staging = nullptr;
+        g->staging_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&g->d_staging, need));
+        g->staging_bytes = need;
+    }
+    HIP_TRY(launch_download_srgb8(g->opt.format, f->images.at(g->output_image).view(), g->d_staging, row_bytes, g->opt.width, Hs,
+                                  g->ctx->d_tables, f->stream));
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    HIP_TRY(hipMemcpy2D(rgba, row_stride, g->d_staging, row_bytes, row_bytes, (size_t)Hs, hipMemcpyDeviceToHost));
+    return RF_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------
+extern "C" rf_status rf_graph_node_times(rf_graph* g, int frame_slot, const char** names, float* ms, int* n)
+{
+    FrameSlot* f;
+    rf_status st = slot_of(g, frame_slot, &f, "rf_graph_node_times");
+    if (st != RF_OK) return st;
+    if (!n) return fail(RF_ERR_INVALID, "rf_graph_node_times: null count");
+    if (!(g->opt.flags & RF_GRAPH_TIMERS)) return fail(RF_ERR_INVALID, "graph was created without RF_GRAPH_TIMERS");
+    const int cap = *n;
+    *n = 0;
+    if (!f->timed_once) return RF_OK;   // no frame recorded yet (current_query_index == 0, vkutils.rs:107-109)
+    HIP_TRY(hipEventSynchronize(f->done));
+    std::vector<std::pair<std::string, float>> rows;
+    for (size_t k = 0; k < g->launches.size(); ++k) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, f->t0[k], f->t1[k]));
+        rows.push_back({g->launches[k].label, t});
+    }
+    std::sort(rows.begin(), rows.end());   // BTreeMap order, vkutils.rs:50
+    g->time_names.clear();
+    for (auto& r : rows) g->time_names.push_back(r.first);
+    int count = 0;
+    for (size_t k = 0; k < rows.size() && count < cap; ++k, ++count) {
+        if (names) names[count] = g->time_names[k].c_str();
+        if (ms) ms[count] = rows[k].second;
+    }
+    *n = count;
+    return RF_OK;
+}
+
+extern "C" rf_status rf_graph_times_string(rf_graph* g, int frame_slot, char* buf, size_t cap)
+{
+    if (!buf || cap == 0) return fail(RF_ERR_INVALID, "rf_graph_times_string: null buffer");
+    buf[0] = 0;
+    const char* names[256];
+    float ms[256];
+    int n = 256;
+    rf_status st = rf_graph_node_times(g, frame_slot, names, ms, &n);
+    if (st != RF_OK) return st;
+    std::string s;
+    char tmp[64];
+    for (int i = 0; i < n; ++i) {   // "{}: {:.3}ms, " vkutils.rs:126
+        std::snprintf(tmp, sizeof(tmp), "%.3fms", ms[i]);
+        s += std::string(names[i]) + ": " + tmp + (i + 1 < n ? ", " : "");
+    }
+    std::snprintf(buf, cap, "%s", s.c_str());
+    return RF_OK;
+}
+
+extern "C" rf_status rf_graph_time_frames(rf_graph* g, int iters, float* total_ms)
+{
+    FrameSlot* f;
+    rf_status st = slot_of(g, 0, &f, "rf_graph_time_frames");
+    if (st != RF_OK) return st;
+    if (iters < 1 || !total_ms) return fail(RF_ERR_INVALID, "rf_graph_time_frames: bad argument");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto body = [&]() -> rf_status {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, f->stream));
+        for (int i = 0; i < iters; ++i) {
+            rf_status s2 = submit_frame(g, *f);
+            if (s2 != RF_OK) return s2;
+        }
+        HIP_TRY(hipEventRecord(e1, f->stream));
+        HIP_TRY(hipEventRecord(f->done, f->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(total_ms, e0, e1));
+        return RF_OK;
+    };
+    st = body();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return st;
+}
+
+extern "C" rf_status rf_graph_time_launch(rf_graph* g, int launch, int iters, float* avg_ms)
+{
+    FrameSlot* f;
+    rf_status st = slot_of(g, 0, &f, "rf_graph_time_launch");
+    if (st != RF_OK) return st;
+    if (launch < 0 || launch >= (int)g->launches.size() || iters < 1 || !avg_ms) return fail(RF_ERR_INVALID, "rf_graph_time_launch: bad argument");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0.f;
+    auto body = [&]() -> rf_status {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        const Launch& L = g->launches[(size_t)launch];
+        const Geom geo = launch_geom(g, L);
+        auto once = [&]() -> hipError_t {
+            if (L.ops.size() == 1 && L.ops[0].kind == OP_MIX)
+                return launch_mix(g->opt.format, f->images.at(L.src[0]).view(), f->images.at(L.src[1]).view(), f->images.at(L.dst).view(), geo,
+                                  L.ops[0].slope, f->stream);
+            return launch_ops(g->opt.format, L.ops.data(), (int)L.ops.size(), f->images.at(L.src[0]).view(), f->images.at(L.dst).view(), geo,
+                              g->tune, f->stream);
+        };
+        HIP_TRY(once());
+        HIP_TRY(hipEventRecord(e0, f->stream));
+        for (int i = 0; i < iters; ++i) HIP_TRY(once());
+        HIP_TRY(hipEventRecord(e1, f->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        return RF_OK;
+    };
+    st = body();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st == RF_OK) *avg_ms = ms / (float)iters;
+    return st;
+}

@@ -1,0 +1,99 @@
+// rf_kernels.h -- host-side launch interface of the gfx950 kernels (rf_kernels.hip).
+//
+// These replace the reference's GLSL compute shaders (shaders/*.comp, of which only
+// passthrough.comp exists) and the per-node vkCmdDispatch of
+// src/vulkan/command.rs:166-242.  Node arithmetic is specified in DESIGN.md
+// "Node specifications"; the CPU restatement the parity tests check against is
+// oracle/rf_oracle.c.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace rf {
+
+constexpr int kFmtRGBA8   = 0;
+constexpr int kFmtRGBA32F = 1;
+constexpr int kMaxRadius  = 15;     // conv2d up to 31x31, gaussian radius up to 15
+constexpr int kMaxFusedOps = 5;
+
+inline size_t bytes_per_pixel(int fmt) { return fmt == kFmtRGBA8 ? 4 : 16; }
+
+// One node's device work.  `kind` selects the stage(s) the node contributes to a
+// streaming pipeline.
+enum OpKind : int {
+    OP_PASSTHROUGH = 0,   // shaders/passthrough.comp:7-13
+    OP_GAUSSIAN    = 1,   // separable, radius r: H taps then V taps on f32
+    OP_GRADE       = 2,   // colour grade point op
+    OP_SHARPEN     = 3,   // 3x3 cross
+    OP_CONV2D      = 4,   // dense KxK (never fused; own tile kernel)
+    OP_MIX         = 5    // two-input blend a + mix*(b-a) (the "combination" node of
+                          // pipeline_graph.rs:462-468's example; own kernel)
+};
+
+struct Op {
+    int   kind = OP_PASSTHROUGH;
+    int   radius = 0;                // gaussian radius / conv K/2
+    float w[kMaxRadius + 1] = {};    // gaussian half kernel
+    float slope = 0, offset = 0, saturation = 0;   // grade (slope doubles as the mix factor of OP_MIX)
+    float wc = 1, ws = 0;            // sharpen centre / side weight
+    const float* dev_weights = nullptr;   // conv2d: device pointer, [K][K]
+};
+
+// A 2-D image (or a row strip of one with ghost rows): `base` addresses local row 0,
+// rows outside [0, rows) may exist as ghost rows; `pitch` in bytes.
+struct Image {
+    void*  base = nullptr;
+    size_t pitch = 0;
+};
+
+// Geometry of one launch.  Rows are in the strip's local coordinates.
+struct Geom {
+    int W = 0;          // frame width in pixels
+    int row_lo = 0;     // lowest readable row (clamp-to-edge bound), may be negative (ghost rows)
+    int row_hi = 0;     // highest readable row, inclusive
+    int y0 = 0, y1 = 0; // output rows [y0, y1)
+};
+
+// Tuning knobs (0 = heuristic).  Read once from the environment by rf_graph.
+struct StreamTuning {
+    int rows_per_chunk = 0;
+};
+
+// true if `ops[0..n)` can run as ONE streaming launch (a fused pipeline)
+bool stream_supported(const Op* ops, int n);
+// horizontal / vertical halo a fused pipeline reads beyond its output
+int  ops_radius(const Op* ops, int n);
+
+// Launch ops[0..n) as one kernel: dst = op[n-1](...op[0](src)).  src == dst is
+// allowed only when every op is a point op.  Returns hipSuccess or the launch error.
+hipError_t launch_ops(int fmt, const Op* ops, int n, Image src, Image dst, const Geom& g,
+                      const StreamTuning& tune, hipStream_t stream);
+
+// dst = a + mix*(b-a) per channel (fmaf(mix, b-a, a)); a == dst or b == dst allowed
+hipError_t launch_mix(int fmt, Image a, Image b, Image dst, const Geom& g, float mix, hipStream_t stream);
+
+// synthetic / structured fills of rows [y_begin, y_end) (local), whose global row is y + y_global0
+hipError_t launch_fill_synthetic(int fmt, Image dst, int W, int y_begin, int y_end, int y_global0,
+                                 uint32_t seed, hipStream_t stream);
+hipError_t launch_fill_structured(int fmt, Image dst, int W, int y_begin, int y_end, int y_global0,
+                                  int Hfull, hipStream_t stream);
+
+// sRGB boundary (src/render.rs:264-313, :406-433).  `tables` = device float[256+255]
+// (EOTF table then encode thresholds).  `rgba` = device RGBA8 rows.
+hipError_t launch_upload_srgb8(int fmt, const uint8_t* rgba, size_t stride, Image dst, int W, int rows,
+                               const float* tables, hipStream_t stream);
+hipError_t launch_download_srgb8(int fmt, Image src, uint8_t* rgba, size_t stride, int W, int rows,
+                                 const float* tables, hipStream_t stream);
+
+// float4 grid-stride copy (bandwidth probe)
+hipError_t launch_copy(const void* src, void* dst, size_t bytes, hipStream_t stream);
+
+// host-side parameter derivation shared with nothing else (the oracle has its own)
+void gaussian_weights(float sigma, int radius, float* w);          // w[0..radius]
+void sharpen_weights(float amount, float* centre, float* side);
+void default_conv_weights(int K, float sigma, float* w);           // [K][K]
+void srgb_tables(float* eotf256, float* thr255);
+
+}  // namespace rf

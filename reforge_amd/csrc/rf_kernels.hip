@@ -1,0 +1,882 @@
+// rf_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the reforge
+// render-graph path.  They replace shaders/*.comp + the per-node vkCmdDispatch of
+// src/vulkan/command.rs:166-242.
+//
+// Design (DESIGN.md "Kernels"): the stencil/point nodes are HBM-bound (32 B/px for an
+// rgba32f node), so the kernel is built to move every input row across the fabric
+// once and keep everything else on chip:
+//
+//   * WAVE-AUTONOMOUS STREAMING PIPELINE.  Each 64-lane wave owns a column strip
+//     64 pixels wide (one 16-byte texel per lane: one 1 KiB fully coalesced
+//     global_load_dwordx4 per row) and walks DOWN a chunk of rows.  A node is a short
+//     list of row stages (horizontal taps, vertical taps, point op, 3x3 cross); a
+//     fused chain of nodes is simply a longer list.  Vertical taps keep a rolling
+//     window of rows in VGPRs; horizontal taps exchange the current row between
+//     lanes through a wave-private 1 KiB LDS row (halo = the wave's own edge lanes),
+//     so there is no workgroup barrier anywhere in the kernel -- LDS operations of
+//     one wave execute in order.
+//   * Input rows are prefetched PF rows ahead into a register ring (static indices
+//     via an unrolled loop) so each wave keeps PF KiB in flight.
+//   * Clamp-to-edge is applied where a stage READS (row index and lane index are
+//     clamped to the image), which is what makes chained stages bit-identical to
+//     running the nodes one full-frame pass at a time.
+//
+// Numerics: every multiply-add is an explicit fmaf in the oracle's tap order; this
+// file is compiled with -ffp-contract=off, so results are bit-identical to
+// oracle/rf_oracle.c for finite inputs.
+#include "rf_kernels.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace rf {
+
+typedef float4 f4;
+
+#define RF_DEV __device__ __forceinline__
+
+RF_DEV f4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+RF_DEV f4 fma4(float w, f4 v, f4 a)
+{
+    return make_float4(fmaf(w, v.x, a.x), fmaf(w, v.y, a.y), fmaf(w, v.z, a.z), fmaf(w, v.w, a.w));
+}
+
+// ---------------------------------------------------------------------------------
+// Texel formats: what imageLoad/imageStore do (shaders/passthrough.comp:9,:12)
+// ---------------------------------------------------------------------------------
+RF_DEV float unorm8_to_f32(unsigned c) { return __fdiv_rn((float)c, 255.0f); }
+RF_DEV unsigned f32_to_unorm8(float v)
+{
+    // clamp (NaN -> 0), x255, round to nearest even
+    v = (v > 0.0f) ? v : 0.0f;
+    v = (v > 1.0f) ? 1.0f : v;
+    return (unsigned)rintf(v * 255.0f);
+}
+
+struct PxF32 {
+    typedef f4 Raw;
+    static constexpr int BPP = 16;
+    static constexpr bool QUANT = false;
+    RF_DEV static Raw load(const char* row, unsigned xoff) { return *reinterpret_cast<const f4*>(row + xoff); }
+    RF_DEV static f4 decode(Raw r) { return r; }
+    RF_DEV static void store(char* row, unsigned xoff, f4 v) { *reinterpret_cast<f4*>(row + xoff) = v; }
+    RF_DEV static f4 requant(f4 v) { return v; }
+};
+
+struct PxU8 {
+    typedef unsigned Raw;
+    static constexpr int BPP = 4;
+    static constexpr bool QUANT = true;
+    RF_DEV static Raw load(const char* row, unsigned xoff) { return *reinterpret_cast<const unsigned*>(row + xoff); }
+    RF_DEV static f4 decode(Raw r)
+    {
+        return make_float4(unorm8_to_f32(r & 255u), unorm8_to_f32((r >> 8) & 255u),
+                           unorm8_to_f32((r >> 16) & 255u), unorm8_to_f32(r >> 24));
+    }
+    RF_DEV static unsigned pack(f4 v)
+    {
+        return f32_to_unorm8(v.x) | (f32_to_unorm8(v.y) << 8) | (f32_to_unorm8(v.z) << 16) |
+               (f32_to_unorm8(v.w) << 24);
+    }
+    RF_DEV static void store(char* row, unsigned xoff, f4 v) { *reinterpret_cast<unsigned*>(row + xoff) = pack(v); }
+    // what a store followed by a load of the next node does to a value
+    RF_DEV static f4 requant(f4 v) { return decode(pack(v)); }
+};
+
+// ---------------------------------------------------------------------------------
+// Per-lane context of a streaming wave
+// ---------------------------------------------------------------------------------
+struct Lane {
+    int lane;   // 0..63
+    int x;      // frame column this lane stands for (may lie outside [0,W) in the halo)
+    int x0;     // column of lane 0
+    int W;
+    f4* lds;    // wave-private LDS rows, 64 texels each
+    // LDS slot holding column clamp(x+dx) -- clamp-to-edge at the frame border, and
+    // kept inside the wave's row for the halo lanes (whose results are discarded)
+    RF_DEV int nbr(int dx) const
+    {
+        int c = min(max(x + dx, 0), W - 1) - x0;
+        return min(max(c, 0), 63);
+    }
+};
+
+// LDS operations of one wave execute in issue order, so a wave-private exchange
+// needs no s_barrier: only the compiler has to be told not to reorder.
+RF_DEV void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------
+// Row stages.  A stage sees a window win[0 .. 2*RV] of consecutive rows of its input
+// (win[RV] is the row it emits for) and returns that output row's texel for the lane.
+// ---------------------------------------------------------------------------------
+template <int R> struct Window { f4 win[2 * R + 1]; };
+
+// horizontal taps of the separable gaussian: sum_i w[|i|] * in[x+i], ascending i
+template <int R> struct StHTap {
+    static constexpr int RV = 0, RH = R, LDS_ROWS = (R > 0) ? 1 : 0;
+    struct Params { float w[R + 1]; };
+    template <class Px> RF_DEV static f4 compute(const Params& p, const Window<0>& s, const Lane& L, f4* lds)
+    {
+        f4 c = s.win[0];
+        if constexpr (R > 0) {
+            lds[L.lane] = c;
+            wave_sync();
+        }
+        f4 acc = f4_zero();
+#pragma unroll
+        for (int i = -R; i <= R; ++i) {
+            f4 v = (i == 0) ? c : lds[L.nbr(i)];
+            acc = fma4(p.w[i < 0 ? -i : i], v, acc);
+        }
+        return acc;
+    }
+};
+
+// vertical taps: sum_j w[|j|] * tmp[y+j], ascending j
+template <int R> struct StVTap {
+    static constexpr int RV = R, RH = 0, LDS_ROWS = 0;
+    struct Params { float w[R + 1]; };
+    template <class Px> RF_DEV static f4 compute(const Params& p, const Window<R>& s, const Lane&, f4*)
+    {
+        f4 acc = f4_zero();
+#pragma unroll
+        for (int j = -R; j <= R; ++j) acc = fma4(p.w[j < 0 ? -j : j], s.win[j + R], acc);
+        return acc;
+    }
+};
+
+// colour grade point op
+struct StGrade {
+    static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
+    struct Params { float slope, offset, saturation; };
+    RF_DEV static float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+    template <class Px> RF_DEV static f4 compute(const Params& p, const Window<0>& s, const Lane&, f4*)
+    {
+        f4 c = s.win[0];
+        float tr = fmaf(c.x, p.slope, p.offset);
+        float tg = fmaf(c.y, p.slope, p.offset);
+        float tb = fmaf(c.z, p.slope, p.offset);
+        float luma = fmaf(0.0722f, tb, fmaf(0.7152f, tg, 0.2126f * tr));
+        return make_float4(clamp01(fmaf(p.saturation, tr - luma, luma)),
+                           clamp01(fmaf(p.saturation, tg - luma, luma)),
+                           clamp01(fmaf(p.saturation, tb - luma, luma)), c.w);
+    }
+};
+
+// 3x3 sharpen cross [0,s,0; s,c,s; 0,s,0], taps in ascending (y outer, x inner) order
+struct StCross3 {
+    static constexpr int RV = 1, RH = 1, LDS_ROWS = 1;
+    struct Params { float wc, ws; };
+    template <class Px> RF_DEV static f4 compute(const Params& p, const Window<1>& s, const Lane& L, f4* lds)
+    {
+        f4 c = s.win[1];
+        lds[L.lane] = c;
+        wave_sync();
+        f4 l = lds[L.nbr(-1)];
+        f4 r = lds[L.nbr(+1)];
+        f4 acc = f4_zero();
+        acc = fma4(p.ws, s.win[0], acc);
+        acc = fma4(p.ws, l, acc);
+        acc = fma4(p.wc, c, acc);
+        acc = fma4(p.ws, r, acc);
+        acc = fma4(p.ws, s.win[2], acc);
+        return acc;
+    }
+};
+
+// node boundary inside a fused chain: the store + load the unfused graph performs
+// (UNORM8 re-quantisation for rgba8, nothing for rgba32f)
+struct StNodeEnd {
+    static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
+    struct Params {};
+    template <class Px> RF_DEV static f4 compute(const Params&, const Window<0>& s, const Lane&, f4*)
+    {
+        return Px::requant(s.win[0]);
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// Parameter pack (kernel argument) and the stage chain (per-wave state)
+// ---------------------------------------------------------------------------------
+template <class... S> struct ParamPack;
+template <> struct ParamPack<> {};
+template <class S, class... Rest> struct ParamPack<S, Rest...> {
+    typename S::Params p;
+    ParamPack<Rest...> rest;
+};
+
+template <class... S> struct SumRH { static constexpr int value = 0; };
+template <class S, class... Rest> struct SumRH<S, Rest...> { static constexpr int value = S::RH + SumRH<Rest...>::value; };
+template <class... S> struct SumLDS { static constexpr int value = 0; };
+template <class S, class... Rest> struct SumLDS<S, Rest...> { static constexpr int value = S::LDS_ROWS + SumLDS<Rest...>::value; };
+
+struct Sink {
+    char* dst;          // address of local row 0
+    size_t pitch;
+    unsigned xoff;      // lane's byte offset in a row
+    bool lane_ok;       // lane owns an output texel
+    int row;            // next output row
+};
+
+template <class Px, int LdsIdx, class... S> struct Chain;
+
+// end of the chain: the store
+template <class Px, int LdsIdx> struct Chain<Px, LdsIdx> {
+    RF_DEV void plan_backward(int oa, int ob, int, int, int& in_a, int& in_b) { in_a = oa; in_b = ob; }
+    RF_DEV int plan_forward(int tprev) { return tprev; }
+    RF_DEV void step(bool has, f4 v, int, const Lane&, Sink& k, const ParamPack<>&)
+    {
+        if (has) {
+            if (k.lane_ok) Px::store(k.dst + (ptrdiff_t)k.row * (ptrdiff_t)k.pitch, k.xoff, v);
+            k.row += 1;
+        }
+    }
+};
+
+template <class Px, int LdsIdx, class S, class... Rest> struct Chain<Px, LdsIdx, S, Rest...> {
+    Window<S::RV> st;
+    // wave-uniform schedule
+    int a;        // first input row
+    int oa;       // first output row
+    int flush;    // replications of the last input row (frame bottom edge)
+    int tprev;    // iteration of the upstream stage's last emission
+    int cnt;      // input rows consumed
+    Chain<Px, LdsIdx + S::LDS_ROWS, Rest...> next;
+
+    // given the rows the LAST stage must emit, derive what each stage must emit/consume
+    RF_DEV void plan_backward(int oa_last, int ob_last, int lo, int hi, int& in_a, int& in_b)
+    {
+        int need_a, need_b;
+        next.plan_backward(oa_last, ob_last, lo, hi, need_a, need_b);
+        oa = need_a;
+        a = max(lo, need_a - S::RV);
+        int b = min(hi, need_b + S::RV);
+        flush = need_b + S::RV - b;
+        cnt = 0;
+        in_a = a;
+        in_b = b;
+    }
+    RF_DEV int plan_forward(int tp)
+    {
+        tprev = tp;
+        return next.plan_forward(tp + flush);
+    }
+    RF_DEV void step(bool has_prev, f4 v, int it, const Lane& L, Sink& k, const ParamPack<S, Rest...>& P)
+    {
+        bool in_valid = has_prev || (it > tprev && it <= tprev + flush);
+        bool has = false;
+        f4 out = f4_zero();
+        if (in_valid) {
+            f4 vin = has_prev ? v : st.win[2 * S::RV];
+            if constexpr (S::RV == 0) {
+                st.win[0] = vin;
+            } else {
+                if (cnt == 0) {
+#pragma unroll
+                    for (int i = 0; i <= 2 * S::RV; ++i) st.win[i] = vin;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2 * S::RV; ++i) st.win[i] = st.win[i + 1];
+                    st.win[2 * S::RV] = vin;
+                }
+            }
+            int centre = a + cnt - S::RV;
+            cnt += 1;
+            has = centre >= oa;
+            if (has) out = S::template compute<Px>(P.p, st, L, L.lds + LdsIdx * 64);
+        }
+        next.step(has, out, it, L, k, P.rest);
+    }
+};
+
+template <class... S> struct StreamArgs {
+    const char* src;
+    size_t src_pitch;
+    char* dst;
+    size_t dst_pitch;
+    int W, row_lo, row_hi, y0, y1, rows_per_chunk, n_strips;
+    ParamPack<S...> params;
+};
+
+constexpr int kWavesPerBlock = 4;
+
+template <class Px, int PF, class... S>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void stream_kernel(const StreamArgs<S...> A)
+{
+    constexpr int RH = SumRH<S...>::value;
+    constexpr int VALID = 64 - 2 * RH;
+    constexpr int LDSR = SumLDS<S...>::value;
+    __shared__ f4 smem[kWavesPerBlock][(LDSR > 0 ? LDSR : 1) * 64];
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int strip = (int)blockIdx.x * kWavesPerBlock + wave;
+    if (strip >= A.n_strips) return;                 // wave-uniform; no barriers below
+    const int y0 = A.y0 + (int)blockIdx.y * A.rows_per_chunk;
+    const int y1 = min(y0 + A.rows_per_chunk, A.y1);
+    if (y0 >= y1) return;
+
+    Lane L;
+    L.lane = (int)(threadIdx.x & 63);
+    L.x0 = strip * VALID - RH;
+    L.x = L.x0 + L.lane;
+    L.W = A.W;
+    L.lds = smem[wave];
+
+    Sink k;
+    k.dst = A.dst;
+    k.pitch = A.dst_pitch;
+    k.xoff = (unsigned)min(max(L.x, 0), A.W - 1) * (unsigned)Px::BPP;
+    k.lane_ok = (L.lane >= RH) && (L.lane < 64 - RH) && (L.x < A.W);
+    k.row = y0;
+
+    Chain<Px, 0, S...> chain;
+    int a0, b0;
+    chain.plan_backward(y0, y1 - 1, A.row_lo, A.row_hi, a0, b0);
+    const int n0 = b0 - a0 + 1;                      // source rows
+    const int total = chain.plan_forward(n0 - 1) + 1;
+
+    // source: rows a0..b0, column clamp(x), prefetched PF rows ahead
+    const unsigned src_xoff = k.xoff;
+    typename Px::Raw ring[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        ring[j] = typename Px::Raw();
+        if (j < n0) ring[j] = Px::load(A.src + (ptrdiff_t)(a0 + j) * (ptrdiff_t)A.src_pitch, src_xoff);
+    }
+    for (int base = 0; base < total; base += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int it = base + j;
+            if (it < total) {
+                const bool has0 = it < n0;
+                f4 v0 = f4_zero();
+                if (has0) {
+                    v0 = Px::decode(ring[j]);
+                    if (it + PF < n0)
+                        ring[j] = Px::load(A.src + (ptrdiff_t)(a0 + it + PF) * (ptrdiff_t)A.src_pitch, src_xoff);
+                }
+                chain.step(has0, v0, it, L, k, A.params);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// conv2d: dense KxK correlation on a 16x16 output tile with an LDS halo tile.
+// First (VALU) version: one output texel per thread, taps from LDS in the oracle's
+// order.  The MFMA/Toeplitz formulation is the planned replacement.
+// ---------------------------------------------------------------------------------
+template <class Px>
+__global__ __launch_bounds__(256) void conv2d_tile_kernel(const char* src, size_t src_pitch, char* dst, size_t dst_pitch,
+                                                          int W, int row_lo, int row_hi, int y0, int y1, int K,
+                                                          const float* __restrict__ weights)
+{
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    f4* tile = reinterpret_cast<f4*>(dyn_smem);
+    const int r = K / 2;
+    const int TW = 16 + 2 * r;
+    float* wl = reinterpret_cast<float*>(tile + TW * TW);
+
+    const int tx = (int)(threadIdx.x & 15), ty = (int)(threadIdx.x >> 4);
+    const int bx = (int)blockIdx.x * 16, by = y0 + (int)blockIdx.y * 16;
+
+    for (int i = (int)threadIdx.x; i < K * K; i += 256) wl[i] = weights[i];
+    for (int i = (int)threadIdx.x; i < TW * TW; i += 256) {
+        int lx = i % TW, ly = i / TW;
+        int gx = min(max(bx + lx - r, 0), W - 1);
+        int gy = min(max(by + ly - r, row_lo), row_hi);
+        tile[i] = Px::decode(Px::load(src + (ptrdiff_t)gy * (ptrdiff_t)src_pitch, (unsigned)gx * (unsigned)Px::BPP));
+    }
+    __syncthreads();
+
+    f4 acc = f4_zero();
+    for (int dy = 0; dy < K; ++dy) {
+        const f4* trow = tile + (ty + dy) * TW + tx;
+        const float* wrow = wl + dy * K;
+        for (int dx = 0; dx < K; ++dx) acc = fma4(wrow[dx], trow[dx], acc);
+    }
+    const int ox = bx + tx, oy = by + ty;
+    if (ox < W && oy < y1) Px::store(dst + (ptrdiff_t)oy * (ptrdiff_t)dst_pitch, (unsigned)ox * (unsigned)Px::BPP, acc);
+}
+
+// ---------------------------------------------------------------------------------
+// Synthetic inputs, identical to rfo_fill_* in the oracle
+// ---------------------------------------------------------------------------------
+RF_DEV uint32_t hash32(uint32_t seed, uint32_t idx, uint32_t c)
+{
+    uint32_t h = seed ^ ((idx * 4u + c) * 0x9E3779B1u);
+    h ^= h >> 16; h *= 0x7FEB352Du;
+    h ^= h >> 15; h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
+}
+
+template <class Px>
+__global__ __launch_bounds__(256) void fill_synthetic_kernel(char* dst, size_t pitch, int W, int y_begin, int y_end,
+                                                             int y_global0, uint32_t seed)
+{
+    const int x = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (x >= W) return;
+    for (int y = y_begin + (int)blockIdx.y; y < y_end; y += (int)gridDim.y) {
+        uint32_t idx = (uint32_t)(y + y_global0) * (uint32_t)W + (uint32_t)x;
+        uint32_t u0 = hash32(seed, idx, 0), u1 = hash32(seed, idx, 1), u2 = hash32(seed, idx, 2), u3 = hash32(seed, idx, 3);
+        char* row = dst + (ptrdiff_t)y * (ptrdiff_t)pitch;
+        if constexpr (Px::QUANT) {
+            *reinterpret_cast<unsigned*>(row + (size_t)x * 4) =
+                (u0 >> 24) | ((u1 >> 24) << 8) | ((u2 >> 24) << 16) | ((u3 >> 24) << 24);
+        } else {
+            *reinterpret_cast<f4*>(row + (size_t)x * 16) =
+                make_float4((float)(u0 >> 8) * 0x1p-24f, (float)(u1 >> 8) * 0x1p-24f,
+                            (float)(u2 >> 8) * 0x1p-24f, (float)(u3 >> 8) * 0x1p-24f);
+        }
+    }
+}
+
+template <class Px>
+__global__ __launch_bounds__(256) void fill_structured_kernel(char* dst, size_t pitch, int W, int y_begin, int y_end,
+                                                              int y_global0, int Hfull)
+{
+    const int x = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (x >= W) return;
+    for (int y = y_begin + (int)blockIdx.y; y < y_end; y += (int)gridDim.y) {
+        int gy = y + y_global0;
+        unsigned c0 = (unsigned)(x & 255), c1 = (unsigned)(gy & 255), c2 = (unsigned)((x + gy) & 255), c3 = 255u;
+        if (x == W / 2 && gy == Hfull / 2) c0 = c1 = c2 = 255u;
+        char* row = dst + (ptrdiff_t)y * (ptrdiff_t)pitch;
+        if constexpr (Px::QUANT) {
+            *reinterpret_cast<unsigned*>(row + (size_t)x * 4) = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+        } else {
+            *reinterpret_cast<f4*>(row + (size_t)x * 16) =
+                make_float4(unorm8_to_f32(c0), unorm8_to_f32(c1), unorm8_to_f32(c2), unorm8_to_f32(c3));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// sRGB boundary (src/render.rs:264-313, :406-433).  tables = eotf[256] ++ thr[255]
+// ---------------------------------------------------------------------------------
+template <class Px>
+__global__ __launch_bounds__(256) void upload_srgb8_kernel(const uint8_t* rgba, size_t stride, char* dst, size_t pitch,
+                                                           int W, int rows, const float* __restrict__ tables)
+{
+    __shared__ float eotf[256];
+    eotf[threadIdx.x] = tables[threadIdx.x];
+    __syncthreads();
+    const int x = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (x >= W) return;
+    for (int y = (int)blockIdx.y; y < rows; y += (int)gridDim.y) {
+        unsigned c = *reinterpret_cast<const unsigned*>(rgba + (size_t)y * stride + (size_t)x * 4);
+        f4 v = make_float4(eotf[c & 255u], eotf[(c >> 8) & 255u], eotf[(c >> 16) & 255u], unorm8_to_f32(c >> 24));
+        Px::store(dst + (ptrdiff_t)y * (ptrdiff_t)pitch, (unsigned)x * (unsigned)Px::BPP, v);
+    }
+}
+
+RF_DEV unsigned srgb_encode(float v, const float* thr)
+{
+    // number of thresholds <= v (NaN -> 0): 8-step binary search over thr[0..254]
+    int lo = 0, hi = 255;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        int mid = (lo + hi) >> 1;
+        bool up = (lo < hi) && (thr[mid] <= v);
+        bool dn = (lo < hi) && !up;
+        lo = up ? mid + 1 : lo;
+        hi = dn ? mid : hi;
+    }
+    return (unsigned)lo;
+}
+
+template <class Px>
+__global__ __launch_bounds__(256) void download_srgb8_kernel(const char* src, size_t pitch, uint8_t* rgba, size_t stride,
+                                                             int W, int rows, const float* __restrict__ tables)
+{
+    __shared__ float thr[256];
+    thr[threadIdx.x] = threadIdx.x < 255 ? tables[256 + threadIdx.x] : INFINITY;
+    __syncthreads();
+    const int x = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (x >= W) return;
+    for (int y = (int)blockIdx.y; y < rows; y += (int)gridDim.y) {
+        f4 v = Px::decode(Px::load(src + (ptrdiff_t)y * (ptrdiff_t)pitch, (unsigned)x * (unsigned)Px::BPP));
+        unsigned c = srgb_encode(v.x, thr) | (srgb_encode(v.y, thr) << 8) | (srgb_encode(v.z, thr) << 16) |
+                     (f32_to_unorm8(v.w) << 24);
+        *reinterpret_cast<unsigned*>(rgba + (size_t)y * stride + (size_t)x * 4) = c;
+    }
+}
+
+template <class Px>
+__global__ __launch_bounds__(256) void mix_kernel(const char* a, size_t a_pitch, const char* b, size_t b_pitch, char* dst,
+                                                  size_t dst_pitch, int W, int y0, int y1, float mix)
+{
+    const int x = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (x >= W) return;
+    const unsigned xoff = (unsigned)x * (unsigned)Px::BPP;
+    for (int y = y0 + (int)blockIdx.y; y < y1; y += (int)gridDim.y) {
+        f4 va = Px::decode(Px::load(a + (ptrdiff_t)y * (ptrdiff_t)a_pitch, xoff));
+        f4 vb = Px::decode(Px::load(b + (ptrdiff_t)y * (ptrdiff_t)b_pitch, xoff));
+        f4 o = make_float4(fmaf(mix, vb.x - va.x, va.x), fmaf(mix, vb.y - va.y, va.y), fmaf(mix, vb.z - va.z, va.z),
+                           fmaf(mix, vb.w - va.w, va.w));
+        Px::store(dst + (ptrdiff_t)y * (ptrdiff_t)dst_pitch, xoff, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(const f4* __restrict__ src, f4* __restrict__ dst, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * 256;
+    for (; i < n; i += step) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------
+// Host side: op list -> stage list -> kernel instantiation
+// ---------------------------------------------------------------------------------
+static int choose_rows_per_chunk(int rows, int n_strips, int halo_rows, const StreamTuning& tune)
+{
+    if (tune.rows_per_chunk > 0) return tune.rows_per_chunk;
+    // aim for ~12 waves per CU over 256 CUs, but keep the re-read of the vertical halo
+    // (2*halo_rows per chunk) under ~10 % of a chunk
+    const int target_waves = 256 * 12;
+    int chunks = (target_waves + n_strips - 1) / n_strips;
+    if (chunks < 1) chunks = 1;
+    int rpc = (rows + chunks - 1) / chunks;
+    int min_rpc = halo_rows > 0 ? 20 * halo_rows : 8;
+    if (rpc < min_rpc) rpc = min_rpc;
+    if (rpc > rows) rpc = rows;
+    if (rpc < 1) rpc = 1;
+    return rpc;
+}
+
+template <class Px, int PF, class... S>
+static hipError_t launch_stream(Image src, Image dst, const Geom& g, const StreamTuning& tune, hipStream_t stream,
+                                const ParamPack<S...>& params, int halo_rows)
+{
+    constexpr int RH = SumRH<S...>::value;
+    constexpr int VALID = 64 - 2 * RH;
+    static_assert(VALID > 0, "horizontal halo too wide for a 64-lane strip");
+    StreamArgs<S...> A;
+    A.src = static_cast<const char*>(src.base);
+    A.src_pitch = src.pitch;
+    A.dst = static_cast<char*>(dst.base);
+    A.dst_pitch = dst.pitch;
+    A.W = g.W;
+    A.row_lo = g.row_lo;
+    A.row_hi = g.row_hi;
+    A.y0 = g.y0;
+    A.y1 = g.y1;
+    A.n_strips = (g.W + VALID - 1) / VALID;
+    const int rows = g.y1 - g.y0;
+    if (rows <= 0 || g.W <= 0) return hipSuccess;
+    A.rows_per_chunk = choose_rows_per_chunk(rows, A.n_strips, halo_rows, tune);
+    A.params = params;
+    dim3 grid((unsigned)((A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock),
+              (unsigned)((rows + A.rows_per_chunk - 1) / A.rows_per_chunk));
+    hipLaunchKernelGGL((stream_kernel<Px, PF, S...>), grid, dim3(64 * kWavesPerBlock), 0, stream, A);
+    return hipGetLastError();
+}
+
+// ---- op -> params helpers -------------------------------------------------------
+template <int R> static typename StHTap<R>::Params htap_params(const Op& op)
+{
+    typename StHTap<R>::Params p;
+    for (int i = 0; i <= R; ++i) p.w[i] = op.w[i];
+    return p;
+}
+template <int R> static typename StVTap<R>::Params vtap_params(const Op& op)
+{
+    typename StVTap<R>::Params p;
+    for (int i = 0; i <= R; ++i) p.w[i] = op.w[i];
+    return p;
+}
+static StGrade::Params grade_params(const Op& op) { return {op.slope, op.offset, op.saturation}; }
+static StCross3::Params cross_params(const Op& op) { return {op.wc, op.ws}; }
+
+constexpr int PF_DEFAULT = 4;
+
+template <class Px> static hipError_t run_passthrough(Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<StNodeEnd> P;
+    return launch_stream<Px, PF_DEFAULT, StNodeEnd>(s, d, g, t, st, P, 0);
+}
+
+template <class Px, int R> static hipError_t run_gauss(const Op& op, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<StHTap<R>, StVTap<R>> P;
+    P.p = htap_params<R>(op);
+    P.rest.p = vtap_params<R>(op);
+    return launch_stream<Px, (R <= 4 ? PF_DEFAULT : 2), StHTap<R>, StVTap<R>>(s, d, g, t, st, P, R);
+}
+
+template <class Px, int R = 0>
+static hipError_t run_gauss_any(const Op& op, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    if constexpr (R > kMaxRadius) {
+        return hipErrorInvalidValue;
+    } else {
+        if (op.radius == R) return run_gauss<Px, R>(op, s, d, g, t, st);
+        return run_gauss_any<Px, R + 1>(op, s, d, g, t, st);
+    }
+}
+
+template <class Px> static hipError_t run_grade(const Op& op, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<StGrade> P;
+    P.p = grade_params(op);
+    return launch_stream<Px, PF_DEFAULT, StGrade>(s, d, g, t, st, P, 0);
+}
+
+template <class Px> static hipError_t run_sharpen(const Op& op, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<StCross3> P;
+    P.p = cross_params(op);
+    return launch_stream<Px, PF_DEFAULT, StCross3>(s, d, g, t, st, P, 1);
+}
+
+// ---- fused catalogue ------------------------------------------------------------
+// gaussian(R) -> grade
+template <class Px, int R> static hipError_t run_gauss_grade(const Op* o, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<StHTap<R>, StVTap<R>, StNodeEnd, StGrade> P;
+    P.p = htap_params<R>(o[0]);
+    P.rest.p = vtap_params<R>(o[0]);
+    P.rest.rest.rest.p = grade_params(o[1]);
+    return launch_stream<Px, PF_DEFAULT, StHTap<R>, StVTap<R>, StNodeEnd, StGrade>(s, d, g, t, st, P, R);
+}
+// grade -> sharpen
+template <class Px> static hipError_t run_grade_sharpen(const Op* o, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<StGrade, StNodeEnd, StCross3> P;
+    P.p = grade_params(o[0]);
+    P.rest.rest.p = cross_params(o[1]);
+    return launch_stream<Px, PF_DEFAULT, StGrade, StNodeEnd, StCross3>(s, d, g, t, st, P, 1);
+}
+// gaussian(R) -> grade -> sharpen
+template <class Px, int R> static hipError_t run_gauss_grade_sharpen(const Op* o, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<StHTap<R>, StVTap<R>, StNodeEnd, StGrade, StNodeEnd, StCross3> P;
+    P.p = htap_params<R>(o[0]);
+    P.rest.p = vtap_params<R>(o[0]);
+    P.rest.rest.rest.p = grade_params(o[1]);
+    P.rest.rest.rest.rest.rest.p = cross_params(o[2]);
+    return launch_stream<Px, PF_DEFAULT, StHTap<R>, StVTap<R>, StNodeEnd, StGrade, StNodeEnd, StCross3>(s, d, g, t, st, P, R + 1);
+}
+
+static bool is_gauss(const Op& o, int r) { return o.kind == OP_GAUSSIAN && o.radius == r; }
+
+// index of the fused pattern matching ops[0..n), -1 if none
+static int fused_pattern(const Op* o, int n)
+{
+    if (n == 2 && is_gauss(o[0], 2) && o[1].kind == OP_GRADE) return 0;
+    if (n == 2 && is_gauss(o[0], 4) && o[1].kind == OP_GRADE) return 1;
+    if (n == 2 && o[0].kind == OP_GRADE && o[1].kind == OP_SHARPEN) return 2;
+    if (n == 3 && is_gauss(o[0], 2) && o[1].kind == OP_GRADE && o[2].kind == OP_SHARPEN) return 3;
+    if (n == 3 && is_gauss(o[0], 4) && o[1].kind == OP_GRADE && o[2].kind == OP_SHARPEN) return 4;
+    return -1;
+}
+
+bool stream_supported(const Op* ops, int n)
+{
+    if (n <= 0 || n > kMaxFusedOps) return false;
+    if (n == 1) return true;
+    return fused_pattern(ops, n) >= 0;
+}
+
+int ops_radius(const Op* ops, int n)
+{
+    int r = 0;
+    for (int i = 0; i < n; ++i) {
+        switch (ops[i].kind) {
+            case OP_GAUSSIAN: r += ops[i].radius; break;
+            case OP_SHARPEN: r += 1; break;
+            case OP_CONV2D: r += ops[i].radius; break;
+            default: break;
+        }
+    }
+    return r;
+}
+
+template <class Px>
+static hipError_t launch_ops_px(const Op* ops, int n, Image src, Image dst, const Geom& g, const StreamTuning& tune,
+                                hipStream_t stream)
+{
+    if (n == 1) {
+        const Op& op = ops[0];
+        switch (op.kind) {
+            case OP_PASSTHROUGH: return run_passthrough<Px>(src, dst, g, tune, stream);
+            case OP_GAUSSIAN:
+                if (op.radius < 0 || op.radius > kMaxRadius) return hipErrorInvalidValue;
+                return run_gauss_any<Px>(op, src, dst, g, tune, stream);
+            case OP_GRADE: return run_grade<Px>(op, src, dst, g, tune, stream);
+            case OP_SHARPEN: return run_sharpen<Px>(op, src, dst, g, tune, stream);
+            case OP_CONV2D: {
+                const int K = 2 * op.radius + 1;
+                if (op.radius < 0 || op.radius > kMaxRadius || !op.dev_weights) return hipErrorInvalidValue;
+                const int rows = g.y1 - g.y0;
+                if (rows <= 0 || g.W <= 0) return hipSuccess;
+                const int TW = 16 + 2 * op.radius;
+                size_t lds = (size_t)TW * TW * sizeof(f4) + (size_t)K * K * sizeof(float);
+                dim3 grid((unsigned)((g.W + 15) / 16), (unsigned)((rows + 15) / 16));
+                hipLaunchKernelGGL((conv2d_tile_kernel<Px>), grid, dim3(256), lds, stream,
+                                   static_cast<const char*>(src.base), src.pitch, static_cast<char*>(dst.base), dst.pitch,
+                                   g.W, g.row_lo, g.row_hi, g.y0, g.y1, K, op.dev_weights);
+                return hipGetLastError();
+            }
+            default: return hipErrorInvalidValue;
+        }
+    }
+    switch (fused_pattern(ops, n)) {
+        case 0: return run_gauss_grade<Px, 2>(ops, src, dst, g, tune, stream);
+        case 1: return run_gauss_grade<Px, 4>(ops, src, dst, g, tune, stream);
+        case 2: return run_grade_sharpen<Px>(ops, src, dst, g, tune, stream);
+        case 3: return run_gauss_grade_sharpen<Px, 2>(ops, src, dst, g, tune, stream);
+        case 4: return run_gauss_grade_sharpen<Px, 4>(ops, src, dst, g, tune, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_ops(int fmt, const Op* ops, int n, Image src, Image dst, const Geom& g, const StreamTuning& tune,
+                      hipStream_t stream)
+{
+    if (fmt == kFmtRGBA8) return launch_ops_px<PxU8>(ops, n, src, dst, g, tune, stream);
+    if (fmt == kFmtRGBA32F) return launch_ops_px<PxF32>(ops, n, src, dst, g, tune, stream);
+    return hipErrorInvalidValue;
+}
+
+static dim3 fill_grid(int W, int rows)
+{
+    unsigned gy = (unsigned)(rows < 1 ? 1 : (rows > 1024 ? 1024 : rows));
+    return dim3((unsigned)((W + 255) / 256), gy);
+}
+
+hipError_t launch_fill_synthetic(int fmt, Image dst, int W, int y_begin, int y_end, int y_global0, uint32_t seed,
+                                 hipStream_t stream)
+{
+    if (y_end <= y_begin || W <= 0) return hipSuccess;
+    dim3 grid = fill_grid(W, y_end - y_begin);
+    char* d = static_cast<char*>(dst.base);
+    if (fmt == kFmtRGBA8)
+        hipLaunchKernelGGL((fill_synthetic_kernel<PxU8>), grid, dim3(256), 0, stream, d, dst.pitch, W, y_begin, y_end, y_global0, seed);
+    else
+        hipLaunchKernelGGL((fill_synthetic_kernel<PxF32>), grid, dim3(256), 0, stream, d, dst.pitch, W, y_begin, y_end, y_global0, seed);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_structured(int fmt, Image dst, int W, int y_begin, int y_end, int y_global0, int Hfull,
+                                  hipStream_t stream)
+{
+    if (y_end <= y_begin || W <= 0) return hipSuccess;
+    dim3 grid = fill_grid(W, y_end - y_begin);
+    char* d = static_cast<char*>(dst.base);
+    if (fmt == kFmtRGBA8)
+        hipLaunchKernelGGL((fill_structured_kernel<PxU8>), grid, dim3(256), 0, stream, d, dst.pitch, W, y_begin, y_end, y_global0, Hfull);
+    else
+        hipLaunchKernelGGL((fill_structured_kernel<PxF32>), grid, dim3(256), 0, stream, d, dst.pitch, W, y_begin, y_end, y_global0, Hfull);
+    return hipGetLastError();
+}
+
+hipError_t launch_upload_srgb8(int fmt, const uint8_t* rgba, size_t stride, Image dst, int W, int rows,
+                               const float* tables, hipStream_t stream)
+{
+    if (rows <= 0 || W <= 0) return hipSuccess;
+    dim3 grid = fill_grid(W, rows);
+    char* d = static_cast<char*>(dst.base);
+    if (fmt == kFmtRGBA8)
+        hipLaunchKernelGGL((upload_srgb8_kernel<PxU8>), grid, dim3(256), 0, stream, rgba, stride, d, dst.pitch, W, rows, tables);
+    else
+        hipLaunchKernelGGL((upload_srgb8_kernel<PxF32>), grid, dim3(256), 0, stream, rgba, stride, d, dst.pitch, W, rows, tables);
+    return hipGetLastError();
+}
+
+hipError_t launch_download_srgb8(int fmt, Image src, uint8_t* rgba, size_t stride, int W, int rows,
+                                 const float* tables, hipStream_t stream)
+{
+    if (rows <= 0 || W <= 0) return hipSuccess;
+    dim3 grid = fill_grid(W, rows);
+    const char* s = static_cast<const char*>(src.base);
+    if (fmt == kFmtRGBA8)
+        hipLaunchKernelGGL((download_srgb8_kernel<PxU8>), grid, dim3(256), 0, stream, s, src.pitch, rgba, stride, W, rows, tables);
+    else
+        hipLaunchKernelGGL((download_srgb8_kernel<PxF32>), grid, dim3(256), 0, stream, s, src.pitch, rgba, stride, W, rows, tables);
+    return hipGetLastError();
+}
+
+hipError_t launch_mix(int fmt, Image a, Image b, Image dst, const Geom& g, float mix, hipStream_t stream)
+{
+    if (g.y1 <= g.y0 || g.W <= 0) return hipSuccess;
+    dim3 grid = fill_grid(g.W, g.y1 - g.y0);
+    const char* pa = static_cast<const char*>(a.base);
+    const char* pb = static_cast<const char*>(b.base);
+    char* pd = static_cast<char*>(dst.base);
+    if (fmt == kFmtRGBA8)
+        hipLaunchKernelGGL((mix_kernel<PxU8>), grid, dim3(256), 0, stream, pa, a.pitch, pb, b.pitch, pd, dst.pitch, g.W, g.y0, g.y1, mix);
+    else
+        hipLaunchKernelGGL((mix_kernel<PxF32>), grid, dim3(256), 0, stream, pa, a.pitch, pb, b.pitch, pd, dst.pitch, g.W, g.y0, g.y1, mix);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy(const void* src, void* dst, size_t bytes, hipStream_t stream)
+{
+    size_t n = bytes / sizeof(f4);
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const f4*>(src),
+                       static_cast<f4*>(dst), n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// Host-side parameter derivation (the product's own; the oracle restates it)
+// ---------------------------------------------------------------------------------
+void gaussian_weights(float sigma, int radius, float* w)
+{
+    if (!(sigma > 0.0f)) {
+        w[0] = 1.0f;
+        for (int i = 1; i <= radius; ++i) w[i] = 0.0f;
+        return;
+    }
+    double e[kMaxRadius + 1];
+    const double s2 = 2.0 * (double)sigma * (double)sigma;
+    for (int i = 0; i <= radius; ++i) e[i] = exp(-(double)(i * i) / s2);
+    double sum = e[0];
+    for (int i = 1; i <= radius; ++i) sum += 2.0 * e[i];
+    for (int i = 0; i <= radius; ++i) w[i] = (float)(e[i] / sum);
+}
+
+void sharpen_weights(float amount, float* centre, float* side)
+{
+    *centre = fmaf(4.0f, amount, 1.0f);
+    *side = -amount;
+}
+
+void default_conv_weights(int K, float sigma, float* w)
+{
+    const int r = K / 2;
+    double g[kMaxRadius + 1];
+    if (!(sigma > 0.0f)) {
+        g[0] = 1.0;
+        for (int i = 1; i <= r; ++i) g[i] = 0.0;
+    } else {
+        const double s2 = 2.0 * (double)sigma * (double)sigma;
+        double sum = 0.0;
+        for (int i = 0; i <= r; ++i) g[i] = exp(-(double)(i * i) / s2);
+        sum = g[0];
+        for (int i = 1; i <= r; ++i) sum += 2.0 * g[i];
+        for (int i = 0; i <= r; ++i) g[i] /= sum;
+    }
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) w[(dy + r) * K + (dx + r)] = (float)(g[dy < 0 ? -dy : dy] * g[dx < 0 ? -dx : dx]);
+}
+
+static double srgb_eotf(double cs) { return cs <= 0.04045 ? cs / 12.92 : pow((cs + 0.055) / 1.055, 2.4); }
+
+void srgb_tables(float* eotf256, float* thr255)
+{
+    for (int c = 0; c < 256; ++c) eotf256[c] = (float)srgb_eotf((double)c / 255.0);
+    for (int q = 0; q < 255; ++q) thr255[q] = (float)srgb_eotf(((double)q + 0.5) / 255.0);
+}
+
+}  // namespace rf

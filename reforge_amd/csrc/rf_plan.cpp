@@ -1,0 +1,430 @@
+// rf_plan.cpp -- see rf_plan.h.  Host only; no GPU involved.
+#include "rf_plan.h"
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
+#include <set>
+
+namespace rf {
+
+// ---------------------------------------------------------------------------------
+// Registry
+// ---------------------------------------------------------------------------------
+int NodeType::binding(const std::string& descriptor) const
+{
+    for (const auto& im : images)
+        if (descriptor == im.first) return im.second;
+    return -1;
+}
+
+const ParamDef* NodeType::param(const std::string& pname) const
+{
+    for (const auto& p : params)
+        if (pname == p.name) return &p;
+    return nullptr;
+}
+
+const std::vector<NodeType>& registry()
+{
+    // passthrough.comp:4-5 declares input_image at binding 0 and output_image at 1; the
+    // authored types keep that layout.  colour_grade adds a read-write `image` so a
+    // config can run it in place (`-> colour_grade:image ->`, pipeline_graph.rs:400-411).
+    static const std::vector<std::pair<const char*, int>> io = {{"input_image", 0}, {"output_image", 1}};
+    static const std::vector<std::pair<const char*, int>> io_rw = {{"input_image", 0}, {"output_image", 1}, {"image", 2}};
+    static const std::vector<std::pair<const char*, int>> io2 = {{"input_image0", 0}, {"input_image1", 1}, {"output_image", 2}};
+    static const std::vector<ParamDef> grade = {{"slope", PARAM_F32}, {"offset", PARAM_F32}, {"saturation", PARAM_F32}};
+    static const std::vector<NodeType> types = {
+        {"passthrough", OP_PASSTHROUGH, 0, io, {}},
+        {"gaussian5", OP_GAUSSIAN, 2, io, {{"sigma", PARAM_F32}}},
+        {"gaussian9", OP_GAUSSIAN, 4, io, {{"sigma", PARAM_F32}}},
+        {"gaussian", OP_GAUSSIAN, -1, io, {{"sigma", PARAM_F32}, {"radius", PARAM_I32}}},
+        {"colour_grade", OP_GRADE, 0, io_rw, grade},
+        {"colour-grade", OP_GRADE, 0, io_rw, grade},
+        {"grade", OP_GRADE, 0, io_rw, grade},
+        {"sharpen", OP_SHARPEN, 1, io, {{"amount", PARAM_F32}}},
+        {"conv2d", OP_CONV2D, -1, io, {{"ksize", PARAM_I32}, {"sigma", PARAM_F32}}},
+        {"combination", OP_MIX, 0, io2, {{"mix", PARAM_F32}}},
+    };
+    return types;
+}
+
+const NodeType* find_type(const std::string& name)
+{
+    for (const auto& t : registry())
+        if (name == t.name) return &t;
+    return nullptr;
+}
+
+// ---------------------------------------------------------------------------------
+// Parameters (render.rs:167-210)
+// ---------------------------------------------------------------------------------
+static bool rust_parse_i32(const std::string& s, int32_t& out)
+{
+    // i32::from_str: optional sign, then decimal digits only; overflow is an error
+    size_t i = 0;
+    if (i < s.size() && (s[i] == '+' || s[i] == '-')) ++i;
+    if (i >= s.size()) return false;
+    for (size_t j = i; j < s.size(); ++j)
+        if (s[j] < '0' || s[j] > '9') return false;
+    errno = 0;
+    long long v = std::strtoll(s.c_str(), nullptr, 10);
+    if (errno != 0 || v < INT32_MIN || v > INT32_MAX) return false;
+    out = (int32_t)v;
+    return true;
+}
+
+static bool rust_parse_f32(const std::string& s, float& out)
+{
+    // the grammar only lets [0-9]+ , -?[0-9]+\.[0-9]+ , true, false through
+    // (config_grammar.lalrpop:74-78); "true"/"false" fail f32::from_str
+    if (s.empty()) return false;
+    size_t i = 0;
+    if (s[i] == '+' || s[i] == '-') ++i;
+    bool digits = false, dot = false;
+    for (; i < s.size(); ++i) {
+        if (s[i] >= '0' && s[i] <= '9') digits = true;
+        else if (s[i] == '.' && !dot) dot = true;
+        else return false;
+    }
+    if (!digits) return false;
+    out = std::strtof(s.c_str(), nullptr);   // correctly rounded decimal -> f32, like Rust
+    return true;
+}
+
+ParamValue parse_param(const std::string* text, ParamType type)
+{
+    ParamValue v;
+    v.i = 0;
+    if (!text) return v;   // absent: zero-filled (render.rs:200-203)
+    switch (type) {
+        case PARAM_F32: {
+            float f;
+            if (rust_parse_f32(*text, f)) v.f = f;
+            break;
+        }
+        case PARAM_I32: {
+            int32_t i;
+            if (rust_parse_i32(*text, i)) v.i = i;
+            break;
+        }
+        case PARAM_BOOL:
+            v.b = (*text == "true") ? 1 : 0;
+            break;
+    }
+    return v;
+}
+
+static float pf(const std::map<std::string, ParamValue>& m, const char* k)
+{
+    auto it = m.find(k);
+    return it == m.end() ? 0.0f : it->second.f;
+}
+static int pi(const std::map<std::string, ParamValue>& m, const char* k)
+{
+    auto it = m.find(k);
+    return it == m.end() ? 0 : it->second.i;
+}
+
+int NodeParams::conv_ksize() const
+{
+    int k = pi(values, "ksize");
+    if (k < 1) k = 1;
+    if (k > 2 * kMaxRadius + 1) k = 2 * kMaxRadius + 1;
+    if (k % 2 == 0) k -= 1;
+    return k;
+}
+
+Op NodeParams::to_op(const float* dev_weights) const
+{
+    Op op;
+    op.kind = type->kind;
+    switch (type->kind) {
+        case OP_GAUSSIAN: {
+            int r = type->fixed_radius;
+            if (r < 0) r = std::min(std::max(pi(values, "radius"), 0), kMaxRadius);
+            op.radius = r;
+            gaussian_weights(pf(values, "sigma"), r, op.w);
+            break;
+        }
+        case OP_GRADE:
+            op.slope = pf(values, "slope");
+            op.offset = pf(values, "offset");
+            op.saturation = pf(values, "saturation");
+            break;
+        case OP_SHARPEN:
+            op.radius = 1;
+            sharpen_weights(pf(values, "amount"), &op.wc, &op.ws);
+            break;
+        case OP_CONV2D:
+            op.radius = conv_ksize() / 2;
+            op.dev_weights = dev_weights;
+            break;
+        case OP_MIX:
+            op.slope = pf(values, "mix");
+            break;
+        default:
+            break;
+    }
+    return op;
+}
+
+// ---------------------------------------------------------------------------------
+// Plan
+// ---------------------------------------------------------------------------------
+const std::string& Plan::resolve(const std::string& resource) const
+{
+    const std::string* name = &resource;
+    for (;;) {
+        auto it = reuse.find(*name);
+        if (it == reuse.end()) return *name;
+        name = &it->second;
+    }
+}
+
+std::vector<std::string> Plan::launch_order() const
+{
+    std::vector<std::string> out;
+    for (const auto& layer : layers)
+        for (const auto& n : layer) out.push_back(n);
+    return out;
+}
+
+// order_by_execution, pipeline_graph.rs:429-497
+static bool order_by_execution(const std::map<std::string, PipelineInfo>& infos,
+                               std::vector<std::vector<std::string>>& layers, std::string& err)
+{
+    std::set<std::string> unexecuted;
+    for (const auto& kv : infos) unexecuted.insert(kv.first);
+
+    auto input_nodes = [&](const PipelineInfo& info) {
+        std::vector<std::string> nodes;
+        for (const auto& cand : infos) {
+            bool feeds = false;
+            for (const auto& out : cand.second.output_images)
+                for (const auto& in : info.input_images)
+                    if (out.first == in.first) feeds = true;
+            if (feeds) nodes.push_back(cand.first);
+        }
+        return nodes;
+    };
+
+    while (!unexecuted.empty()) {
+        const std::set<std::string> snapshot = unexecuted;   // readiness is judged against the snapshot (:470,:479)
+        std::vector<std::string> layer;
+        for (const auto& node : snapshot) {
+            bool ready = true;
+            for (const auto& dep : input_nodes(infos.at(node)))
+                if (snapshot.count(dep)) ready = false;
+            if (ready) {
+                unexecuted.erase(node);
+                layer.push_back(node);
+            }
+        }
+        if (snapshot.size() == unexecuted.size()) {   // :487-490
+            err = "Graph incorrectly constructed. Failed to add nodes into execution: [";
+            bool first = true;
+            for (const auto& n : snapshot) {
+                err += (first ? "\"" : ", \"") + n + "\"";
+                first = false;
+            }
+            err += "]";
+            return false;
+        }
+        layers.push_back(layer);
+    }
+    return true;
+}
+
+// reusable_image_remapping, pipeline_graph.rs:358-427
+static std::map<std::string, std::string> reusable_image_remapping(
+    const std::vector<std::vector<std::string>>& layers, const std::map<std::string, PipelineInfo>& infos)
+{
+    std::vector<std::string> free_images;
+    std::set<std::string> images;
+    std::map<std::string, std::string> reuse;
+
+    auto has_remap = [&](const std::string& name, const std::vector<std::pair<std::string, int>>& imgs) {
+        for (const auto& im : imgs) {
+            auto it = reuse.find(im.first);
+            if (it != reuse.end() && it->second == name) return true;
+        }
+        return false;
+    };
+    auto node_uses = [&](const PipelineInfo& node, const std::string& name) {
+        for (const auto& im : node.input_images)
+            if (im.first == name) return true;
+        for (const auto& im : node.output_images)
+            if (im.first == name) return true;
+        return has_remap(name, node.input_images) || has_remap(name, node.output_images);
+    };
+    auto still_in_use = [&](const std::string& name, size_t start_layer) {
+        for (size_t l = start_layer; l < layers.size(); ++l)
+            for (const auto& n : layers[l])
+                if (node_uses(infos.at(n), name)) return true;
+        return false;
+    };
+
+    for (size_t li = 0; li < layers.size(); ++li) {
+        for (const auto& name : images) {
+            if (std::find(free_images.begin(), free_images.end(), name) != free_images.end()) continue;
+            if (!still_in_use(name, li)) free_images.push_back(name);
+        }
+        for (const auto& n : layers[li]) {
+            const PipelineInfo& node = infos.at(n);
+            for (const auto& out : node.output_images) {
+                bool point_op = false;   // same binding as an input: run in place (:400-411)
+                for (const auto& in : node.input_images) {
+                    if (out.second == in.second) {
+                        point_op = true;
+                        reuse[out.first] = in.first;
+                    }
+                }
+                if (point_op) continue;
+                if (free_images.empty()) {
+                    images.insert(out.first);
+                } else {
+                    reuse[out.first] = free_images.back();
+                    free_images.pop_back();
+                }
+            }
+        }
+    }
+    return reuse;
+}
+
+static bool is_simple(const PipelineInfo& p) { return p.input_images.size() == 1 && p.output_images.size() == 1; }
+
+// Fuse chains of single-input/single-output nodes whose intermediate image has exactly
+// one producer and one consumer and is not the graph output (no reference counterpart:
+// the reference materialises every edge, pipeline_graph.rs:219-221).
+static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& infos)
+{
+    std::map<std::string, std::vector<std::string>> producers, consumers;
+    for (const auto& kv : infos) {
+        for (const auto& o : kv.second.output_images) producers[o.first].push_back(kv.first);
+        for (const auto& i : kv.second.input_images) consumers[i.first].push_back(kv.first);
+    }
+    auto next_of = [&](const std::string& n) -> std::string {
+        const PipelineInfo& p = infos.at(n);
+        if (!is_simple(p)) return "";
+        const std::string& r = p.output_images[0].first;
+        if (r == kFinalOutput || r == kFileInput) return "";
+        if (producers[r].size() != 1 || consumers[r].size() != 1) return "";
+        const std::string& c = consumers[r][0];
+        if (c == n || !is_simple(infos.at(c))) return "";
+        return c;
+    };
+    std::map<std::string, std::string> prev_of;
+    for (const auto& kv : infos) {
+        std::string nx = next_of(kv.first);
+        if (!nx.empty()) prev_of[nx] = kv.first;
+    }
+    std::vector<std::vector<std::string>> groups;
+    for (const auto& kv : infos) {
+        if (prev_of.count(kv.first)) continue;   // not a chain head
+        std::vector<std::string> chain;
+        std::set<std::string> seen;
+        for (std::string n = kv.first; !n.empty() && !seen.count(n); n = next_of(n)) {
+            chain.push_back(n);
+            seen.insert(n);
+        }
+        // greedy: longest supported prefix first
+        size_t i = 0;
+        while (i < chain.size()) {
+            size_t best = 1;
+            for (size_t len = std::min(chain.size() - i, (size_t)kMaxFusedOps); len >= 2; --len) {
+                std::vector<Op> ops;
+                for (size_t k = 0; k < len; ++k) ops.push_back(plan.nodes.at(chain[i + k]).to_op(nullptr));
+                if (stream_supported(ops.data(), (int)len)) { best = len; break; }
+            }
+            if (best >= 2) groups.emplace_back(chain.begin() + i, chain.begin() + i + best);
+            i += best;
+        }
+    }
+    for (const auto& g : groups) {
+        PipelineInfo f;
+        for (size_t k = 0; k < g.size(); ++k) {
+            f.name += (k ? "+" : "") + g[k];
+            f.members.push_back(g[k]);
+        }
+        // private binding numbers: a fused chain is never an in-place alias
+        f.input_images = {{infos.at(g.front()).input_images[0].first, 1000}};
+        f.output_images = {{infos.at(g.back()).output_images[0].first, 1001}};
+        for (const auto& n : g) infos.erase(n);
+        infos[f.name] = f;
+    }
+}
+
+bool build_plan(const Config& cfg, uint32_t flags, Plan& plan, std::string& err)
+{
+    plan = Plan();
+    // synthesize_config, vkutils.rs:140-196
+    for (const auto& kv : cfg.graph_pipelines) {
+        const std::string& name = kv.first;
+        const std::string& tname = cfg.type_of(name);
+        const NodeType* type = find_type(tname);
+        if (!type) {   // Shader::from_path -> None (utils.rs:23)
+            err = "Error reading node type '" + tname + "' for node '" + name + "': no such filter";
+            return false;
+        }
+        PipelineInfo info;
+        info.name = name;
+        info.members = {name};
+        for (int side = 0; side < 2; ++side) {
+            const auto& descs = side == 0 ? kv.second.inputs : kv.second.outputs;
+            auto& dst = side == 0 ? info.input_images : info.output_images;
+            for (const auto& d : descs) {
+                int b = type->binding(d.descriptor_name);
+                if (b < 0) {   // vkutils.rs:179
+                    err = "Shader " + tname + " has no binding named: " + d.descriptor_name;
+                    return false;
+                }
+                dst.push_back({d.resource_name, b});
+            }
+        }
+        plan.infos[name] = info;
+
+        NodeParams np;
+        np.type = type;
+        const auto& given = cfg.params_of(name);
+        for (const auto& pd : type->params) {
+            auto it = given.find(pd.name);
+            np.values[pd.name] = parse_param(it == given.end() ? nullptr : &it->second, pd.type);
+        }
+        plan.nodes[name] = np;
+    }
+
+    if (!(flags & kPlanNoFusion)) {
+        size_t before = plan.infos.size();
+        fuse_chains(plan, plan.infos);
+        plan.fused = plan.infos.size() != before;
+    }
+
+    if (!order_by_execution(plan.infos, plan.layers, err)) return false;
+    plan.reuse = reusable_image_remapping(plan.layers, plan.infos);
+
+    // images created per frame, pipeline_graph.rs:205-224
+    std::set<std::string> images;
+    for (const auto& layer : plan.layers) {
+        for (const auto& n : layer) {
+            const PipelineInfo& info = plan.infos.at(n);
+            for (const auto& in : info.input_images)
+                if (in.first == kFileInput) images.insert(in.first);
+            for (const auto& out : info.output_images) images.insert(plan.resolve(out.first));
+        }
+    }
+    plan.images.assign(images.begin(), images.end());
+    return true;
+}
+
+void strip_rows(int height, int world, int rank, int& y0, int& y1)
+{
+    // contiguous strips; the first (height % world) ranks hold one extra row
+    const int base = height / world, extra = height % world;
+    y0 = rank * base + std::min(rank, extra);
+    y1 = y0 + base + (rank < extra ? 1 : 0);
+}
+
+}  // namespace rf

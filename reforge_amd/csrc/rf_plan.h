@@ -1,0 +1,88 @@
+// rf_plan.h -- node-type registry + graph planner (host only).
+//
+// Registry: what the reference learns by compiling `{shader_path}/{type}.comp` and
+// reflecting its SPIR-V (src/vulkan/shader.rs:29-160, vkutils.rs:140-196): image
+// variable name -> binding index, uniform-block members -> (type).  Here a node type
+// is a hand-written HIP stage list instead of a GLSL file, so the table is static.
+//
+// Planner: PipelineGraph::order_by_execution (pipeline_graph.rs:429-497) and
+// PipelineGraph::reusable_image_remapping (pipeline_graph.rs:358-427), applied to the
+// node graph -- or, with fusion enabled, to the graph whose nodes are fused chains.
+#pragma once
+
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "rf_config.h"
+#include "rf_kernels.h"
+
+namespace rf {
+
+enum ParamType { PARAM_F32 = 0, PARAM_I32 = 1, PARAM_BOOL = 2 };   // render.rs:171-184
+
+struct ParamDef {
+    const char* name;
+    ParamType type;
+};
+
+struct NodeType {
+    const char* name;
+    OpKind kind;
+    int fixed_radius;                                     // -1: from the `radius` / `ksize` parameter
+    std::vector<std::pair<const char*, int>> images;      // variable name -> binding (shader.rs:151-153)
+    std::vector<ParamDef> params;                         // uniform members (pipeline_graph.rs:276-292)
+    int binding(const std::string& descriptor) const;     // -1 if absent
+    const ParamDef* param(const std::string& name) const;
+};
+
+const std::vector<NodeType>& registry();
+const NodeType* find_type(const std::string& name);
+
+// one uniform member's value (the UBO bytes of render.rs:167-210)
+union ParamValue {
+    float f;
+    int32_t i;
+    int32_t b;
+};
+// Rust str::parse::<f32|i32|bool>; failure or absence -> 0 (render.rs:173,:177,:181,:200-203)
+ParamValue parse_param(const std::string* text, ParamType type);
+
+// pipeline.rs:17-25 restricted to images
+struct PipelineInfo {
+    std::string name;                                      // node name, or "a+b+c" for a fused chain
+    std::vector<std::string> members;                      // node names in execution order (1 unless fused)
+    std::vector<std::pair<std::string, int>> input_images; // (resource name, binding)
+    std::vector<std::pair<std::string, int>> output_images;
+};
+
+// per-node resolved parameters -> the device op
+struct NodeParams {
+    const NodeType* type = nullptr;
+    std::map<std::string, ParamValue> values;   // every member of the type, zero-filled if absent
+    Op to_op(const float* dev_weights) const;   // derives weights (gaussian/sharpen) on the host
+    int conv_ksize() const;                     // conv2d: `ksize` clamped to odd [1,31]
+};
+
+struct Plan {
+    std::map<std::string, NodeParams> nodes;               // every config node
+    std::map<std::string, PipelineInfo> infos;             // planned units (nodes or fused chains)
+    std::vector<std::vector<std::string>> layers;          // order_by_execution, name-sorted inside a layer
+    std::map<std::string, std::string> reuse;              // image_reuse_remapping
+    std::vector<std::string> images;                       // allocated per frame, sorted
+    bool fused = false;
+
+    const std::string& resolve(const std::string& resource) const;   // remap_resource_name, :75-79
+    // planned units in execution order (layer by layer)
+    std::vector<std::string> launch_order() const;
+};
+
+constexpr uint32_t kPlanNoFusion = 0x2u;   // == RF_GRAPH_NO_FUSION
+
+bool build_plan(const Config& cfg, uint32_t flags, Plan& out, std::string& err);
+
+// rows [y0,y1) of `height` owned by `rank` of `world`: contiguous, sizes differ by <= 1
+void strip_rows(int height, int world, int rank, int& y0, int& y1);
+
+}  // namespace rf

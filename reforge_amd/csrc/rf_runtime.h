@@ -1,0 +1,106 @@
+// rf_runtime.h -- device runtime behind the C ABI: context, per-frame images, the
+// stream/event executor and the row-strip halo exchange.
+//
+// Counterparts in the reference: VkCore (src/vulkan/core.rs), Frame
+// (src/vulkan/frame.rs), PipelineGraph / PipelineGraphFrame
+// (src/vulkan/pipeline_graph.rs:24-57,:133-323), command::execute_pipeline_graph
+// (src/vulkan/command.rs:166-242), GpuTimer (src/vulkan/vkutils.rs:47-135) and the
+// upload/download halves of Render (src/render.rs:264-313,:406-433).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rfhip.h"
+#include "rf_config.h"
+#include "rf_kernels.h"
+#include "rf_plan.h"
+
+namespace rf {
+
+// thread-local error text behind rf_last_error()
+void set_error(const std::string& msg);
+const char* last_error();
+
+struct RcclApi;   // lazily dlopen'ed librccl (only a multi-rank context needs it)
+
+}  // namespace rf
+
+struct rf_config {
+    rf::Config cfg;
+    std::vector<std::string> node_names;   // name-sorted
+};
+
+struct rf_plan {
+    rf::Plan plan;
+    std::vector<std::string> launch_labels;
+    std::vector<std::pair<std::string, std::string>> aliases;   // key-sorted
+};
+
+struct rf_ctx {
+    int device = 0;
+    int rank = 0, world = 1;
+    std::string arch;
+    hipStream_t util_stream = nullptr;     // uploads, fills, probes
+    float* d_tables = nullptr;             // sRGB eotf[256] ++ thr[255]
+    void* comm = nullptr;                  // ncclComm_t
+    const rf::RcclApi* rccl = nullptr;
+};
+
+namespace rf {
+
+struct DeviceImage {
+    void* alloc = nullptr;   // hipMalloc'd block: (ghost + rows + ghost) * pitch
+    char* base = nullptr;    // address of local row 0
+    size_t pitch = 0;
+    Image view() const { return Image{base, pitch}; }
+};
+
+// one kernel launch of the frame (a node, or a fused chain of nodes)
+struct Launch {
+    std::string label;
+    std::vector<std::string> members;
+    int layer = 0;
+    std::vector<std::string> src;   // allocated image names (1, or 2 for OP_MIX by binding order)
+    std::string dst;                // allocated image name
+    std::vector<Op> ops;
+    int radius = 0;                 // vertical halo read beyond the output rows
+    int need_src = 0;               // ghost rows of src this launch reads
+    int need_dst = 0;               // ghost rows of dst this launch must also produce
+};
+
+struct FrameSlot {
+    std::map<std::string, DeviceImage> images;
+    hipStream_t stream = nullptr;            // the frame's queue (Frame.cmd_buffer, frame.rs:10-18)
+    std::vector<hipStream_t> aux;            // side streams for multi-node layers
+    hipEvent_t fork = nullptr;
+    std::vector<hipEvent_t> join;
+    hipEvent_t done = nullptr;               // Frame.fence (frame.rs:47)
+    std::vector<hipEvent_t> t0, t1;          // GpuTimer query pairs, one per launch
+    bool timed_once = false;
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+};
+
+}  // namespace rf
+
+struct rf_graph {
+    rf_ctx* ctx = nullptr;
+    rf_graph_options opt{};
+    rf_plan plan;                      // owned view handed out by rf_graph_plan
+    int strip_y0 = 0, strip_y1 = 0;    // global rows this rank owns
+    int ghost = 0;                     // ghost rows allocated above and below every image
+    std::vector<rf::Launch> launches;  // execution order
+    std::vector<rf::FrameSlot> frames;
+    std::map<std::string, float*> dev_weights;   // conv2d nodes
+    std::string input_image;           // allocated name of rf:file-input ("" if the graph has none)
+    std::string output_image;          // allocated name rf:final-output resolves to
+    int need_input = 0;                // ghost rows of the input the frame reads
+    rf::StreamTuning tune;
+    uint8_t* d_staging = nullptr;      // RGBA8 staging rows (render.rs:552-564)
+    size_t staging_bytes = 0;
+    std::vector<std::string> time_names;   // scratch for rf_graph_node_times
+};
