@@ -132,6 +132,24 @@ const char* rf_plan_resolve(const rf_plan* plan, const char* resource);
  * ("a+b+c"); with RF_GRAPH_NO_FUSION one launch per node */
 int         rf_plan_num_launches(const rf_plan* plan);
 const char* rf_plan_launch_label(const rf_plan* plan, int i);
+int         rf_plan_launch_layer(const rf_plan* plan, int i);
+int         rf_plan_launch_num_members(const rf_plan* plan, int i);
+const char* rf_plan_launch_member(const rf_plan* plan, int i, int k);
+/* allocated images a launch reads (1; 2 for `combination`) and writes */
+int         rf_plan_launch_num_inputs(const rf_plan* plan, int i);
+const char* rf_plan_launch_input(const rf_plan* plan, int i, int k);
+const char* rf_plan_launch_output(const rf_plan* plan, int i);
+/* rows a launch reads above/below the rows it writes (sum of its stencil radii) */
+int         rf_plan_launch_radius(const rf_plan* plan, int i);
+/* [host] ghost-row schedule of a row-strip partition (new: SURVEY.md 8e).
+ *   exchange != 0: before launch i its input's need_src[i] = radius edge rows are
+ *                  exchanged with the neighbour ranks; need_dst[i] = 0.
+ *   exchange == 0: over-fetch (RF_GRAPH_NO_HALO_XCHG): the input carries *need_input
+ *                  ghost rows; launch i reads need_src[i] and also writes need_dst[i]
+ *                  ghost rows, so no per-launch communication is needed.
+ * n = capacity of the arrays (>= rf_plan_num_launches); *ghost = rows to allocate. */
+rf_status   rf_plan_halo_schedule(const rf_plan* plan, int exchange, int* need_src, int* need_dst, int n,
+                                  int* need_input, int* ghost);
 
 /* ------------------------------------------------------------------------- */
 /* Node-type registry: what SPIR-V reflection gives the reference             */
@@ -234,6 +252,13 @@ rf_status rf_graph_times_string(rf_graph* g, int frame_slot, char* buf, size_t c
 rf_status rf_graph_time_frames(rf_graph* g, int iters, float* total_ms);
 /* same, but one launch only (index into rf_plan_launch_label): average ms */
 rf_status rf_graph_time_launch(rf_graph* g, int launch, int iters, float* avg_ms);
+/* `iters` whole frames on slot 0 with a hipEvent pair around every launch, recorded on
+ * the stream that launch runs on: avg_ms[k] = average duration of launch k (execution
+ * order); n = capacity of avg_ms (>= rf_plan_num_launches) */
+rf_status rf_graph_time_launches(rf_graph* g, int iters, float* avg_ms, int n);
+/* one-rank RCCL round trip (communicator of world 1, grouped send+recv to self of
+ * `bytes` bytes on `device`): librccl loads and is called with the right ABI */
+rf_status rf_comm_selftest(int device, size_t bytes);
 /* float4 copy of `bytes` device bytes, `iters` times: achieved GB/s (the
  * practical HBM ceiling on this box) */
 rf_status rf_ctx_copy_bandwidth(rf_ctx* ctx, size_t bytes, int iters, float* gbps);

@@ -12,7 +12,7 @@ PipelineGraph (src/vulkan/pipeline_graph.rs), Render / RenderInfo
 """
 from ._lib import (RF_FORMAT_RGBA8, RF_FORMAT_RGBA32F, RF_GRAPH_TIMERS, RF_GRAPH_NO_FUSION,
                    RF_GRAPH_HIPGRAPH, RF_GRAPH_NO_HALO_XCHG, SO_PATH, lib)
-from .host import (RfError, Config, Plan, Context, Graph, Render, RenderInfo, get_dim,
+from .host import (RfError, Config, Plan, Context, Graph, Render, RenderInfo, get_dim, comm_selftest,
                    registry_types, registry_binding, strip_rows, FILE_INPUT, FINAL_OUTPUT)
 
 __all__ = [

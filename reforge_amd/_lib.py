@@ -70,6 +70,14 @@ SIGNATURES = {
     "rf_plan_resolve": (_cp, [_vp, _cp]),
     "rf_plan_num_launches": (_i, [_vp]),
     "rf_plan_launch_label": (_cp, [_vp, _i]),
+    "rf_plan_launch_layer": (_i, [_vp, _i]),
+    "rf_plan_launch_num_members": (_i, [_vp, _i]),
+    "rf_plan_launch_member": (_cp, [_vp, _i, _i]),
+    "rf_plan_launch_num_inputs": (_i, [_vp, _i]),
+    "rf_plan_launch_input": (_cp, [_vp, _i, _i]),
+    "rf_plan_launch_output": (_cp, [_vp, _i]),
+    "rf_plan_launch_radius": (_i, [_vp, _i]),
+    "rf_plan_halo_schedule": (_i, [_vp, _i, _pi, _pi, _i, _pi, _pi]),
     "rf_registry_num_types": (_i, []),
     "rf_registry_type_name": (_cp, [_i]),
     "rf_registry_binding": (_i, [_cp, _cp]),
@@ -103,6 +111,8 @@ SIGNATURES = {
     "rf_graph_times_string": (_i, [_vp, _i, _cp, _sz]),
     "rf_graph_time_frames": (_i, [_vp, _i, _pf]),
     "rf_graph_time_launch": (_i, [_vp, _i, _i, _pf]),
+    "rf_graph_time_launches": (_i, [_vp, _i, _pf, _i]),
+    "rf_comm_selftest": (_i, [_i, _sz]),
     "rf_ctx_copy_bandwidth": (_i, [_vp, _sz, _i, _pf]),
 }
 

@@ -164,8 +164,7 @@ extern "C" rf_status rf_plan_create(const rf_config* cfg, uint32_t flags, rf_pla
         delete p;
         return fail(RF_ERR_GRAPH, err);
     }
-    p->launch_labels = p->plan.launch_order();
-    p->aliases.assign(p->plan.reuse.begin(), p->plan.reuse.end());
+    p->index();
     *out = p;
     return RF_OK;
 }
@@ -207,10 +206,72 @@ extern "C" const char* rf_plan_resolve(const rf_plan* p, const char* resource)
     if (it == p->plan.reuse.end()) return resource;
     return p->plan.resolve(it->second).c_str();
 }
-extern "C" int rf_plan_num_launches(const rf_plan* p) { return p ? (int)p->launch_labels.size() : 0; }
+void rf_plan::index()
+{
+    aliases.assign(plan.reuse.begin(), plan.reuse.end());
+    launch_error.clear();
+    if (!build_launches(plan, launches, launch_error)) launches.clear();
+}
+
+static const LaunchDesc* launch_at(const rf_plan* p, int i)
+{
+    return (p && i >= 0 && i < (int)p->launches.size()) ? &p->launches[(size_t)i] : nullptr;
+}
+
+extern "C" int rf_plan_num_launches(const rf_plan* p) { return p ? (int)p->launches.size() : 0; }
 extern "C" const char* rf_plan_launch_label(const rf_plan* p, int i)
 {
-    return (p && i >= 0 && i < (int)p->launch_labels.size()) ? p->launch_labels[(size_t)i].c_str() : nullptr;
+    const LaunchDesc* l = launch_at(p, i);
+    return l ? l->label.c_str() : nullptr;
+}
+extern "C" int rf_plan_launch_layer(const rf_plan* p, int i)
+{
+    const LaunchDesc* l = launch_at(p, i);
+    return l ? l->layer : -1;
+}
+extern "C" int rf_plan_launch_num_members(const rf_plan* p, int i)
+{
+    const LaunchDesc* l = launch_at(p, i);
+    return l ? (int)l->members.size() : 0;
+}
+extern "C" const char* rf_plan_launch_member(const rf_plan* p, int i, int k)
+{
+    const LaunchDesc* l = launch_at(p, i);
+    return (l && k >= 0 && k < (int)l->members.size()) ? l->members[(size_t)k].c_str() : nullptr;
+}
+extern "C" int rf_plan_launch_num_inputs(const rf_plan* p, int i)
+{
+    const LaunchDesc* l = launch_at(p, i);
+    return l ? (int)l->src.size() : 0;
+}
+extern "C" const char* rf_plan_launch_input(const rf_plan* p, int i, int k)
+{
+    const LaunchDesc* l = launch_at(p, i);
+    return (l && k >= 0 && k < (int)l->src.size()) ? l->src[(size_t)k].c_str() : nullptr;
+}
+extern "C" const char* rf_plan_launch_output(const rf_plan* p, int i)
+{
+    const LaunchDesc* l = launch_at(p, i);
+    return l ? l->dst.c_str() : nullptr;
+}
+extern "C" int rf_plan_launch_radius(const rf_plan* p, int i)
+{
+    const LaunchDesc* l = launch_at(p, i);
+    return l ? l->radius : -1;
+}
+extern "C" rf_status rf_plan_halo_schedule(const rf_plan* p, int exchange, int* need_src, int* need_dst, int n,
+                                           int* need_input, int* ghost)
+{
+    if (!p || !need_src || !need_dst || !need_input || !ghost) return fail(RF_ERR_INVALID, "rf_plan_halo_schedule: null argument");
+    if (!p->launch_error.empty()) return fail(RF_ERR_GRAPH, p->launch_error);
+    if (n < (int)p->launches.size()) return fail(RF_ERR_INVALID, "rf_plan_halo_schedule: arrays shorter than rf_plan_num_launches");
+    std::vector<LaunchDesc> l = p->launches;
+    halo_schedule(l, true, exchange != 0, *need_input, *ghost);
+    for (size_t k = 0; k < l.size(); ++k) {
+        need_src[k] = l[k].need_src;
+        need_dst[k] = l[k].need_dst;
+    }
+    return RF_OK;
 }
 
 // ---------------------------------------------------------------------------------

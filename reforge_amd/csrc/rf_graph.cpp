@@ -94,8 +94,6 @@ rf_status fail(rf_status st, const std::string& msg)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-bool is_point_kind(int kind) { return kind == OP_PASSTHROUGH || kind == OP_GRADE; }
-
 RcclLib* ctx_rccl(const rf_ctx* ctx) { return (RcclLib*)ctx->rccl; }
 
 int strip_rows_of(const rf_graph* g) { return g->strip_y1 - g->strip_y0; }
@@ -120,6 +118,9 @@ rf_status exchange_rows(rf_graph* g, const DeviceImage& img, int r, hipStream_t 
     rf_ctx* ctx = g->ctx;
     if (ctx->world <= 1 || r <= 0) return RF_OK;
     RcclLib* lib = ctx_rccl(ctx);
+    if (!lib || !ctx->comm)
+        return fail(RF_ERR_UNSUPPORTED, "this rank has no RCCL communicator (rf_ctx_create_dist was given no unique id): "
+                                        "use RF_GRAPH_NO_HALO_XCHG with rf_graph_fill_*, or create the context with an id");
     const int Hs = strip_rows_of(g);
     const size_t bytes = (size_t)r * img.pitch;
     NCCL_TRY(lib, lib->GroupStart());
@@ -200,7 +201,6 @@ void rebuild_ops(rf_graph* g)
             auto it = g->dev_weights.find(m);
             L.ops.push_back(np.to_op(it == g->dev_weights.end() ? nullptr : it->second));
         }
-        L.radius = ops_radius(L.ops.data(), (int)L.ops.size());
     }
 }
 
@@ -210,11 +210,6 @@ void destroy_graph_exec(FrameSlot& f)
     if (f.graph) { (void)hipGraphDestroy(f.graph); f.graph = nullptr; }
 }
 
-void fill_plan_views(rf_plan& p)
-{
-    p.launch_labels = p.plan.launch_order();
-    p.aliases.assign(p.plan.reuse.begin(), p.plan.reuse.end());
-}
 
 }  // namespace
 
@@ -278,7 +273,9 @@ extern "C" rf_status rf_ctx_create_dist(int device, int rank, int world, const v
     ctx->rank = rank;
     ctx->world = world;
     if (world == 1) return RF_OK;
-    if (!id128) { rf_ctx_destroy(ctx); *out = nullptr; return fail(RF_ERR_INVALID, "rf_ctx_create_dist: null unique id"); }
+    // no unique id: a rank without a communicator.  Its graphs must carry their halo
+    // themselves (RF_GRAPH_NO_HALO_XCHG with a generated input); any exchange fails loudly.
+    if (!id128) return RF_OK;
     std::string err;
     RcclLib* lib = rccl_lib(err);
     if (!lib) { rf_ctx_destroy(ctx); *out = nullptr; return fail(RF_ERR_DEVICE, err); }
@@ -360,7 +357,7 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
     const rf_graph_options& opt = g->opt;
     std::string err;
     if (!build_plan(cfg->cfg, opt.flags, g->plan.plan, err)) return fail(RF_ERR_GRAPH, err);
-    fill_plan_views(g->plan);
+    g->plan.index();
     const Plan& plan = g->plan.plan;
 
     strip_rows(opt.height, ctx->world, ctx->rank, g->strip_y0, g->strip_y1);
@@ -382,86 +379,28 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
         HIP_TRY(hipMemcpy(d, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
     }
 
-    // launches in execution order
-    for (size_t layer = 0; layer < plan.layers.size(); ++layer) {
-        for (const auto& unit : plan.layers[layer]) {
-            const PipelineInfo& info = plan.infos.at(unit);
-            if (info.output_images.empty()) continue;   // nothing observable is written
+    // launches in execution order + the ghost rows each one reads beyond the strip
+    {
+        if (!g->plan.launch_error.empty()) return fail(RF_ERR_GRAPH, g->plan.launch_error);
+        std::vector<LaunchDesc> descs = g->plan.launches;
+        halo_schedule(descs, ctx->world > 1, exchange_mode(g), g->need_input, g->ghost);
+        if (exchange_mode(g) && g->ghost > 0 && !ctx->comm)
+            return fail(RF_ERR_UNSUPPORTED, "this rank has no RCCL communicator: create the graph with RF_GRAPH_NO_HALO_XCHG "
+                                            "or the context with a unique id");
+        for (const auto& d : descs) {
             Launch L;
-            L.label = unit;
-            L.members = info.members;
-            L.layer = (int)layer;
-            const int kind0 = plan.nodes.at(info.members[0]).type->kind;
-            if (info.input_images.empty())
-                return fail(RF_ERR_GRAPH, "node '" + unit + "' has no input image (a graph must start at 'input')");
-            if (kind0 == OP_MIX) {
-                std::string a, b;
-                for (const auto& in : info.input_images) {
-                    if (in.second == 0) a = in.first;
-                    if (in.second == 1) b = in.first;
-                }
-                if (a.empty() || b.empty() || info.input_images.size() != 2)
-                    return fail(RF_ERR_GRAPH, "node '" + unit + "' needs exactly input_image0 and input_image1");
-                L.src = {plan.resolve(a), plan.resolve(b)};
-            } else {
-                if (info.input_images.size() != 1)
-                    return fail(RF_ERR_GRAPH, "node '" + unit + "' takes one input image, the graph wires " +
-                                                  std::to_string(info.input_images.size()));
-                L.src = {plan.resolve(info.input_images[0].first)};
-            }
-            if (info.output_images.size() != 1)
-                return fail(RF_ERR_GRAPH, "node '" + unit + "' writes one output image, the graph wires " +
-                                              std::to_string(info.output_images.size()));
-            L.dst = plan.resolve(info.output_images[0].first);
-            for (const auto& s : L.src)
-                if (std::find(plan.images.begin(), plan.images.end(), s) == plan.images.end())
-                    return fail(RF_ERR_GRAPH, "No image found for input " + s);   // pipeline_graph.rs:236
+            static_cast<LaunchDesc&>(L) = d;
             g->launches.push_back(L);
         }
     }
     rebuild_ops(g);
-    for (const auto& L : g->launches) {
-        bool all_point = true;
-        for (const auto& op : L.ops) all_point = all_point && is_point_kind(op.kind);
-        if (L.ops.size() == 1 && L.ops[0].kind == OP_MIX) continue;
-        if (L.src[0] == L.dst && !all_point)
-            return fail(RF_ERR_GRAPH, "node '" + L.label + "' would run a stencil in place");
-    }
-
-    // ghost rows: what each launch reads beyond the strip
-    g->ghost = 0;
-    g->need_input = 0;
     g->input_image = std::find(plan.images.begin(), plan.images.end(), kFileInput) != plan.images.end() ? kFileInput : "";
     g->output_image = plan.resolve(kFinalOutput);
     if (std::find(plan.images.begin(), plan.images.end(), g->output_image) == plan.images.end())
         return fail(RF_ERR_GRAPH, "the graph never writes rf:final-output");
-    if (ctx->world > 1) {
-        if (exchange_mode(g)) {
-            for (auto& L : g->launches) {
-                L.need_src = L.radius;
-                L.need_dst = 0;
-                g->ghost = std::max(g->ghost, L.radius);
-            }
-        } else {
-            std::map<std::string, int> need;
-            for (size_t k = g->launches.size(); k-- > 0;) {
-                Launch& L = g->launches[k];
-                int nd = 0;
-                auto it = need.find(L.dst);
-                if (it != need.end()) { nd = it->second; need.erase(it); }
-                L.need_dst = nd;
-                L.need_src = nd + L.radius;
-                for (const auto& s : L.src) need[s] = std::max(need.count(s) ? need[s] : 0, L.need_src);
-                g->ghost = std::max(g->ghost, L.need_src);
-            }
-            if (!g->input_image.empty() && need.count(g->input_image)) g->need_input = need[g->input_image];
-        }
-        int min_rows = opt.height / ctx->world;
-        if (g->ghost > min_rows)
-            return fail(RF_ERR_UNSUPPORTED, "strip height " + std::to_string(min_rows) + " is smaller than the halo " + std::to_string(g->ghost));
-    } else {
-        for (auto& L : g->launches) { L.need_src = L.radius; L.need_dst = 0; }
-    }
+    if (ctx->world > 1 && g->ghost > opt.height / ctx->world)
+        return fail(RF_ERR_UNSUPPORTED, "strip height " + std::to_string(opt.height / ctx->world) +
+                                            " is smaller than the halo " + std::to_string(g->ghost));
 
     if (const char* e = std::getenv("RF_ROWS_PER_CHUNK")) g->tune.rows_per_chunk = std::atoi(e);
 
@@ -945,5 +884,95 @@ extern "C" rf_status rf_graph_time_launch(rf_graph* g, int launch, int iters, fl
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (st == RF_OK) *avg_ms = ms / (float)iters;
+    return st;
+}
+
+// `iters` whole frames on slot 0 with a hipEvent pair around EVERY launch (recorded on
+// the stream that launch runs on): average milliseconds per launch, in execution order.
+extern "C" rf_status rf_graph_time_launches(rf_graph* g, int iters, float* avg_ms, int n)
+{
+    FrameSlot* f;
+    rf_status st = slot_of(g, 0, &f, "rf_graph_time_launches");
+    if (st != RF_OK) return st;
+    const size_t nl = g->launches.size();
+    if (iters < 1 || !avg_ms || n < (int)nl) return fail(RF_ERR_INVALID, "rf_graph_time_launches: bad argument");
+    std::vector<hipEvent_t> ev(2 * nl * (size_t)iters, nullptr);
+    std::vector<hipEvent_t> keep0 = f->t0, keep1 = f->t1;
+    auto body = [&]() -> rf_status {
+        for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+        f->t0.assign(nl, nullptr);
+        f->t1.assign(nl, nullptr);
+        for (int it = 0; it < iters; ++it) {
+            for (size_t k = 0; k < nl; ++k) {
+                f->t0[k] = ev[2 * ((size_t)it * nl + k)];
+                f->t1[k] = ev[2 * ((size_t)it * nl + k) + 1];
+            }
+            rf_status s2 = issue_frame(g, *f, true);
+            if (s2 != RF_OK) return s2;
+        }
+        HIP_TRY(hipEventRecord(f->done, f->stream));
+        HIP_TRY(hipEventSynchronize(f->done));
+        for (size_t k = 0; k < nl; ++k) {
+            double sum = 0.0;
+            for (int it = 0; it < iters; ++it) {
+                float t = 0.f;
+                HIP_TRY(hipEventElapsedTime(&t, ev[2 * ((size_t)it * nl + k)], ev[2 * ((size_t)it * nl + k) + 1]));
+                sum += t;
+            }
+            avg_ms[k] = (float)(sum / iters);
+        }
+        return RF_OK;
+    };
+    st = body();
+    f->t0 = keep0;
+    f->t1 = keep1;
+    for (auto e : ev)
+        if (e) (void)hipEventDestroy(e);
+    return st;
+}
+
+// One-rank RCCL round trip on `device`: communicator of world 1, a grouped send+recv to
+// self of `bytes` bytes, result compared.  Proves that librccl loads and that the entry
+// points are called with the right ABI on this machine; the multi-rank pattern itself is
+// covered by tests/test_dist_gloo.py.
+extern "C" rf_status rf_comm_selftest(int device, size_t bytes)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RF_ERR_NO_DEVICE, "no HIP device (librfhip has no CPU fallback)");
+    if (device < 0 || device >= n || bytes == 0) return fail(RF_ERR_INVALID, "rf_comm_selftest: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    std::string err;
+    RcclLib* lib = rccl_lib(err);
+    if (!lib) return fail(RF_ERR_DEVICE, err);
+    NcclId id;
+    NCCL_TRY(lib, lib->GetUniqueId(&id));
+    void* comm = nullptr;
+    NCCL_TRY(lib, lib->CommInitRank(&comm, 1, id, 0));
+    char *a = nullptr, *b = nullptr;
+    hipStream_t s = nullptr;
+    std::vector<char> host(bytes), back(bytes);
+    for (size_t i = 0; i < bytes; ++i) host[i] = (char)(i * 131u + 7u);
+    auto body = [&]() -> rf_status {
+        HIP_TRY(hipMalloc((void**)&a, bytes));
+        HIP_TRY(hipMalloc((void**)&b, bytes));
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        HIP_TRY(hipMemcpyAsync(a, host.data(), bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(b, 0, bytes, s));
+        NCCL_TRY(lib, lib->GroupStart());
+        NCCL_TRY(lib, lib->Send(a, bytes, kNcclChar, 0, comm, s));
+        NCCL_TRY(lib, lib->Recv(b, bytes, kNcclChar, 0, comm, s));
+        NCCL_TRY(lib, lib->GroupEnd());
+        HIP_TRY(hipMemcpyAsync(back.data(), b, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (back != host) return fail(RF_ERR_DEVICE, "rf_comm_selftest: received bytes differ from the bytes sent");
+        return RF_OK;
+    };
+    rf_status st = body();
+    std::string keep = last_error();
+    if (s) (void)hipStreamDestroy(s);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    lib->CommDestroy(comm);
+    if (st != RF_OK) set_error(keep);
     return st;
 }

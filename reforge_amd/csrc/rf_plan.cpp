@@ -419,6 +419,110 @@ bool build_plan(const Config& cfg, uint32_t flags, Plan& plan, std::string& err)
     return true;
 }
 
+static bool point_kind(int kind) { return kind == OP_PASSTHROUGH || kind == OP_GRADE; }
+
+bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string& err)
+{
+    out.clear();
+    for (size_t layer = 0; layer < plan.layers.size(); ++layer) {
+        for (const auto& unit : plan.layers[layer]) {
+            // a node named in several graph expressions lists the same (resource, binding)
+            // more than once (config.rs:149-190 pushes per occurrence); the reference binds
+            // the same image to the same slot again, which is harmless
+            PipelineInfo info = plan.infos.at(unit);
+            auto dedupe = [](std::vector<std::pair<std::string, int>>& v) {
+                std::vector<std::pair<std::string, int>> u;
+                for (const auto& e : v)
+                    if (std::find(u.begin(), u.end(), e) == u.end()) u.push_back(e);
+                v.swap(u);
+            };
+            dedupe(info.input_images);
+            dedupe(info.output_images);
+            if (info.output_images.empty()) continue;   // nothing observable is written
+            LaunchDesc L;
+            L.label = unit;
+            L.members = info.members;
+            L.layer = (int)layer;
+            const int kind0 = plan.nodes.at(info.members[0]).type->kind;
+            if (info.input_images.empty()) {
+                err = "node '" + unit + "' has no input image (a graph must start at 'input')";
+                return false;
+            }
+            if (kind0 == OP_MIX) {
+                std::string a, b;
+                for (const auto& in : info.input_images) {
+                    if (in.second == 0) a = in.first;
+                    if (in.second == 1) b = in.first;
+                }
+                if (a.empty() || b.empty() || info.input_images.size() != 2) {
+                    err = "node '" + unit + "' needs exactly input_image0 and input_image1";
+                    return false;
+                }
+                L.src = {plan.resolve(a), plan.resolve(b)};
+            } else {
+                if (info.input_images.size() != 1) {
+                    err = "node '" + unit + "' takes one input image, the graph wires " + std::to_string(info.input_images.size());
+                    return false;
+                }
+                L.src = {plan.resolve(info.input_images[0].first)};
+            }
+            if (info.output_images.size() != 1) {
+                err = "node '" + unit + "' writes one output image, the graph wires " + std::to_string(info.output_images.size());
+                return false;
+            }
+            L.dst = plan.resolve(info.output_images[0].first);
+            for (const auto& s : L.src) {
+                if (std::find(plan.images.begin(), plan.images.end(), s) == plan.images.end()) {
+                    err = "No image found for input " + s;   // pipeline_graph.rs:236
+                    return false;
+                }
+            }
+            bool all_point = true;
+            std::vector<Op> ops;
+            for (const auto& m : L.members) {
+                ops.push_back(plan.nodes.at(m).to_op(nullptr));
+                all_point = all_point && point_kind(ops.back().kind);
+            }
+            L.radius = ops_radius(ops.data(), (int)ops.size());
+            if (kind0 != OP_MIX && L.src[0] == L.dst && !all_point) {
+                err = "node '" + unit + "' would run a stencil in place";
+                return false;
+            }
+            out.push_back(L);
+        }
+    }
+    return true;
+}
+
+void halo_schedule(std::vector<LaunchDesc>& launches, bool multi_rank, bool exchange, int& need_input, int& ghost)
+{
+    need_input = 0;
+    ghost = 0;
+    if (!multi_rank || exchange) {
+        // single rank: the clamp bounds are clipped to the frame, nothing is allocated
+        for (auto& L : launches) {
+            L.need_src = L.radius;
+            L.need_dst = 0;
+            if (multi_rank) ghost = std::max(ghost, L.radius);
+        }
+        return;
+    }
+    // over-fetch: walk the frame backwards; need[image] = ghost rows its pending readers want
+    std::map<std::string, int> need;
+    for (size_t k = launches.size(); k-- > 0;) {
+        LaunchDesc& L = launches[k];
+        int nd = 0;
+        auto it = need.find(L.dst);
+        if (it != need.end()) { nd = it->second; need.erase(it); }
+        L.need_dst = nd;
+        L.need_src = nd + L.radius;
+        for (const auto& s : L.src) need[s] = std::max(need.count(s) ? need[s] : 0, L.need_src);
+        ghost = std::max(ghost, L.need_src);
+    }
+    auto it = need.find(kFileInput);
+    if (it != need.end()) need_input = it->second;
+}
+
 void strip_rows(int height, int world, int rank, int& y0, int& y1)
 {
     // contiguous strips; the first (height % world) ranks hold one extra row

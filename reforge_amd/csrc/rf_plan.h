@@ -78,6 +78,31 @@ struct Plan {
     std::vector<std::string> launch_order() const;
 };
 
+// One kernel launch of a frame, in execution order.
+struct LaunchDesc {
+    std::string label;              // planned unit: node name or "a+b+c"
+    std::vector<std::string> members;
+    int layer = 0;
+    std::vector<std::string> src;   // allocated image names (1; 2 for OP_MIX in binding order)
+    std::string dst;                // allocated image name
+    int radius = 0;                 // vertical halo read beyond the rows written
+    int need_src = 0;               // ghost rows of src the launch reads (multi-rank)
+    int need_dst = 0;               // ghost rows of dst the launch must also produce (over-fetch mode)
+};
+
+// planned units -> launches; validates what the kernels can execute (one input image,
+// two for `combination`; one output image; no in-place stencil)
+bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string& err);
+
+// Ghost-row schedule of a row-strip partition (no reference counterpart).
+//   exchange = true : before a launch of vertical radius r its input's r edge rows are
+//                     exchanged with the neighbour ranks (need_src = r, need_dst = 0);
+//   exchange = false: over-fetch -- the input carries the cumulative halo of everything
+//                     downstream and each launch also produces the ghost rows its
+//                     consumers read (need_dst), so no per-launch communication.
+// need_input = ghost rows of rf:file-input the frame reads; ghost = rows to allocate.
+void halo_schedule(std::vector<LaunchDesc>& launches, bool multi_rank, bool exchange, int& need_input, int& ghost);
+
 constexpr uint32_t kPlanNoFusion = 0x2u;   // == RF_GRAPH_NO_FUSION
 
 bool build_plan(const Config& cfg, uint32_t flags, Plan& out, std::string& err);

@@ -36,7 +36,10 @@ struct rf_config {
 
 struct rf_plan {
     rf::Plan plan;
-    std::vector<std::string> launch_labels;
+    std::vector<rf::LaunchDesc> launches;                       // execution order; empty if launch_error is set
+    std::string launch_error;
+    // fills launches / aliases from `plan`
+    void index();
     std::vector<std::pair<std::string, std::string>> aliases;   // key-sorted
 };
 
@@ -59,17 +62,10 @@ struct DeviceImage {
     Image view() const { return Image{base, pitch}; }
 };
 
-// one kernel launch of the frame (a node, or a fused chain of nodes)
-struct Launch {
-    std::string label;
-    std::vector<std::string> members;
-    int layer = 0;
-    std::vector<std::string> src;   // allocated image names (1, or 2 for OP_MIX by binding order)
-    std::string dst;                // allocated image name
+// one kernel launch of the frame (a node, or a fused chain of nodes): the planner's
+// description plus the resolved device ops
+struct Launch : LaunchDesc {
     std::vector<Op> ops;
-    int radius = 0;                 // vertical halo read beyond the output rows
-    int need_src = 0;               // ghost rows of src this launch reads
-    int need_dst = 0;               // ghost rows of dst this launch must also produce
 };
 
 struct FrameSlot {

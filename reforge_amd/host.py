@@ -65,6 +65,11 @@ def strip_rows(height, world, rank):
     return y0.value, y1.value
 
 
+def comm_selftest(device=0, nbytes=1 << 20):
+    """One-rank RCCL send/recv round trip on `device` (rf_comm_selftest)."""
+    _check(lib().rf_comm_selftest(device, nbytes), "rf_comm_selftest")
+
+
 class Config:
     """config::Config (src/config/config.rs:35-38) parsed by the library."""
 
@@ -136,6 +141,24 @@ class Plan:
         L, h = lib(), self._h
         return [_s(L.rf_plan_launch_label(h, i)) for i in range(L.rf_plan_num_launches(h))]
 
+    def launch_info(self):
+        """One dict per kernel launch, in execution order."""
+        L, h = lib(), self._h
+        return [{"label": _s(L.rf_plan_launch_label(h, i)),
+                 "layer": L.rf_plan_launch_layer(h, i),
+                 "members": [_s(L.rf_plan_launch_member(h, i, k)) for k in range(L.rf_plan_launch_num_members(h, i))],
+                 "inputs": [_s(L.rf_plan_launch_input(h, i, k)) for k in range(L.rf_plan_launch_num_inputs(h, i))],
+                 "output": _s(L.rf_plan_launch_output(h, i)),
+                 "radius": L.rf_plan_launch_radius(h, i)} for i in range(L.rf_plan_num_launches(h))]
+
+    def halo_schedule(self, exchange=True):
+        """(need_src[], need_dst[], need_input, ghost) of a row-strip partition."""
+        n = lib().rf_plan_num_launches(self._h)
+        ns, nd = (C.c_int * max(n, 1))(), (C.c_int * max(n, 1))()
+        ni, gh = C.c_int(), C.c_int()
+        _check(lib().rf_plan_halo_schedule(self._h, int(exchange), ns, nd, n, C.byref(ni), C.byref(gh)), "rf_plan_halo_schedule")
+        return list(ns[:n]), list(nd[:n]), ni.value, gh.value
+
 
 class Context:
     """VkCore (src/vulkan/core.rs:66-146): one GPU, optionally one rank of a node-wide job."""
@@ -143,7 +166,8 @@ class Context:
     def __init__(self, device=0, rank=0, world=1, unique_id=None):
         self._h = C.c_void_p()
         if world > 1:
-            buf = C.create_string_buffer(bytes(unique_id), 128)
+            # unique_id None: a rank without a communicator (over-fetch graphs only)
+            buf = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
             _check(lib().rf_ctx_create_dist(device, rank, world, buf, C.byref(self._h)), "rf_ctx_create_dist")
         else:
             _check(lib().rf_ctx_create(device, C.byref(self._h)), "rf_ctx_create")
@@ -300,6 +324,13 @@ class Graph:
         ms = C.c_float()
         _check(lib().rf_graph_time_launch(self._h, launch, iters, C.byref(ms)), "rf_graph_time_launch")
         return ms.value
+
+    def time_launches(self, iters):
+        """[(label, average ms)] of every launch over `iters` frames, hipEvent pairs on the launch's stream."""
+        labels = self.plan.launches()
+        ms = (C.c_float * max(len(labels), 1))()
+        _check(lib().rf_graph_time_launches(self._h, iters, ms, len(labels)), "rf_graph_time_launches")
+        return list(zip(labels, list(ms[:len(labels)])))
 
 
 @dataclass

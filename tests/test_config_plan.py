@@ -1,0 +1,215 @@
+"""CPU: the product's config parser and planner (through the C ABI, host-only entry
+points) against the reference's documented semantics and
+against the Python restatement in oracle/graph.py."""
+import pytest
+
+import reforge_amd as rf
+from oracle import graph as og
+from tests import util
+
+NF = rf.RF_GRAPH_NO_FUSION
+
+
+def both(text, expects_input=True):
+    return rf.Config(text, expects_input).nodes(), og.parse_config(text, expects_input)
+
+
+def same_config(text, expects_input=True):
+    prod, ora = both(text, expects_input)
+    assert set(prod) == set(ora.graph_pipelines)
+    for name, node in prod.items():
+        assert node["inputs"] == ora.graph_pipelines[name]["inputs"], name
+        assert node["outputs"] == ora.graph_pipelines[name]["outputs"], name
+        assert node["type"] == ora.type_of(name)
+        assert node["params"] == ora.params_of(name)
+    return prod
+
+
+def test_default_graph_kat():
+    """"input -> passthrough -> output" (render.rs:115)."""
+    n = same_config("input -> passthrough -> output")
+    assert n == {"passthrough": {"type": "passthrough", "inputs": [("rf:file-input", "input_image")],
+                                 "outputs": [("rf:final-output", "output_image")], "params": {}}}
+
+
+def test_descriptor_suffix_semantics():
+    """config.rs:169-186: a mid-chain `X:foo` uses foo as BOTH its input and its output
+    descriptor; the next node reads resource `X:foo`."""
+    n = same_config("input -> aa:image -> bb -> output")
+    assert n["aa"]["inputs"] == [("rf:file-input", "image")]
+    assert n["aa"]["outputs"] == [("aa:image", "image")]
+    assert n["bb"]["inputs"] == [("aa:image", "input_image")]
+    assert n["bb"]["outputs"] == [("rf:final-output", "output_image")]
+
+
+def test_instances_and_values():
+    text = """
+    // a comment between expressions
+    input -> blur -> output
+    blur: gaussian { sigma: 2.5, radius: 3, flag: true, neg: -0.25, sigma: 1.5 }
+    /* block */
+    other: sharpen {}
+    """
+    n = same_config(text)
+    assert n["blur"]["type"] == "gaussian"
+    assert n["blur"]["params"] == {"sigma": "1.5", "radius": "3", "flag": "true", "neg": "-0.25"}   # last insert wins
+
+
+def test_multiple_graph_expressions_accumulate():
+    n = same_config(util.DIAMOND)
+    assert n["mixer"]["inputs"] == [("blur:output_image", "input_image0"), ("sharp:output_image", "input_image1")]
+    assert n["mixer"]["outputs"] == [("rf:final-output", "output_image")]
+
+
+@pytest.mark.parametrize("text,expects_input", [
+    ("", True), ("   \n\t", True),                    # config.rs:99-102
+    ("input -> aa", True),                            # 'output' never used, :202
+    ("input -> aa -> output", False),                 # 'input' without an input image, :201
+    ("input -> output", True),                        # empty graph, :200
+    ("input->aa->output", True),                      # '-' belongs to the identifier regex: "input-" then '>'
+    ("a -> output", True),                            # identifiers need two characters (:81)
+    ("input -> aa -> output\naa: passthrough { }", True),     # "{ }" is not the "{}" token
+    ("input -> aa -> output\naa: gaussian { sigma: -3 }", True),   # no negative integers (:75-76)
+    ("input -> aa -> output\naa: gaussian { sigma: 1e3 }", True),  # no exponents
+    ("input -> aa // trailing\n -> output", True),    # a comment ends the graph expression
+    ("aa", True), ("aa:bb", True), ("input -> -> output", True),
+    ("input -> aa -> output\naa: gaussian { sigma 1.0 }", True),
+])
+def test_rejected_configs(text, expects_input):
+    with pytest.raises(rf.RfError) as e:
+        rf.Config(text, expects_input)
+    assert e.value.status == 2          # RF_ERR_CONFIG
+    with pytest.raises(og.ConfigError):
+        og.parse_config(text, expects_input)
+
+
+def test_block_comment_longest_match_quirk():
+    """config_grammar.lalrpop:27: the regex accepts any text between the first "/*" and
+    the LAST "*/", and the lexer takes the longest match -- everything between two
+    block comments is swallowed.  Kept as the reference behaves."""
+    text = "input -> aa -> output\n/* one */ aa: gaussian { sigma: 9.0 } /* two */"
+    n = same_config(text)
+    assert n["aa"]["type"] == "aa" and n["aa"]["params"] == {}
+
+
+def test_single_shader_mode():
+    """config.rs:77-90"""
+    n = rf.Config(single="sharpen").nodes()
+    assert list(n) == ["sharpen"] and n["sharpen"]["inputs"] == [("rf:file-input", "input_image")]
+    n = rf.Config(single="sharpen", expects_input=False).nodes()
+    assert n["sharpen"]["inputs"] == [] and n["sharpen"]["outputs"] == [("rf:final-output", "output_image")]
+
+
+# ---- planner -----------------------------------------------------------------------
+def plans(text):
+    p = rf.Plan(rf.Config(text), NF)
+    cfg = og.parse_config(text)
+    infos = og.synthesize(cfg)
+    layers = og.order_by_execution(infos)
+    reuse = og.reusable_image_remapping(layers, infos)
+    return p, layers, reuse
+
+
+PLAN_CASES = [
+    "input -> passthrough -> output",
+    util.CHAIN3, util.CHAIN5, util.DIAMOND,
+    "input -> aa -> bb -> cc -> dd -> output\naa: passthrough {}\nbb: sharpen {}\ncc: passthrough {}\ndd: sharpen {}",
+    "input -> gaussian5 -> colour_grade:image -> sharpen -> output",
+    "input -> aa:image -> bb:image -> output\naa: grade {}\nbb: grade {}",
+    "input -> aa -> output\ninput -> bb -> output\naa: sharpen {}\nbb: gaussian5 {}",
+]
+
+
+@pytest.mark.parametrize("text", PLAN_CASES)
+def test_plan_matches_restatement(text):
+    p, layers, reuse = plans(text)
+    assert p.layers() == layers
+    assert p.aliases() == reuse
+    g = og.GraphOracle(text, 4, 4, util.F32)
+    assert p.images() == g.allocated_images()
+    assert p.launches() == [n for l in layers for n in l]
+    for r in list(reuse) + ["rf:final-output", "rf:file-input"]:
+        assert p.resolve(r) == og._remap(r, reuse)
+
+
+def test_diamond_layers_kat():
+    """pipeline_graph.rs:462-468: two independent branches form one layer, the join the next."""
+    p, _, _ = plans(util.DIAMOND)
+    assert p.layers() == [["blur", "sharp"], ["mixer"]]
+
+
+def test_four_chain_alias_kat():
+    """A->B->C->D: C reuses A's image, the final output reuses B's."""
+    p, _, _ = plans(PLAN_CASES[4])
+    assert p.aliases() == {"cc:output_image": "aa:output_image", "rf:final-output": "bb:output_image"}
+    assert p.images() == ["aa:output_image", "bb:output_image", "rf:file-input"]     # input + 2 ping-pong images
+
+
+def test_point_op_alias_kat():
+    """pipeline_graph.rs:400-411: same binding for input and output => in place."""
+    p, _, _ = plans(PLAN_CASES[5])
+    assert p.aliases() == {"colour_grade:image": "gaussian5:output_image"}
+    assert p.resolve("colour_grade:image") == "gaussian5:output_image"
+
+
+def test_file_input_is_never_recycled():
+    p, _, _ = plans(util.CHAIN5)
+    assert "rf:file-input" in p.images() and "rf:file-input" not in p.aliases().values()
+
+
+def test_cycle_is_rejected():
+    """pipeline_graph.rs:487-490"""
+    with pytest.raises(rf.RfError) as e:
+        rf.Plan(rf.Config("input -> aa -> bb -> aa -> output\naa: sharpen {}\nbb: sharpen {}"), NF)
+    assert e.value.status == 3 and "Graph incorrectly constructed" in str(e.value)
+
+
+def test_unknown_type_and_binding():
+    with pytest.raises(rf.RfError) as e:
+        rf.Plan(rf.Config("input -> nosuchfilter -> output"), NF)
+    assert e.value.status == 3
+    with pytest.raises(rf.RfError) as e:          # vkutils.rs:179
+        rf.Plan(rf.Config("input -> sharpen:nosuchimage -> output"), NF)
+    assert "has no binding named: nosuchimage" in str(e.value)
+
+
+def test_fusion_groups():
+    p = rf.Plan(rf.Config(util.CHAIN3), 0)
+    assert p.launches() == ["blur+grade+sharp"] and p.layers() == [["blur+grade+sharp"]]
+    assert p.images() == ["rf:file-input", "rf:final-output"] and p.aliases() == {}
+    p = rf.Plan(rf.Config(util.CHAIN5), 0)
+    assert p.launches() == ["blur+grade+sharp", "wide+finish"]
+    # a fused chain is planned as one node: the aliasing plan is recomputed on the fused
+    # graph, so its output can never land on the image it reads
+    assert p.resolve("rf:final-output") != "rf:file-input"
+    # branches are not fused across a fork/join
+    assert rf.Plan(rf.Config(util.DIAMOND), 0).launches() == ["blur", "sharp", "mixer"]
+    # an image that two nodes read is materialised
+    fork = "input -> aa -> bb -> output\naa -> cc -> output\naa: gaussian5 {}\nbb: grade {}\ncc: grade {}"
+    assert "aa" in rf.Plan(rf.Config(fork), 0).launches()
+
+
+def test_registry():
+    assert rf.registry_binding("passthrough", "input_image") == 0      # passthrough.comp:4
+    assert rf.registry_binding("passthrough", "output_image") == 1     # passthrough.comp:5
+    assert rf.registry_binding("passthrough", "image") == -1
+    assert rf.registry_binding("colour_grade", "image") == 2
+    assert set(og.NODE_TYPES) == set(rf.registry_types())
+
+
+def test_get_dim():
+    """utils.rs:56-74"""
+    assert rf.get_dim(800, 600) == (800, 600)
+    assert rf.get_dim(800, 600, 400, None) == (400, 300)
+    assert rf.get_dim(800, 600, None, 300) == (400, 300)
+    assert rf.get_dim(800, 600, 123, 45) == (123, 45)
+    assert rf.get_dim(1920, 1080, 1000, None) == (1000, 562)
+
+
+def test_strip_rows_partition():
+    for H, world in ((2160, 8), (16384, 8), (17, 4), (5, 5), (1080, 3)):
+        rows = [rf.strip_rows(H, world, r) for r in range(world)]
+        assert rows[0][0] == 0 and rows[-1][1] == H
+        assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in rows]
+        assert max(sizes) - min(sizes) <= 1

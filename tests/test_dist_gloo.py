@@ -1,0 +1,134 @@
+"""CPU, world_size 2 and 3 over gloo: the row-strip partition and the ghost-row
+schedules the product computes (rf_strip_rows, rf_plan_launch_*, rf_plan_halo_schedule --
+host-only C-ABI calls) are replayed with the CPU oracle as the per-strip kernel and
+torch.distributed (gloo) as the neighbour exchange, and must reproduce the full-frame
+result bit for bit.  This is the N>1 path of rf_graph.cpp (exchange_rows / launch_geom)
+with RCCL swapped for gloo and the HIP kernels swapped for the oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import reforge_amd as rf  # noqa: E402
+from oracle import graph as og  # noqa: E402
+from oracle import pixel  # noqa: E402
+from tests import util  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _member_chain_text(cfg, members):
+    lines = ["input -> " + " -> ".join(members) + " -> output"]
+    for m in members:
+        t = cfg.type_of(m)
+        params = cfg.params_of(m)
+        body = "{ " + ", ".join("%s: %s" % kv for kv in sorted(params.items())) + " }" if params else "{}"
+        lines.append("%s: %s %s" % (m, t, body))
+    return "\n".join(lines)
+
+
+def _exchange(arr, ghost, Hs, r, rank, world):
+    """exchange_rows of rf_graph.cpp: top r rows -> rank-1's bottom ghost, bottom r rows
+    -> rank+1's top ghost, and the symmetric receives."""
+    t = torch.from_numpy(arr)
+    ops = []
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, t[ghost:ghost + r].contiguous(), rank - 1))
+        ops.append(dist.P2POp(dist.irecv, t[ghost - r:ghost], rank - 1))
+    if rank < world - 1:
+        ops.append(dist.P2POp(dist.isend, t[ghost + Hs - r:ghost + Hs].contiguous(), rank + 1))
+        ops.append(dist.P2POp(dist.irecv, t[ghost + Hs:ghost + Hs + r], rank + 1))
+    for req in dist.batch_isend_irecv(ops) if ops else []:
+        req.wait()
+
+
+def _worker(rank, world, port, text, W, H, fmt, exchange, fused, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        flags = 0 if fused else rf.RF_GRAPH_NO_FUSION
+        plan = rf.Plan(rf.Config(text), flags)
+        launches = plan.launch_info()
+        need_src, need_dst, need_input, ghost = plan.halo_schedule(exchange)
+        y0, y1 = rf.strip_rows(H, world, rank)
+        Hs = y1 - y0
+        assert ghost <= H // world
+        cfg = og.parse_config(text)
+        dtype = pixel.dtype_of(fmt)
+        images = {name: np.full((Hs + 2 * ghost, W, 4), 77, dtype) for name in plan.images()}   # ghost rows start as garbage
+
+        # upload: every rank holds ONLY its own rows of the frame
+        frame = pixel.fill_synthetic(W, H, fmt, 0x5EED0004)
+        images[rf.FILE_INPUT][ghost:ghost + Hs] = frame[y0:y1]
+        if not exchange and need_input > 0:
+            _exchange(images[rf.FILE_INPUT], ghost, Hs, need_input, rank, world)      # after_input_write
+
+        for i, L in enumerate(launches):
+            if exchange and L["radius"] > 0:
+                for s in L["inputs"]:
+                    _exchange(images[s], ghost, Hs, L["radius"], rank, world)          # run_launch
+            # launch_geom
+            row_lo, row_hi = max(-need_src[i], -y0), min(Hs - 1 + need_src[i], H - 1 - y0)
+            o0, o1 = max(-need_dst[i], -y0), min(Hs + need_dst[i], H - y0)
+            srcs = [images[s][ghost + row_lo:ghost + row_hi + 1] for s in L["inputs"]]
+            if cfg.type_of(L["members"][0]) == "combination":
+                t = float(np.float32(float(cfg.params_of(L["members"][0])["mix"])))
+                res = pixel.mix(srcs[0], srcs[1], t)
+            else:
+                res = util.run_oracle(_member_chain_text(cfg, L["members"]), np.ascontiguousarray(srcs[0]))
+            images[L["output"]][ghost + o0:ghost + o1] = res[o0 - row_lo:o1 - row_lo]
+
+        out = images[plan.resolve(rf.FINAL_OUTPUT)][ghost:ghost + Hs]
+        np.save(os.path.join(out_dir, "strip%d.npy" % rank), out)
+    finally:
+        dist.destroy_process_group()
+
+
+CASES = [
+    # text, world, exchange, fused
+    (util.CHAIN5, 2, True, False),
+    (util.CHAIN5, 2, True, True),
+    (util.CHAIN5, 2, False, True),
+    (util.CHAIN5, 3, False, False),
+    (util.DIAMOND, 2, True, True),
+    (util.CHAIN3, 3, True, True),
+]
+
+
+@pytest.mark.parametrize("text,world,exchange,fused", CASES)
+@pytest.mark.parametrize("fmt", [util.F32, util.U8])
+def test_row_strips_reproduce_the_full_frame(tmp_path, text, world, exchange, fused, fmt):
+    W, H = 29, 41
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, text, W, H, fmt, exchange, fused, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / ("strip%d.npy" % r)) for r in range(world)], axis=0)
+    want = util.run_oracle(text, pixel.fill_synthetic(W, H, fmt, 0x5EED0004))
+    util.assert_same(got, want, "row strips, world=%d exchange=%s fused=%s" % (world, exchange, fused))
+
+
+def test_halo_schedules_kat():
+    """Exchange mode: each launch exchanges its own radius.  Over-fetch: the input
+    carries the cumulative halo (2+1+4 = 7 rows for the 5-stage chain)."""
+    p = rf.Plan(rf.Config(util.CHAIN5), rf.RF_GRAPH_NO_FUSION)
+    assert [l["radius"] for l in p.launch_info()] == [2, 0, 1, 4, 0]
+    assert p.halo_schedule(True) == ([2, 0, 1, 4, 0], [0, 0, 0, 0, 0], 0, 4)
+    assert p.halo_schedule(False) == ([7, 5, 5, 4, 0], [5, 5, 4, 0, 0], 7, 7)
+    p = rf.Plan(rf.Config(util.CHAIN5), 0)
+    assert [l["radius"] for l in p.launch_info()] == [3, 4]
+    assert p.halo_schedule(False) == ([7, 4], [4, 0], 7, 7)

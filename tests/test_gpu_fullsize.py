@@ -1,0 +1,113 @@
+"""GPU (MI355X): BASELINE.json's full sizes.  The oracle cannot run whole 4K/8K frames
+in seconds, so full frames are checked through size-independent properties:
+  * passthrough == identity (checksum of the whole frame against the generator);
+  * fused execution == one-launch-per-node execution, bit for bit, whole frame;
+  * the output does not depend on how rows are chunked across waves;
+  * BAND CHECK: for bands of rows at the top edge, the bottom edge and the interior, the
+    oracle is run on the band plus its halo (full width) and must equal the GPU rows
+    bit for bit -- any row of the frame could be chosen, so this samples the full-size
+    result against the oracle itself."""
+import os
+
+import numpy as np
+import pytest
+
+import reforge_amd as rf
+from oracle import pixel
+from tests import util
+
+pytestmark = pytest.mark.gpu
+NF = rf.RF_GRAPH_NO_FUSION
+
+GAUSS9 = "input -> gaussian9 -> output\ngaussian9: gaussian9 { sigma: 2.0 }"
+CONV31 = "input -> conv2d -> output\nconv2d: conv2d { ksize: 31, sigma: 5.0 }"
+
+
+def gpu_frame(ctx, text, W, H, fmt, seed, flags=0, rpc=None):
+    old = os.environ.get("RF_ROWS_PER_CHUNK")
+    if rpc is not None:
+        os.environ["RF_ROWS_PER_CHUNK"] = str(rpc)
+    try:
+        g = rf.Graph(ctx, rf.Config(text), W, H, fmt, flags=flags)
+    finally:
+        if rpc is not None:
+            if old is None:
+                os.environ.pop("RF_ROWS_PER_CHUNK", None)
+            else:
+                os.environ["RF_ROWS_PER_CHUNK"] = old
+    g.fill_synthetic(seed)
+    g.execute()
+    g.wait()
+    out = g.download_raw()
+    g.close()
+    return out
+
+
+def band_check(out, text, W, H, fmt, seed, radius, bands):
+    for b0, b1 in bands:
+        lo, hi = max(0, b0 - radius), min(H, b1 + radius)
+        src = pixel.fill_synthetic(W, hi - lo, fmt, seed, y0=lo)       # rows lo..hi of the frame
+        want = util.run_oracle(text, src)[b0 - lo:b1 - lo]
+        util.assert_same(np.ascontiguousarray(out[b0:b1]), np.ascontiguousarray(want), "rows %d..%d" % (b0, b1))
+
+
+def test_config1_passthrough_512_rgba8(ctx):
+    """BASELINE config 1: passthrough, 512x512 rgba8."""
+    out = gpu_frame(ctx, "input -> passthrough -> output", 512, 512, util.U8, 0x5EED0001)
+    assert out.tobytes() == pixel.fill_synthetic(512, 512, util.U8, 0x5EED0001).tobytes()
+
+
+def test_config2_chain3_4k_rgba32f(ctx):
+    """BASELINE config 2 (the headline metric): gaussian5 -> colour-grade -> sharpen, 3840x2160 rgba32f."""
+    W, H, seed = 3840, 2160, 0x5EED0002
+    fused = gpu_frame(ctx, util.CHAIN3, W, H, util.F32, seed)
+    unfused = gpu_frame(ctx, util.CHAIN3, W, H, util.F32, seed, flags=NF)
+    assert fused.tobytes() == unfused.tobytes()
+    assert gpu_frame(ctx, util.CHAIN3, W, H, util.F32, seed, rpc=61).tobytes() == fused.tobytes()
+    band_check(fused, util.CHAIN3, W, H, util.F32, seed, 3, [(0, 24), (1068, 1092), (2136, 2160)])
+
+
+def test_config2_chain3_4k_rgba8(ctx):
+    W, H, seed = 3840, 2160, 0x5EED0002
+    fused = gpu_frame(ctx, util.CHAIN3, W, H, util.U8, seed)
+    assert fused.tobytes() == gpu_frame(ctx, util.CHAIN3, W, H, util.U8, seed, flags=NF).tobytes()
+    band_check(fused, util.CHAIN3, W, H, util.U8, seed, 3, [(0, 16), (2144, 2160)])
+
+
+def test_passthrough_4k_identity(ctx):
+    W, H = 3840, 2160
+    out = gpu_frame(ctx, "input -> passthrough -> output", W, H, util.F32, 7)
+    assert out.tobytes() == pixel.fill_synthetic(W, H, util.F32, 7).tobytes()
+
+
+def test_config3_gaussian9_8k(ctx):
+    """BASELINE config 3: 9x9 separable gaussian, 7680x4320 rgba32f."""
+    W, H, seed = 7680, 4320, 0x5EED0003
+    out = gpu_frame(ctx, GAUSS9, W, H, util.F32, seed)
+    assert out.tobytes() == gpu_frame(ctx, GAUSS9, W, H, util.F32, seed, rpc=97).tobytes()
+    band_check(out, GAUSS9, W, H, util.F32, seed, 4, [(0, 12), (2000, 2012), (4308, 4320)])
+
+
+def test_config4_chain5_tall_strip(ctx):
+    """BASELINE config 4 is 16384^2 over 8 GPUs; one rank's share is a 16384 x 2048 strip.
+    Run that strip-sized frame on one GPU, fused vs unfused, plus band checks."""
+    W, H, seed = 16384, 2048, 0x5EED0004
+    fused = gpu_frame(ctx, util.CHAIN5, W, H, util.F32, seed)
+    assert fused.tobytes() == gpu_frame(ctx, util.CHAIN5, W, H, util.F32, seed, flags=NF).tobytes()
+    band_check(fused, util.CHAIN5, W, H, util.F32, seed, 7, [(0, 8), (1020, 1028), (2040, 2048)])
+
+
+def test_config5_conv31_8k_band(ctx):
+    """BASELINE config 5: 31x31 dense convolution on 7680x4320 rgba32f."""
+    W, H, seed = 7680, 4320, 0x5EED0005
+    out = gpu_frame(ctx, CONV31, W, H, util.F32, seed)
+    band_check(out, CONV31, W, H, util.F32, seed, 15, [(0, 2), (2159, 2161), (4318, 4320)])
+    # linearity in the input survives at full size: conv(x) of a constant frame is that
+    # constant times the kernel sum, identical at every pixel away from nothing (clamp-to-edge
+    # keeps a constant frame constant everywhere)
+    g = rf.Graph(ctx, rf.Config(CONV31), 512, 512, util.F32)
+    g.upload_raw(np.full((512, 512, 4), 0.5, np.float32))
+    g.execute(); g.wait()
+    c = g.download_raw()
+    g.close()
+    assert (c == c[0, 0, 0]).all() and abs(float(c[0, 0, 0]) - 0.5) < 1e-5

@@ -1,0 +1,283 @@
+"""GPU (MI355X): the HIP path, called through the C ABI (librfhip.so), against the CPU
+oracle on the same seeded inputs, against hand-derivable known answers and against the
+committed golden vectors.  Bit-exact for rgba8 AND rgba32f (the stated bar is
+pixel-exact rgba8 and <= 1 ulp rgba32f; the kernels use the oracle's exact fmaf order,
+so the tests hold them to 0 ulp).  One process, one rf_ctx for the whole session."""
+import os
+
+import numpy as np
+import pytest
+
+import reforge_amd as rf
+from oracle import pixel
+from tests import kat, util
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden.npz"))
+NF = rf.RF_GRAPH_NO_FUSION
+
+
+def test_the_hip_library_is_what_runs(ctx):
+    assert ctx.arch.startswith("gfx950")
+    with open("/proc/self/maps") as fh:
+        maps = fh.read()
+    assert "librfhip.so" in maps
+
+
+def test_rccl_loads_and_round_trips():
+    """One-rank communicator, grouped send+recv to self: librccl is loadable on the box and
+    is called with the right ABI.  (The multi-rank pattern is tests/test_dist_gloo.py.)"""
+    rf.comm_selftest(0, 3 * 3840 * 16)
+
+
+# ---- known answers (same checks the oracle passes in test_oracle.py) ----------------
+@pytest.fixture()
+def run(ctx):
+    def _run(text, img, weights=None):
+        return util.run_hip(ctx, text, img, weights=weights)
+    return _run
+
+
+@pytest.mark.parametrize("fmt", [util.F32, util.U8])
+@pytest.mark.parametrize("W,H", kat.PASSTHROUGH_SIZES)
+def test_passthrough_identity(run, fmt, W, H):
+    kat.check_passthrough_identity(run, fmt, W, H)
+
+
+def test_passthrough_special_floats(run):
+    kat.check_passthrough_preserves_special_floats(run)
+
+
+def test_unorm8_decode_all_codes(run):
+    """imageLoad of every UNORM8 code, observed through a gaussian delta kernel on rgba32f-free
+    arithmetic: an rgba8 grade with slope 1 reproduces c/255 -> store exactly."""
+    c = np.arange(256, dtype=np.uint8).reshape(1, 64, 4)
+    out = run("input -> gaussian5 -> output", np.ascontiguousarray(c))      # sigma absent: delta
+    assert (out == c).all()
+
+
+def test_impulse_responses(run):
+    kat.check_gaussian_impulse(run, GOLDEN)
+    kat.check_gaussian9_weights(run, GOLDEN)
+    kat.check_sharpen_impulse(run)
+    kat.check_conv_impulse_is_flipped_kernel(run)
+
+
+@pytest.mark.parametrize("fmt", [util.F32, util.U8])
+def test_degenerate_parameters_are_identity(run, fmt):
+    kat.check_gaussian_delta_is_identity(run, fmt)
+    kat.check_sharpen_zero_is_identity(run, fmt)
+
+
+def test_grade_properties(run):
+    kat.check_grade_saturation_zero_is_grey(run)
+    kat.check_unorm8_store_rounds_to_even(run)
+
+
+# ---- golden vectors -------------------------------------------------------------------
+@pytest.mark.parametrize("flags", [0, NF])
+@pytest.mark.parametrize("tag", ["f32", "u8"])
+def test_golden_vectors(ctx, tag, flags):
+    x = GOLDEN["in_" + tag]
+    for name, text in (("chain3", util.CHAIN3), ("chain5", util.CHAIN5), ("diamond", util.DIAMOND),
+                       ("gauss9", "input -> gaussian9 -> output\ngaussian9: gaussian9 { sigma: 2.0 }"),
+                       ("conv7", "input -> conv2d -> output\nconv2d: conv2d { ksize: 7, sigma: 1.5 }")):
+        util.assert_same(util.run_hip(ctx, text, x, flags=flags), GOLDEN["%s_%s" % (name, tag)], "%s %s flags=%d" % (name, tag, flags))
+
+
+# ---- oracle parity on seeded frames: every node type, ragged sizes, chunk seams ---------
+NODES = {
+    "passthrough": "input -> passthrough -> output",
+    "gaussian5": "input -> gaussian5 -> output\ngaussian5: gaussian5 { sigma: 1.0 }",
+    "gaussian9": "input -> gaussian9 -> output\ngaussian9: gaussian9 { sigma: 2.0 }",
+    "gaussian_r1": "input -> gg -> output\ngg: gaussian { sigma: 0.8, radius: 1 }",
+    "gaussian_r7": "input -> gg -> output\ngg: gaussian { sigma: 3.0, radius: 7 }",
+    "gaussian_r15": "input -> gg -> output\ngg: gaussian { sigma: 6.0, radius: 15 }",
+    "grade": "input -> grade -> output\ngrade: grade { slope: 1.3, offset: -0.1, saturation: 0.6 }",
+    "sharpen": "input -> sharpen -> output\nsharpen: sharpen { amount: 1.25 }",
+    "conv3": "input -> conv2d -> output\nconv2d: conv2d { ksize: 3, sigma: 0.7 }",
+    "conv9": "input -> conv2d -> output\nconv2d: conv2d { ksize: 9, sigma: 2.0 }",
+    "chain3": util.CHAIN3,
+    "chain5": util.CHAIN5,
+    "diamond": util.DIAMOND,
+    "inplace": "input -> gaussian5 -> colour_grade:image -> sharpen -> output\n"
+               "gaussian5: gaussian5 { sigma: 1.2 }\ncolour_grade: colour_grade { slope: 0.8, offset: 0.1, saturation: 1.5 }\n"
+               "sharpen: sharpen { amount: 0.4 }",
+}
+# widths around the strip seams (a 64-lane strip yields 64-2r columns), heights around chunks
+SIZES = [(1, 1), (2, 3), (5, 1), (1, 9), (17, 13), (59, 7), (60, 33), (61, 64), (121, 35), (250, 131)]
+
+
+@pytest.mark.parametrize("fmt", [util.F32, util.U8])
+@pytest.mark.parametrize("name", sorted(NODES))
+def test_node_parity_ragged_sizes(ctx, name, fmt):
+    for W, H in SIZES:
+        x = util.synthetic(W, H, fmt, seed=0x5EED0000 + W * 131 + H)
+        want = util.run_oracle(NODES[name], x)
+        util.assert_same(util.run_hip(ctx, NODES[name], x), want, "%s %dx%d fused" % (name, W, H))
+        util.assert_same(util.run_hip(ctx, NODES[name], x, flags=NF), want, "%s %dx%d unfused" % (name, W, H))
+
+
+@pytest.mark.parametrize("rows_per_chunk", [1, 2, 3, 7, 16, 1000])
+@pytest.mark.parametrize("name", ["gaussian9", "chain3", "chain5", "sharpen"])
+def test_chunk_seams(ctx, name, rows_per_chunk):
+    """Every vertical chunk re-primes its rolling windows: seams at every possible phase."""
+    W, H = 130, 45
+    for fmt in (util.F32, util.U8):
+        x = util.synthetic(W, H, fmt, seed=11)
+        want = util.run_oracle(NODES[name], x)
+        util.assert_same(util.run_hip(ctx, NODES[name], x, rows_per_chunk=rows_per_chunk), want,
+                         "%s rpc=%d" % (name, rows_per_chunk))
+
+
+def test_medium_frame_all_paths(ctx):
+    """640x360: large enough for several workgroups per strip row and many chunks."""
+    for fmt in (util.F32, util.U8):
+        x = util.synthetic(640, 360, fmt)
+        for text in (util.CHAIN3, util.CHAIN5, util.DIAMOND):
+            want = util.run_oracle(text, x)
+            for flags in (0, NF, rf.RF_GRAPH_HIPGRAPH, NF | rf.RF_GRAPH_HIPGRAPH, rf.RF_GRAPH_TIMERS):
+                util.assert_same(util.run_hip(ctx, text, x, flags=flags), want, "flags=%d" % flags)
+
+
+def test_structured_frame_and_fills(ctx):
+    """Device-side generators equal the oracle's, and the ramp+impulse frame goes through the chain."""
+    for fmt in (util.F32, util.U8):
+        W, H = 300, 170
+        g = rf.Graph(ctx, rf.Config("input -> passthrough -> output"), W, H, fmt)
+        g.fill_synthetic(0x5EED0001)
+        g.execute(); g.wait()
+        assert g.download_raw().tobytes() == pixel.fill_synthetic(W, H, fmt, 0x5EED0001).tobytes()
+        g.fill_structured()
+        g.execute(); g.wait()
+        s = pixel.fill_structured(W, H, fmt)
+        assert g.download_raw().tobytes() == s.tobytes()
+        g.close()
+        util.assert_same(util.run_hip(ctx, util.CHAIN3, s), util.run_oracle(util.CHAIN3, s), "structured chain3")
+
+
+def test_conv2d_31x31_and_custom_weights(ctx):
+    rng = np.random.RandomState(3)
+    w = rng.uniform(-0.05, 0.05, (31, 31)).astype(np.float32)
+    text = "input -> conv2d -> output\nconv2d: conv2d { ksize: 31, sigma: 5.0 }"
+    for fmt in (util.F32, util.U8):
+        x = util.synthetic(97, 50, fmt)
+        util.assert_same(util.run_hip(ctx, text, x), util.run_oracle(text, x), "conv31 default weights")
+        util.assert_same(util.run_hip(ctx, text, x, weights={"conv2d": w}), util.run_oracle(text, x, {"conv2d": w}), "conv31 custom")
+
+
+# ---- the sRGB boundary (render.rs:264-313, :406-433) ------------------------------------
+def test_srgb_identity_and_lut(ctx):
+    c = np.zeros((4, 256, 4), np.uint8)
+    c[:, :, :] = np.arange(256)[None, :, None]
+    for fmt, want_rgb in ((util.F32, np.arange(256)), (util.U8, GOLDEN["srgb_rgba8_roundtrip"])):
+        g = rf.Graph(ctx, rf.Config("input -> passthrough -> output"), 256, 4, fmt)
+        g.upload_srgb8(c)
+        g.execute(); g.wait()
+        out = g.download_srgb8()
+        assert (out[..., 0] == want_rgb[None, :]).all() and (out[..., 3] == np.arange(256)[None, :]).all()
+        lin = g.download_raw()
+        assert lin.tobytes() == pixel.upload_srgb8(c, fmt).tobytes()
+        g.close()
+
+
+def test_srgb_chain_matches_oracle(ctx):
+    rgba = pixel.fill_synthetic(211, 97, util.U8, 0xABCDEF)
+    for fmt in (util.F32, util.U8):
+        from oracle import graph as og
+        ref = og.GraphOracle(util.CHAIN3, 211, 97, fmt)
+        ref.upload_srgb8(rgba)
+        ref.execute()
+        g = rf.Graph(ctx, rf.Config(util.CHAIN3), 211, 97, fmt)
+        g.upload_srgb8(rgba)
+        g.execute(); g.wait()
+        assert g.download_srgb8().tobytes() == ref.download_srgb8().tobytes()
+        g.close()
+
+
+def test_srgb_encode_edge_values(ctx):
+    x = np.zeros((1, 8, 4), np.float32)
+    x[0, :, 0] = [np.nan, -1.0, 0.0, 1.0, 2.0, np.inf, -np.inf, 0.5]
+    x[0, :, 3] = [np.nan, -1.0, 0.0, 1.0, 2.0, 0.5, 0.25, 0.75]
+    g = rf.Graph(ctx, rf.Config("input -> passthrough -> output"), 8, 1, util.F32)
+    g.upload_raw(x)
+    g.execute(); g.wait()
+    assert g.download_srgb8().tobytes() == pixel.download_srgb8(x).tobytes()
+    g.close()
+
+
+# ---- executor behaviour ------------------------------------------------------------------
+def test_parameters_timers_and_frames_in_flight(ctx):
+    W, H, fmt = 200, 120, util.F32
+    x = util.synthetic(W, H, fmt)
+    g = rf.Graph(ctx, rf.Config(util.CHAIN3), W, H, fmt, num_frames=2, flags=rf.RF_GRAPH_TIMERS | NF)
+    assert g.node_times(0) == []                       # nothing recorded yet (vkutils.rs:107-109)
+    g.upload_raw(x)
+    for slot in (0, 1, 0):
+        g.execute(slot)
+    g.wait(0); g.wait(1)
+    want = util.run_oracle(util.CHAIN3, x)
+    util.assert_same(g.download_raw(0), want, "slot 0")
+    util.assert_same(g.download_raw(1), want, "slot 1")
+    times = g.node_times(0)
+    assert [n for n, _ in times] == ["blur", "grade", "sharp"] and all(0.0 < t < 50.0 for _, t in times)
+    s = g.times_string(0)
+    assert s.startswith("blur: ") and s.count("ms") == 3 and ", grade: " in s
+    # update a uniform member (render.rs:167-210) and re-run
+    g.set_param("sharp", "amount", 1.0)
+    g.execute(0); g.wait(0)
+    text2 = util.CHAIN3.replace("amount: 0.5", "amount: 1.0")
+    util.assert_same(g.download_raw(0), util.run_oracle(text2, x), "after set_param")
+    with pytest.raises(rf.RfError) as e:
+        g.set_param("sharp", "nosuch", 1.0)
+    assert e.value.status == 16
+    # the intermediate images of the unfused graph are observable
+    two = "input -> blur -> grade -> output\nblur: gaussian5 { sigma: 1.0 }\ngrade: colour_grade { slope: 1.1, offset: -0.02, saturation: 1.2 }"
+    util.assert_same(g.download_image("grade:output_image", 1), util.run_oracle(two, x), "intermediate image")
+    assert g.plan.resolve("rf:final-output") == "blur:output_image"     # the output reuses the first ping-pong image
+    g.close()
+
+
+def test_radius_change_needs_a_new_graph(ctx):
+    g = rf.Graph(ctx, rf.Config("input -> gg -> output\ngg: gaussian { sigma: 1.0, radius: 2 }"), 64, 64, util.F32)
+    with pytest.raises(rf.RfError) as e:
+        g.set_param("gg", "radius", 3)
+    assert e.value.status == 6
+    g.set_param("gg", "sigma", 2.0)
+    g.close()
+
+
+def test_graph_errors(ctx):
+    with pytest.raises(rf.RfError) as e:                # no input image wired (pipeline_graph.rs:236 panics)
+        rf.Graph(ctx, rf.Config("sharpen -> output", expects_input=False), 32, 32, util.F32)
+    assert e.value.status == 3
+    with pytest.raises(rf.RfError):
+        rf.Graph(ctx, rf.Config("input -> passthrough -> output"), 0, 32, util.F32)
+
+
+def test_render_host_mirror(ctx, tmp_path):
+    """The Render object drives the same call order as main.rs:134-182 (headless)."""
+    cfg = tmp_path / "pipe.cfg"
+    cfg.write_text(util.CHAIN3)
+    info = rf.RenderInfo(width=96, height=64, config_path=str(cfg), format=util.F32)
+    r = rf.Render(info, ctx)
+    rgba = pixel.fill_synthetic(96, 64, util.U8, 42)
+    r.staging_buffer()[...] = rgba
+    out = r.render_frame().copy()
+    from oracle import graph as og
+    ref = og.GraphOracle(util.CHAIN3, 96, 64, util.F32)
+    ref.upload_srgb8(rgba); ref.execute()
+    assert out.tobytes() == ref.download_srgb8().tobytes()
+    assert "ms" in r.last_frame_gpu_times()
+    # hot reload: a broken config keeps the old graph; a fixed one replaces it (render.rs:121-165)
+    cfg.write_text("input -> nosuchfilter -> output")
+    os.utime(cfg, (1, 1))
+    assert r.trigger_reloads() is False and r.graph is not None
+    cfg.write_text("input -> passthrough -> output")
+    os.utime(cfg, (2, 2))
+    assert r.trigger_reloads() is True
+    r.staging_buffer()[...] = rgba
+    out2 = r.render_frame()
+    assert out2.tobytes() == rgba.tobytes()             # sRGB identity through rgba32f
+    r.graph.close()
