@@ -58,7 +58,8 @@ struct Geom {
 
 // Tuning knobs (0 = heuristic).  Read once from the environment by rf_graph.
 struct StreamTuning {
-    int rows_per_chunk = 0;
+    int rows_per_chunk = 0;   // RF_ROWS_PER_CHUNK
+    int prefetch_rows = 0;    // RF_PREFETCH_ROWS: 0 = the kernel's default (4), 8 = deeper ring
 };
 
 // true if `ops[0..n)` can run as ONE streaming launch (a fused pipeline)

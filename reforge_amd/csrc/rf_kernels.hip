@@ -29,6 +29,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <type_traits>
+
 namespace rf {
 
 typedef float4 f4;
@@ -59,6 +61,20 @@ struct PxF32 {
     static constexpr bool QUANT = false;
     RF_DEV static Raw load(const char* row, unsigned xoff) { return *reinterpret_cast<const f4*>(row + xoff); }
     RF_DEV static f4 decode(Raw r) { return r; }
+    // Take a row out of the prefetch ring into registers of its own.  A real v_mov (the asm
+    // is opaque to the optimiser) ends the ring slot's live range HERE, so the refill that
+    // follows loads in place and the slot keeps its registers around the loop; without it
+    // the compiler renames, copies the slots at the back edge and drains every load in
+    // flight with s_waitcnt vmcnt(0) to do so.
+    RF_DEV static f4 take(Raw r)
+    {
+        f4 o;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(o.x) : "v"(r.x));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(o.y) : "v"(r.y));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(o.z) : "v"(r.z));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(o.w) : "v"(r.w));
+        return o;
+    }
     RF_DEV static void store(char* row, unsigned xoff, f4 v) { *reinterpret_cast<f4*>(row + xoff) = v; }
     RF_DEV static f4 requant(f4 v) { return v; }
 };
@@ -73,6 +89,7 @@ struct PxU8 {
         return make_float4(unorm8_to_f32(r & 255u), unorm8_to_f32((r >> 8) & 255u),
                            unorm8_to_f32((r >> 16) & 255u), unorm8_to_f32(r >> 24));
     }
+    RF_DEV static f4 take(Raw r) { return decode(r); }   // the conversion already leaves the ring slot dead
     RF_DEV static unsigned pack(f4 v)
     {
         return f32_to_unorm8(v.x) | (f32_to_unorm8(v.y) << 8) | (f32_to_unorm8(v.z) << 16) |
@@ -111,42 +128,152 @@ RF_DEV void wave_sync()
 }
 
 // ---------------------------------------------------------------------------------
-// Row stages.  A stage sees a window win[0 .. 2*RV] of consecutive rows of its input
-// (win[RV] is the row it emits for) and returns that output row's texel for the lane.
+// Source: the wave's input rows, streamed global -> LDS by LDS-DMA (global_load_lds_*:
+// no VGPR destination) into a wave-private ring of PF row slots, PF rows ahead.
+//
+// Why hand-written: with compiler-visible loads hipcc drains EVERY load in flight
+// (s_waitcnt vmcnt(0)) at each use, because loads and stores share vmcnt on gfx9 and its
+// wait-count pass treats mixed pending events as out of order.  The DMA is issued from an
+// asm statement (invisible to that pass) and waited for with a COUNTED vmcnt: vector
+// memory operations retire in issue order, and a wave issues exactly one DMA per input
+// row and one store per output row, in a fixed program order (see wait_row).
 // ---------------------------------------------------------------------------------
-template <int R> struct Window { f4 win[2 * R + 1]; };
+template <int N> RF_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+struct Sink {
+    char* dst;          // address of local row 0
+    size_t pitch;
+    unsigned xoff;      // lane's byte offset in a row
+    bool lane_ok;       // lane owns an output texel
+    int row;            // next output row
+    int first_store;    // iteration of the first store, -1 before it (wave-uniform)
+};
+
+template <class Px, int PF> struct Source {
+    static_assert(PF >= 2, "the ring needs at least two slots");
+    static constexpr int SLOTS = PF;
+    static constexpr int SLOT_BYTES = 64 * Px::BPP;
+    const char* src;      // address of local row 0, already offset by the lane's column
+    ptrdiff_t pitch;
+    int a0, n0;           // first source row, number of source rows
+    unsigned lds_base;    // LDS byte address of slot 0 (wave-uniform)
+    const char* ring;     // the same ring through a generic pointer
+
+    RF_DEV const char* slot(int r) const { return ring + (size_t)(r % SLOTS) * SLOT_BYTES; }
+
+    // DMA source row r into slot r % PF.  Program order inside iteration `it` is
+    //   [first stage consumes row it] -> issue(it+PF) -> wait_row(it+1) -> ... -> store
+    RF_DEV void issue(int r) const
+    {
+        const char* g = src + (ptrdiff_t)(a0 + r) * pitch;
+        const unsigned dst = lds_base + (unsigned)(r % SLOTS) * (unsigned)SLOT_BYTES;
+        unsigned keep;
+        if constexpr (Px::BPP == 16)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+    }
+    RF_DEV void prologue() const
+    {
+        for (int r = 0; r < PF && r < n0; ++r) issue(r);
+    }
+    // Wait until row r has landed, leaving younger operations in flight.  Younger than
+    // row r's DMA at this point: the DMAs of rows r+1 .. r+PF-1 (when they exist) and, once
+    // the pipeline emits a row per iteration, the stores of the PF-1 iterations in between.
+    RF_DEV void wait_row(int r, const Sink& k) const
+    {
+        if (n0 - 1 - r >= PF - 1) {
+            if (k.first_store >= 0 && k.first_store <= r - PF) wait_vmcnt<2 * PF - 2>();
+            else wait_vmcnt<PF - 1>();
+        } else {
+            wait_vmcnt<0>();
+        }
+    }
+};
+
+// what the first stage is handed each iteration, fetched from the ring one iteration
+// ahead so the LDS latency hides behind the previous row's arithmetic
+template <class Px> struct OwnFeed {      // the lane's own texel
+    typename Px::Raw nxt;
+    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane& L)
+    {
+        nxt = *reinterpret_cast<const typename Px::Raw*>(s.slot(r) + (size_t)L.lane * Px::BPP);
+    }
+    RF_DEV f4 own() const { return Px::decode(nxt); }
+};
+template <int R> struct TapFeed {         // rgba32f: the 2R+1 horizontal taps, straight from the DMA ring
+    f4 t[2 * R + 1];
+    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane& L)
+    {
+        const f4* row = reinterpret_cast<const f4*>(s.slot(r));
+#pragma unroll
+        for (int i = -R; i <= R; ++i) t[i + R] = row[L.nbr(i)];
+    }
+    RF_DEV f4 own() const { return t[R]; }
+};
+
+// ---------------------------------------------------------------------------------
+// Row stages.  advance() is called once per row entering the stage:
+//   v      the row's texel for this lane (undefined when !real)
+//   real   a new input row; false = the newest row repeated (clamp-to-edge below the frame)
+//   first  the stage's first row: it primes the whole window (clamp-to-edge above the frame,
+//          or rows that are shifted out again before anything is emitted)
+//   emit   the window's centre row is wanted downstream (wave-uniform, from the schedule)
+// ---------------------------------------------------------------------------------
+struct NoState {};
 
 // horizontal taps of the separable gaussian: sum_i w[|i|] * in[x+i], ascending i
 template <int R> struct StHTap {
     static constexpr int RV = 0, RH = R, LDS_ROWS = (R > 0) ? 1 : 0;
     struct Params { float w[R + 1]; };
-    template <class Px> RF_DEV static f4 compute(const Params& p, const Window<0>& s, const Lane& L, f4* lds)
+    template <class Px> using State = NoState;
+    // as the FIRST stage of an rgba32f pipeline the taps come straight from the DMA ring
+    template <class Px> using Feed = typename std::conditional<Px::QUANT, OwnFeed<Px>, TapFeed<R>>::type;
+    RF_DEV static f4 from_taps(const Params& p, const TapFeed<R>& f)
     {
-        f4 c = s.win[0];
+        f4 acc = f4_zero();
+#pragma unroll
+        for (int i = -R; i <= R; ++i) acc = fma4(p.w[i < 0 ? -i : i], f.t[i + R], acc);
+        return acc;
+    }
+    template <class Px> RF_DEV static void advance(const Params& p, NoState&, const Lane& L, f4* lds, f4 v, bool, bool, bool, f4& out)
+    {
         if constexpr (R > 0) {
-            lds[L.lane] = c;
+            lds[L.lane] = v;
             wave_sync();
         }
         f4 acc = f4_zero();
 #pragma unroll
         for (int i = -R; i <= R; ++i) {
-            f4 v = (i == 0) ? c : lds[L.nbr(i)];
-            acc = fma4(p.w[i < 0 ? -i : i], v, acc);
+            f4 t = (i == 0) ? v : lds[L.nbr(i)];
+            acc = fma4(p.w[i < 0 ? -i : i], t, acc);
         }
-        return acc;
+        out = acc;
     }
 };
 
-// vertical taps: sum_j w[|j|] * tmp[y+j], ascending j
+// vertical taps: sum_j w[|j|] * tmp[y+j], ascending j; the window lives in VGPRs
 template <int R> struct StVTap {
     static constexpr int RV = R, RH = 0, LDS_ROWS = 0;
     struct Params { float w[R + 1]; };
-    template <class Px> RF_DEV static f4 compute(const Params& p, const Window<R>& s, const Lane&, f4*)
+    template <class Px> struct State { f4 win[2 * R + 1]; };
+    template <class Px> using Feed = OwnFeed<Px>;
+    template <class Px> RF_DEV static void advance(const Params& p, State<Px>& s, const Lane&, f4*, f4 v, bool real, bool first, bool emit, f4& out)
     {
-        f4 acc = f4_zero();
+        const int pushes = first ? 2 * R + 1 : 1;
+        for (int q = 0; q < pushes; ++q) {
 #pragma unroll
-        for (int j = -R; j <= R; ++j) acc = fma4(p.w[j < 0 ? -j : j], s.win[j + R], acc);
-        return acc;
+            for (int i = 0; i < 2 * R; ++i) s.win[i] = s.win[i + 1];
+            if (real) s.win[2 * R] = v;
+        }
+        if (emit) {
+            f4 acc = f4_zero();
+#pragma unroll
+            for (int j = -R; j <= R; ++j) acc = fma4(p.w[j < 0 ? -j : j], s.win[j + R], acc);
+            out = acc;
+        }
     }
 };
 
@@ -154,38 +281,59 @@ template <int R> struct StVTap {
 struct StGrade {
     static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
     struct Params { float slope, offset, saturation; };
+    template <class Px> using State = NoState;
+    template <class Px> using Feed = OwnFeed<Px>;
     RF_DEV static float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
-    template <class Px> RF_DEV static f4 compute(const Params& p, const Window<0>& s, const Lane&, f4*)
+    template <class Px> RF_DEV static void advance(const Params& p, NoState&, const Lane&, f4*, f4 c, bool, bool, bool, f4& out)
     {
-        f4 c = s.win[0];
         float tr = fmaf(c.x, p.slope, p.offset);
         float tg = fmaf(c.y, p.slope, p.offset);
         float tb = fmaf(c.z, p.slope, p.offset);
         float luma = fmaf(0.0722f, tb, fmaf(0.7152f, tg, 0.2126f * tr));
-        return make_float4(clamp01(fmaf(p.saturation, tr - luma, luma)),
-                           clamp01(fmaf(p.saturation, tg - luma, luma)),
-                           clamp01(fmaf(p.saturation, tb - luma, luma)), c.w);
+        out = make_float4(clamp01(fmaf(p.saturation, tr - luma, luma)), clamp01(fmaf(p.saturation, tg - luma, luma)),
+                          clamp01(fmaf(p.saturation, tb - luma, luma)), c.w);
     }
 };
 
-// 3x3 sharpen cross [0,s,0; s,c,s; 0,s,0], taps in ascending (y outer, x inner) order
+// 3x3 sharpen cross [0,s,0; s,c,s; 0,s,0], taps in ascending (y outer, x inner) order.
+// The horizontal neighbours of a row are fetched through LDS when the row ARRIVES and
+// are first used one iteration later, when that row is the centre: the LDS round trip
+// hides behind a whole iteration instead of stalling the wave.
 struct StCross3 {
     static constexpr int RV = 1, RH = 1, LDS_ROWS = 1;
     struct Params { float wc, ws; };
-    template <class Px> RF_DEV static f4 compute(const Params& p, const Window<1>& s, const Lane& L, f4* lds)
+    template <class Px> struct State { f4 n, c, cw, ce; };   // rows y-1, y and y's left/right neighbours
+    template <class Px> using Feed = OwnFeed<Px>;
+    RF_DEV static void exchange(const Lane& L, f4* lds, f4 v, f4& w, f4& e)
     {
-        f4 c = s.win[1];
-        lds[L.lane] = c;
+        lds[L.lane] = v;
         wave_sync();
-        f4 l = lds[L.nbr(-1)];
-        f4 r = lds[L.nbr(+1)];
-        f4 acc = f4_zero();
-        acc = fma4(p.ws, s.win[0], acc);
-        acc = fma4(p.ws, l, acc);
-        acc = fma4(p.wc, c, acc);
-        acc = fma4(p.ws, r, acc);
-        acc = fma4(p.ws, s.win[2], acc);
-        return acc;
+        w = lds[L.nbr(-1)];
+        e = lds[L.nbr(+1)];
+    }
+    template <class Px> RF_DEV static void advance(const Params& p, State<Px>& s, const Lane& L, f4* lds, f4 v, bool real, bool first, bool emit, f4& out)
+    {
+        if (first) {                     // window = [v, v, (next row)]
+            s.n = v;
+            s.c = v;
+            exchange(L, lds, v, s.cw, s.ce);
+            return;
+        }
+        const f4 below = real ? v : s.c;
+        if (emit) {
+            f4 acc = f4_zero();
+            acc = fma4(p.ws, s.n, acc);
+            acc = fma4(p.ws, s.cw, acc);
+            acc = fma4(p.wc, s.c, acc);
+            acc = fma4(p.ws, s.ce, acc);
+            acc = fma4(p.ws, below, acc);
+            out = acc;
+        }
+        s.n = s.c;
+        if (real) {
+            s.c = v;
+            exchange(L, lds, v, s.cw, s.ce);
+        }
     }
 };
 
@@ -194,9 +342,11 @@ struct StCross3 {
 struct StNodeEnd {
     static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
     struct Params {};
-    template <class Px> RF_DEV static f4 compute(const Params&, const Window<0>& s, const Lane&, f4*)
+    template <class Px> using State = NoState;
+    template <class Px> using Feed = OwnFeed<Px>;
+    template <class Px> RF_DEV static void advance(const Params&, NoState&, const Lane&, f4*, f4 v, bool, bool, bool, f4& out)
     {
-        return Px::requant(s.win[0]);
+        out = Px::requant(v);
     }
 };
 
@@ -214,14 +364,7 @@ template <class... S> struct SumRH { static constexpr int value = 0; };
 template <class S, class... Rest> struct SumRH<S, Rest...> { static constexpr int value = S::RH + SumRH<Rest...>::value; };
 template <class... S> struct SumLDS { static constexpr int value = 0; };
 template <class S, class... Rest> struct SumLDS<S, Rest...> { static constexpr int value = S::LDS_ROWS + SumLDS<Rest...>::value; };
-
-struct Sink {
-    char* dst;          // address of local row 0
-    size_t pitch;
-    unsigned xoff;      // lane's byte offset in a row
-    bool lane_ok;       // lane owns an output texel
-    int row;            // next output row
-};
+template <class S, class...> struct FirstOf { typedef S type; };
 
 template <class Px, int LdsIdx, class... S> struct Chain;
 
@@ -229,17 +372,19 @@ template <class Px, int LdsIdx, class... S> struct Chain;
 template <class Px, int LdsIdx> struct Chain<Px, LdsIdx> {
     RF_DEV void plan_backward(int oa, int ob, int, int, int& in_a, int& in_b) { in_a = oa; in_b = ob; }
     RF_DEV int plan_forward(int tprev) { return tprev; }
-    RF_DEV void step(bool has, f4 v, int, const Lane&, Sink& k, const ParamPack<>&)
+    template <bool STEADY> RF_DEV void step(bool has, f4 v, int it, const Lane&, Sink& k, const ParamPack<>&)
     {
-        if (has) {
+        if (STEADY || has) {
+            // exactly ONE vector-memory instruction per emitted row: Source::wait_row counts on it
             if (k.lane_ok) Px::store(k.dst + (ptrdiff_t)k.row * (ptrdiff_t)k.pitch, k.xoff, v);
             k.row += 1;
+            if (!STEADY && k.first_store < 0) k.first_store = it;
         }
     }
 };
 
 template <class Px, int LdsIdx, class S, class... Rest> struct Chain<Px, LdsIdx, S, Rest...> {
-    Window<S::RV> st;
+    typename S::template State<Px> st;
     // wave-uniform schedule
     int a;        // first input row
     int oa;       // first output row
@@ -266,31 +411,76 @@ template <class Px, int LdsIdx, class S, class... Rest> struct Chain<Px, LdsIdx,
         tprev = tp;
         return next.plan_forward(tp + flush);
     }
-    RF_DEV void step(bool has_prev, f4 v, int it, const Lane& L, Sink& k, const ParamPack<S, Rest...>& P)
+    // A row (or a flush tick) enters this stage.  STEADY = every stage receives a real row,
+    // is past its first row and emits: the schedule tests fold away at compile time.
+    template <bool STEADY> RF_DEV void step(bool has_prev, f4 v, int it, const Lane& L, Sink& k, const ParamPack<S, Rest...>& P)
     {
-        bool in_valid = has_prev || (it > tprev && it <= tprev + flush);
         bool has = false;
         f4 out = f4_zero();
-        if (in_valid) {
-            f4 vin = has_prev ? v : st.win[2 * S::RV];
+        if constexpr (STEADY) {
+            S::template advance<Px>(P.p, st, L, L.lds + LdsIdx * 64, v, true, false, true, out);
+            cnt += 1;
+            has = true;
+        } else if constexpr (S::RV == 0) {
+            if (has_prev) {              // row-local stage: one row in, one row out, never flushed
+                S::template advance<Px>(P.p, st, L, L.lds + LdsIdx * 64, v, true, cnt == 0, true, out);
+                cnt += 1;
+                has = true;
+            }
+        } else {
+            const bool flushing = !has_prev && it > tprev && it <= tprev + flush;
+            if (has_prev || flushing) {
+                has = (a + cnt - S::RV) >= oa;
+                S::template advance<Px>(P.p, st, L, L.lds + LdsIdx * 64, v, has_prev, cnt == 0, has, out);
+                cnt += 1;
+            }
+        }
+        next.template step<STEADY>(has, out, it, L, k, P.rest);
+    }
+    // first stage: the row comes from the source feed; once it is consumed its ring slot is
+    // refilled and the NEXT row's values are fetched into registers
+    template <bool STEADY, class Feed, class Src>
+    RF_DEV void step_first(bool has0, Feed& feed, const Src& src, int it, const Lane& L, Sink& k, const ParamPack<S, Rest...>& P)
+    {
+        bool has = false;
+        f4 out = f4_zero();
+        if constexpr (STEADY) {
+            if constexpr (std::is_same<Feed, OwnFeed<Px>>::value)
+                S::template advance<Px>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), true, false, true, out);
+            else
+                out = S::from_taps(P.p, feed);
+            cnt += 1;
+            has = true;
+            src.issue(it + Src::SLOTS);
+            wait_vmcnt<2 * Src::SLOTS - 2>();
+            feed.fetch(src, it + 1, L);
+        } else {
             if constexpr (S::RV == 0) {
-                st.win[0] = vin;
+                if (has0) {
+                    if constexpr (std::is_same<Feed, OwnFeed<Px>>::value)
+                        S::template advance<Px>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), true, cnt == 0, true, out);
+                    else
+                        out = S::from_taps(P.p, feed);
+                    cnt += 1;
+                    has = true;
+                }
             } else {
-                if (cnt == 0) {
-#pragma unroll
-                    for (int i = 0; i <= 2 * S::RV; ++i) st.win[i] = vin;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 2 * S::RV; ++i) st.win[i] = st.win[i + 1];
-                    st.win[2 * S::RV] = vin;
+                const bool flushing = !has0 && it > tprev && it <= tprev + flush;
+                if (has0 || flushing) {
+                    has = (a + cnt - S::RV) >= oa;
+                    S::template advance<Px>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), has0, cnt == 0, has, out);
+                    cnt += 1;
                 }
             }
-            int centre = a + cnt - S::RV;
-            cnt += 1;
-            has = centre >= oa;
-            if (has) out = S::template compute<Px>(P.p, st, L, L.lds + LdsIdx * 64);
+            if (has0) {
+                if (it + Src::SLOTS < src.n0) src.issue(it + Src::SLOTS);
+                if (it + 1 < src.n0) {
+                    src.wait_row(it + 1, k);
+                    feed.fetch(src, it + 1, L);
+                }
+            }
         }
-        next.step(has, out, it, L, k, P.rest);
+        next.template step<STEADY>(has, out, it, L, k, P.rest);
     }
 };
 
@@ -311,7 +501,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void stream_kernel(const Strea
     constexpr int RH = SumRH<S...>::value;
     constexpr int VALID = 64 - 2 * RH;
     constexpr int LDSR = SumLDS<S...>::value;
+    typedef Source<Px, PF> Src;
+    typedef typename FirstOf<S...>::type::template Feed<Px> Feed;
     __shared__ f4 smem[kWavesPerBlock][(LDSR > 0 ? LDSR : 1) * 64];
+    __shared__ __attribute__((aligned(16))) char ring[kWavesPerBlock][Src::SLOTS * Src::SLOT_BYTES];
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int strip = (int)blockIdx.x * kWavesPerBlock + wave;
@@ -333,37 +526,38 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void stream_kernel(const Strea
     k.xoff = (unsigned)min(max(L.x, 0), A.W - 1) * (unsigned)Px::BPP;
     k.lane_ok = (L.lane >= RH) && (L.lane < 64 - RH) && (L.x < A.W);
     k.row = y0;
+    k.first_store = -1;
 
     Chain<Px, 0, S...> chain;
-    int a0, b0;
-    chain.plan_backward(y0, y1 - 1, A.row_lo, A.row_hi, a0, b0);
-    const int n0 = b0 - a0 + 1;                      // source rows
-    const int total = chain.plan_forward(n0 - 1) + 1;
+    Src src;
+    int b0;
+    chain.plan_backward(y0, y1 - 1, A.row_lo, A.row_hi, src.a0, b0);
+    src.n0 = b0 - src.a0 + 1;                        // source rows
+    const int total = chain.plan_forward(src.n0 - 1) + 1;
 
-    // source: rows a0..b0, column clamp(x), prefetched PF rows ahead
-    const unsigned src_xoff = k.xoff;
-    typename Px::Raw ring[PF];
-#pragma unroll
-    for (int j = 0; j < PF; ++j) {
-        ring[j] = typename Px::Raw();
-        if (j < n0) ring[j] = Px::load(A.src + (ptrdiff_t)(a0 + j) * (ptrdiff_t)A.src_pitch, src_xoff);
+    // source: rows a0..b0, column clamp(x)
+    src.src = A.src + k.xoff;
+    src.pitch = (ptrdiff_t)A.src_pitch;
+    src.ring = ring[wave];
+    src.lds_base = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&ring[0][0]) + (unsigned)wave * (unsigned)(Src::SLOTS * Src::SLOT_BYTES));
+    src.prologue();
+    Feed feed;
+    src.wait_row(0, k);
+    feed.fetch(src, 0, L);
+
+    // Three phases: a generic loop while the pipeline primes, a branch-free STEADY loop while
+    // every stage takes a real row and emits one (and the counted waits are in their steady
+    // form: the PF-1 previous iterations all stored, the next PF rows all exist), and the
+    // generic loop again for the tail and the bottom-edge flush.
+    int it = 0;
+    while (it < total && !(k.first_store >= 0 && it + 1 - PF >= k.first_store)) {
+        chain.template step_first<false>(it < src.n0, feed, src, it, L, k, A.params);
+        ++it;
     }
-    for (int base = 0; base < total; base += PF) {
-#pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            const int it = base + j;
-            if (it < total) {
-                const bool has0 = it < n0;
-                f4 v0 = f4_zero();
-                if (has0) {
-                    v0 = Px::decode(ring[j]);
-                    if (it + PF < n0)
-                        ring[j] = Px::load(A.src + (ptrdiff_t)(a0 + it + PF) * (ptrdiff_t)A.src_pitch, src_xoff);
-                }
-                chain.step(has0, v0, it, L, k, A.params);
-            }
-        }
-    }
+    const int steady_end = src.n0 - PF;
+    for (; it < steady_end; ++it) chain.template step_first<true>(true, feed, src, it, L, k, A.params);
+    for (; it < total; ++it) chain.template step_first<false>(it < src.n0, feed, src, it, L, k, A.params);
 }
 
 // ---------------------------------------------------------------------------------
@@ -543,7 +737,10 @@ static int choose_rows_per_chunk(int rows, int n_strips, int halo_rows, const St
     int chunks = (target_waves + n_strips - 1) / n_strips;
     if (chunks < 1) chunks = 1;
     int rpc = (rows + chunks - 1) / chunks;
-    int min_rpc = halo_rows > 0 ? 20 * halo_rows : 8;
+    // measured on MI355X (3840x2160, fused 3-stage chain, 6 halo rows per chunk): 48-row chunks
+    // 49 us, 32-row 51 us, 64..90-row 54-56 us, 135-row 62 us -- more, shorter chunks win until
+    // the re-read of the vertical halo (2*halo_rows per chunk) passes ~12 % of a chunk
+    int min_rpc = halo_rows > 0 ? 16 * halo_rows : 8;
     if (rpc < min_rpc) rpc = min_rpc;
     if (rpc > rows) rpc = rows;
     if (rpc < 1) rpc = 1;
@@ -574,6 +771,14 @@ static hipError_t launch_stream(Image src, Image dst, const Geom& g, const Strea
     A.params = params;
     dim3 grid((unsigned)((A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock),
               (unsigned)((rows + A.rows_per_chunk - 1) / A.rows_per_chunk));
+    // prefetch depth: the template argument is the default; RF_PREFETCH_ROWS=8 selects the
+    // deeper ring where it is instantiated (radius <= 4)
+    if constexpr (PF == 4) {
+        if (tune.prefetch_rows == 8) {
+            hipLaunchKernelGGL((stream_kernel<Px, 8, S...>), grid, dim3(64 * kWavesPerBlock), 0, stream, A);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((stream_kernel<Px, PF, S...>), grid, dim3(64 * kWavesPerBlock), 0, stream, A);
     return hipGetLastError();
 }

@@ -35,11 +35,18 @@ if __name__ == "__main__":
         print("copy GB/s", nb >> 20, "MiB:", ctx.copy_bandwidth(nb, 20), flush=True)
     F = rf.RF_FORMAT_RGBA32F
     rpcs = os.environ.get("PROBE_RPC", "0").split(",")
-    for rpc in rpcs:
-        os.environ["RF_ROWS_PER_CHUNK"] = rpc
-        run(ctx, CHAIN3, 3840, 2160, F, rf.RF_GRAPH_NO_FUSION, label="4K unfused rpc=" + rpc)
-        run(ctx, CHAIN3, 3840, 2160, F, 0, label="4K fused rpc=" + rpc)
+    pfs = os.environ.get("PROBE_PF", "0").split(",")
+    for pf in pfs:
+        os.environ["RF_PREFETCH_ROWS"] = pf
+        for rpc in rpcs:
+            os.environ["RF_ROWS_PER_CHUNK"] = rpc
+            if os.environ.get("PROBE_UNFUSED", "1") == "1":
+                run(ctx, CHAIN3, 3840, 2160, F, rf.RF_GRAPH_NO_FUSION, label="4K unfused pf=%s rpc=%s" % (pf, rpc))
+            run(ctx, CHAIN3, 3840, 2160, F, 0, label="4K fused pf=%s rpc=%s" % (pf, rpc))
     os.environ["RF_ROWS_PER_CHUNK"] = "0"
+    os.environ["RF_PREFETCH_ROWS"] = "0"
+    if os.environ.get("PROBE_REST", "1") != "1":
+        sys.exit(0)
     run(ctx, "input -> passthrough -> output", 3840, 2160, F, 0, label="4K passthrough")
     run(ctx, "input -> gaussian9 -> output\ngaussian9: gaussian9 {sigma: 2.0}", 7680, 4320, F, 0, label="8K gaussian9")
     run(ctx, CHAIN3, 7680, 4320, F, 0, label="8K fused3")
