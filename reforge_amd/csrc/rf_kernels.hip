@@ -599,6 +599,124 @@ __global__ __launch_bounds__(256) void conv2d_tile_kernel(const char* src, size_
 }
 
 // ---------------------------------------------------------------------------------
+// conv2d on the matrix cores: dense KxK correlation as a banded (Toeplitz) contraction on
+// v_mfma_f32_16x16x4_f32.  This is the im2col idea restricted to what a single shared
+// KxK kernel allows: the "patch matrix" has only ONE filter column, so instead the
+// horizontal taps of one weight row become a banded matrix
+//     T_dy[x_in][x_out] = w[dy][x_in - x_out]   (0 outside the K taps)
+// and for every weight row dy
+//     Out[(y,c)][x_out] += In[(y+dy, c)][x_in] * T_dy[x_in][x_out]
+// with M = 16 = 4 output rows x 4 channels, N = 16 output columns, K-dim = the 16+2r
+// input columns (padded to a multiple of 4).  31x31: 12 MFMAs per weight row per tile,
+// 31/48 = 65 % of the multiply-adds are real taps.
+//
+// Exactness: an f32 MFMA is a k-ordered chain of single-rounding fmaf (MI355X guide,
+// "FP32-input MFMA"), the contraction index runs over x_in ascending = dx ascending, weight
+// rows are accumulated dy ascending, and a zero band entry adds exactly nothing to a finite
+// sum -- so the result is bit-identical to the oracle's (dy outer, dx inner) fmaf chain for
+// finite inputs.  (A non-finite texel poisons the whole 16-column tile row it feeds instead
+// of only the K columns around it: 0 * inf = NaN.)
+//
+// Data movement: one workgroup (4 waves = 64 output columns) walks DOWN a chunk of rows 8
+// output rows at a time, keeping the 8+2r input rows it needs in an LDS ring (row pitch = 8
+// mod 32 dwords so the 16 (row,channel) x 2 (k) operand reads of a lane group hit 32 banks);
+// each step loads only the 8 new rows, so an input row is fetched once per strip.
+// ---------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kConvStripW = 64;     // output columns per workgroup
+constexpr int kConvStepRows = 8;    // output rows per step (2 M-tiles of 4 rows per wave)
+constexpr int kConvWRow = 64;       // dwords per padded weight row: 15 zeros, K taps, zeros
+
+static int conv_mfma_pitch(int r) { return (((kConvStripW + 2 * r) * 4 + 31) & ~31) + 8; }   // dwords, = 8 mod 32
+static int conv_mfma_ring(int r) { return (kConvStepRows + 2 * r + 3) & ~3; }
+
+template <class Px, int STEPS>   // STEPS = MFMA k-steps per weight row = ceil((16 + 2r) / 4), compile-time so the row unrolls
+__global__ __launch_bounds__(256) void conv2d_mfma_kernel(const char* src, size_t src_pitch, char* dst, size_t dst_pitch,
+                                                          int W, int row_lo, int row_hi, int y0, int y1, int rows_per_chunk,
+                                                          int K, int pitch, int ring, const float* __restrict__ weights)
+{
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    float* wpad = reinterpret_cast<float*>(dyn_smem);            // [K][64]
+    float* tile = wpad + K * kConvWRow;                           // [ring][pitch]
+    const int r = K / 2;
+    const int xin = kConvStripW + 2 * r;                          // input columns of the strip
+    const int tid = (int)threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 15, kq = lane >> 4;                      // B: column j, k index kq;  A: row i = lane&15, k index kq
+    const int a_yy = (lane & 15) >> 2, a_c = lane & 3;
+
+    const int x_out0 = (int)blockIdx.x * kConvStripW;
+    const int cy0 = y0 + (int)blockIdx.y * rows_per_chunk;
+    const int cy1 = min(cy0 + rows_per_chunk, y1);
+    if (cy0 >= cy1) return;
+
+    // padded weight rows: wpad[dy][15 + t] = w[dy][t]
+    for (int i = tid; i < K * kConvWRow; i += 256) {
+        int dy = i / kConvWRow, t = i % kConvWRow - 15;
+        wpad[i] = (t >= 0 && t < K) ? weights[dy * K + t] : 0.0f;
+    }
+
+    // columns beyond the strip's last input column are multiplied by zero band entries: they
+    // must be finite, so the whole ring starts as zeros
+    for (int i = tid; i < ring * pitch; i += 256) tile[i] = 0.0f;
+    __syncthreads();
+
+    const int first_in = cy0 - r;                                 // frame row held by ring offset 0
+    int loaded_to = first_in;                                     // rows [first_in, loaded_to) are in the ring
+    for (int ys = cy0; ys < cy1; ys += kConvStepRows) {
+        // stage the rows this step needs that are not in the ring yet (clamp-to-edge on load)
+        const int need_to = ys + kConvStepRows + r;
+        const int nrows = need_to - loaded_to;
+        for (int i = tid; i < nrows * xin; i += 256) {
+            const int rr = loaded_to + i / xin, xx = i % xin;
+            const int gy = min(max(rr, row_lo), row_hi);
+            const int gx = min(max(x_out0 - r + xx, 0), W - 1);
+            const f4 v = Px::decode(Px::load(src + (ptrdiff_t)gy * (ptrdiff_t)src_pitch, (unsigned)gx * (unsigned)Px::BPP));
+            const int slot = (rr - first_in) % ring;
+            *reinterpret_cast<f4*>(tile + slot * pitch + xx * 4) = v;
+        }
+        loaded_to = need_to;
+        __syncthreads();
+
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // ring slot of input row (ys + 4m + yy + dy - r) = ((ys - cy0) + 4m + yy + dy) mod ring
+        int slot0 = ((ys - cy0) + a_yy) % ring;
+        int slot1 = ((ys - cy0) + 4 + a_yy) % ring;
+        const int a_col = (16 * wave + kq) * 4 + a_c;              // dword offset of (column 16w+k, channel c)
+        const float* bptr = wpad + 15 + kq - j;
+        for (int dy = 0; dy < K; ++dy) {
+            const float* a0 = tile + slot0 * pitch + a_col;
+            const float* a1 = tile + slot1 * pitch + a_col;
+            const float* b = bptr + dy * kConvWRow;
+            // all operand reads of the weight row are issued ahead of its MFMAs
+            float bv[STEPS], av0[STEPS], av1[STEPS];
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                bv[s] = b[4 * s];
+                av0[s] = a0[16 * s];
+                av1[s] = a1[16 * s];
+            }
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[s], bv[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[s], bv[s], acc1, 0, 0, 0);
+            }
+            slot0 = slot0 + 1 == ring ? 0 : slot0 + 1;
+            slot1 = slot1 + 1 == ring ? 0 : slot1 + 1;
+        }
+        // D: column j = lane&15, row i = 4*(lane>>4) + reg  =>  output row yy = lane>>4, channel = reg
+        const int ox = x_out0 + 16 * wave + j;
+        const int oy0 = ys + kq, oy1 = ys + 4 + kq;
+        if (ox < W) {
+            if (oy0 < cy1) Px::store(dst + (ptrdiff_t)oy0 * (ptrdiff_t)dst_pitch, (unsigned)ox * (unsigned)Px::BPP, make_float4(acc0[0], acc0[1], acc0[2], acc0[3]));
+            if (oy1 < cy1) Px::store(dst + (ptrdiff_t)oy1 * (ptrdiff_t)dst_pitch, (unsigned)ox * (unsigned)Px::BPP, make_float4(acc1[0], acc1[1], acc1[2], acc1[3]));
+        }
+        __syncthreads();      // the next step overwrites the oldest rows
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Synthetic inputs, identical to rfo_fill_* in the oracle
 // ---------------------------------------------------------------------------------
 RF_DEV uint32_t hash32(uint32_t seed, uint32_t idx, uint32_t c)
@@ -869,6 +987,30 @@ template <class Px, int R> static hipError_t run_gauss_grade_sharpen(const Op* o
     return launch_stream<Px, PF_DEFAULT, StHTap<R>, StVTap<R>, StNodeEnd, StGrade, StNodeEnd, StCross3>(s, d, g, t, st, P, R + 1);
 }
 
+// k-steps 5..12 cover 9x9 (r = 4 -> 6) .. 31x31 (r = 15 -> 12); smaller kernels use the tile kernel
+template <class Px, int STEPS = 5>
+static hipError_t launch_conv_mfma(int steps, dim3 grid, size_t lds, hipStream_t stream, const char* src, size_t src_pitch, char* dst,
+                                   size_t dst_pitch, int W, int row_lo, int row_hi, int y0, int y1, int rpc, int K, int pitch, int ring,
+                                   const float* weights)
+{
+    if constexpr (STEPS > 12) {
+        return hipErrorInvalidValue;
+    } else {
+        if (steps != STEPS)
+            return launch_conv_mfma<Px, STEPS + 1>(steps, grid, lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0, y1, rpc, K,
+                                                   pitch, ring, weights);
+        static bool attr_set = false;   // more than 64 KiB of dynamic LDS needs the attribute
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<Px, STEPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv2d_mfma_kernel<Px, STEPS>), grid, dim3(256), lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0,
+                           y1, rpc, K, pitch, ring, weights);
+        return hipGetLastError();
+    }
+}
+
 static bool is_gauss(const Op& o, int r) { return o.kind == OP_GAUSSIAN && o.radius == r; }
 
 // index of the fused pattern matching ops[0..n), -1 if none
@@ -921,6 +1063,23 @@ static hipError_t launch_ops_px(const Op* ops, int n, Image src, Image dst, cons
                 if (op.radius < 0 || op.radius > kMaxRadius || !op.dev_weights) return hipErrorInvalidValue;
                 const int rows = g.y1 - g.y0;
                 if (rows <= 0 || g.W <= 0) return hipSuccess;
+                // large kernels run on the matrix cores; small ones keep the 16x16 LDS-tile kernel
+                const bool mfma = tune.conv_path == 2 || (tune.conv_path != 1 && K >= 9);
+                if (mfma) {
+                    const int pitch = conv_mfma_pitch(op.radius), ring = conv_mfma_ring(op.radius);
+                    const size_t lds = ((size_t)K * kConvWRow + (size_t)ring * pitch) * sizeof(float);
+                    const int strips = (g.W + kConvStripW - 1) / kConvStripW;
+                    // ~4 workgroups per CU in flight; chunks are whole steps of 8 rows
+                    int chunks = (256 * 8 + strips - 1) / strips;
+                    int rpc = (rows + chunks - 1) / chunks;
+                    rpc = (rpc + kConvStepRows - 1) / kConvStepRows * kConvStepRows;
+                    if (rpc < 4 * kConvStepRows) rpc = 4 * kConvStepRows;
+                    if (tune.rows_per_chunk > 0) rpc = (tune.rows_per_chunk + kConvStepRows - 1) / kConvStepRows * kConvStepRows;
+                    dim3 grid((unsigned)strips, (unsigned)((rows + rpc - 1) / rpc));
+                    return launch_conv_mfma<Px>((16 + 2 * op.radius + 3) / 4, grid, lds, stream, static_cast<const char*>(src.base), src.pitch,
+                                                static_cast<char*>(dst.base), dst.pitch, g.W, g.row_lo, g.row_hi, g.y0, g.y1, rpc, K, pitch,
+                                                ring, op.dev_weights);
+                }
                 const int TW = 16 + 2 * op.radius;
                 size_t lds = (size_t)TW * TW * sizeof(f4) + (size_t)K * K * sizeof(float);
                 dim3 grid((unsigned)((g.W + 15) / 16), (unsigned)((rows + 15) / 16));
