@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--no-fusion", action="store_true", help="one launch per node, as the reference dispatches")
     ap.add_argument("--hipgraph", action="store_true")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N>1 plumbing check on a one-GPU box: all ranks on device 0, gloo barrier; numbers are meaningless")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,12 +128,20 @@ def main():
 
     import reforge_amd as rf
 
+    if args.rehearse:
+        # plumbing rehearsal on a one-GPU box: every rank on device 0, gloo for the barrier
+        # (RCCL refuses two ranks on one device).  The numbers it prints mean nothing.
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if args.rehearse else "cuda"
 
     def barrier_sync():
         if dist is not None:
@@ -143,9 +153,9 @@ def main():
 
     uid = None
     if world > 1 and args.halo == "exchange":
-        t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        t = torch.zeros(128, dtype=torch.uint8, device=red_dev)
         if rank == 0:
-            t = torch.frombuffer(bytearray(rf.Context.unique_id()), dtype=torch.uint8).cuda()
+            t = torch.frombuffer(bytearray(rf.Context.unique_id()), dtype=torch.uint8).to(red_dev)
         dist.broadcast(t, 0)
         uid = bytes(t.cpu().numpy().tobytes())
     ctx = rf.Context(local_rank, rank, world, uid) if world > 1 else rf.Context(local_rank)
@@ -174,7 +184,7 @@ def main():
     barrier_sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -281,3 +281,41 @@ def test_render_host_mirror(ctx, tmp_path):
     out2 = r.render_frame()
     assert out2.tobytes() == rgba.tobytes()             # sRGB identity through rgba32f
     r.graph.close()
+
+
+# ---- row strips on real kernels (one GPU standing in for N ranks) --------------------------
+@pytest.mark.parametrize("text,world,flags", [
+    (util.CHAIN5, 2, 0), (util.CHAIN5, 3, NF), (util.CHAIN3, 4, 0), (util.DIAMOND, 2, 0),
+])
+def test_row_strips_overfetch_on_one_gpu(text, world, flags):
+    """The N>1 path of rf_graph.cpp in over-fetch mode (RF_GRAPH_NO_HALO_XCHG: strips carry
+    their cumulative halo, no communication per frame): every rank's context lives on GPU 0
+    here, without a communicator; each generates its strip + ghost rows, runs the graph, and
+    the stacked strips must equal the whole frame computed by the oracle."""
+    W, H = 190, 97
+    for fmt in (util.F32, util.U8):
+        want = util.run_oracle(text, pixel.fill_synthetic(W, H, fmt, 0x5EED0004))
+        strips = []
+        for rank in range(world):
+            c = rf.Context(0, rank, world, None)
+            g = rf.Graph(c, rf.Config(text), W, H, fmt, flags=flags | rf.RF_GRAPH_NO_HALO_XCHG)
+            assert g.strip == rf.strip_rows(H, world, rank)
+            g.fill_synthetic(0x5EED0004)
+            g.execute(); g.wait()
+            strips.append(g.download_raw())
+            g.close()
+            c.close()
+        util.assert_same(np.concatenate(strips, axis=0), want, "world=%d flags=%d fmt=%d" % (world, flags, fmt))
+
+
+def test_exchange_mode_needs_a_communicator():
+    c = rf.Context(0, 0, 2, None)
+    with pytest.raises(rf.RfError) as e:
+        rf.Graph(c, rf.Config(util.CHAIN3), 64, 64, util.F32)         # exchange mode, no unique id
+    assert e.value.status == 6 and "communicator" in str(e.value)
+    # uploads in over-fetch mode would need the neighbours' rows: refused without a communicator
+    g = rf.Graph(c, rf.Config(util.CHAIN3), 64, 64, util.F32, flags=rf.RF_GRAPH_NO_HALO_XCHG)
+    with pytest.raises(rf.RfError):
+        g.upload_raw(np.zeros((32, 64, 4), np.float32))
+    g.close()
+    c.close()
