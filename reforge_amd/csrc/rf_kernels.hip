@@ -46,7 +46,18 @@ RF_DEV f4 fma4(float w, f4 v, f4 a)
 // ---------------------------------------------------------------------------------
 // Texel formats: what imageLoad/imageStore do (shaders/passthrough.comp:9,:12)
 // ---------------------------------------------------------------------------------
-RF_DEV float unorm8_to_f32(unsigned c) { return __fdiv_rn((float)c, 255.0f); }
+// c / 255 correctly rounded, without the ~12-instruction IEEE division sequence: one Newton
+// step on q = c * fl(1/255) gives the correctly rounded quotient for all 256 codes
+// (tests/test_gpu_parity.py::test_unorm8_decode_all_codes checks every code against the
+// oracle's true division).
+RF_DEV float unorm8_to_f32(unsigned c)
+{
+    const float r = 1.0f / 255.0f;
+    const float x = (float)c;
+    const float q = x * r;
+    const float e = fmaf(-q, 255.0f, x);
+    return fmaf(e, r, q);
+}
 RF_DEV unsigned f32_to_unorm8(float v)
 {
     // clamp (NaN -> 0), x255, round to nearest even
