@@ -8,8 +8,8 @@
 // (render.rs:115), single-shader mode (config.rs:77-90), headless = one frame then
 // encode (main.rs:220-224), the status line (main.rs:157).
 // Out of scope: the winit/swapchain window (no display on an MI355X box) and the
-// ffmpeg codecs -- images are read as binary PPM (P6) or raw RGBA8 and written as
-// PNG (stored deflate), PPM or raw RGBA8, chosen by file extension.
+// ffmpeg codecs -- images are read as PNG (host/png_io.h), binary PPM (P6) or raw RGBA8 and
+// written as PNG (stored deflate), PPM or raw RGBA8, chosen by file extension.
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "png_io.h"
 #include "rfhip.h"
 
 namespace {
@@ -32,6 +33,7 @@ struct Args {   // main.rs:43-71
     int width = -1, height = -1;
     std::string shader_format = "rgba32f";
     int num_frames = 2;
+    bool decode_only = false;   // -i file -o file without touching the GPU: decoder check
     // additions for headless benchmarking
     long synthetic_seed = -1;
     int frames = 1;
@@ -44,7 +46,7 @@ void usage()
         "Usage: reforge [OPTIONS] [shader]\n\n"
         "Arguments:\n  [shader]  A single filter type to execute instead of a config\n\n"
         "Options:\n"
-        "  -i, --input-file <INPUT_FILE>      File to read from (.ppm P6 or .rgba raw)\n"
+        "  -i, --input-file <INPUT_FILE>      File to read from (.png, .ppm P6 or .rgba raw)\n"
         "  -o, --output-file <OUTPUT_FILE>    File to write to (.png, .ppm or .rgba)\n"
         "      --width <WIDTH>\n"
         "      --height <HEIGHT>\n"
@@ -55,6 +57,7 @@ void usage()
         "      --synthetic <SEED>             Generate the input on the GPU instead of reading a file\n"
         "      --frames <N>                   Execute the graph N times and report the mean frame time\n"
         "      --no-fusion                    One kernel launch per node, as the reference dispatches\n"
+        "      --decode-only                  Decode -i and re-encode to -o without touching the GPU\n"
         "      --hipgraph                     Replay the frame as one hipGraph\n"
         "  -h, --help                         Print help\n",
         stderr);
@@ -81,6 +84,7 @@ bool parse_args(int argc, char** argv, Args& a)
         else if (s == "--num-frames") { if (!val(v)) return false; a.num_frames = std::atoi(v.c_str()); }
         else if (s == "--synthetic") { if (!val(v)) return false; a.synthetic_seed = std::strtol(v.c_str(), nullptr, 0); }
         else if (s == "--frames") { if (!val(v)) return false; a.frames = std::atoi(v.c_str()); }
+        else if (s == "--decode-only") a.decode_only = true;
         else if (s == "--no-fusion") a.no_fusion = true;
         else if (s == "--hipgraph") a.hipgraph = true;
         else if (!s.empty() && s[0] == '-') { warnln("error: unexpected argument '" + s + "'"); return false; }
@@ -140,70 +144,6 @@ bool read_ppm(const std::string& path, int& w, int& h, std::vector<uint8_t>& rgb
     return true;
 }
 
-uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n)
-{
-    static uint32_t table[256];
-    static bool init = false;
-    if (!init) {
-        for (uint32_t i = 0; i < 256; ++i) {
-            uint32_t c = i;
-            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-            table[i] = c;
-        }
-        init = true;
-    }
-    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
-    return crc;
-}
-
-void put_be32(std::vector<uint8_t>& v, uint32_t x)
-{
-    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
-}
-
-void png_chunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_t>& data)
-{
-    put_be32(out, (uint32_t)data.size());
-    size_t start = out.size();
-    out.insert(out.end(), type, type + 4);
-    out.insert(out.end(), data.begin(), data.end());
-    put_be32(out, crc32_update(0xFFFFFFFFu, out.data() + start, out.size() - start) ^ 0xFFFFFFFFu);
-}
-
-// RGBA8 PNG with stored (uncompressed) deflate blocks: valid for every decoder
-bool write_png(const std::string& path, int w, int h, const uint8_t* rgba)
-{
-    std::vector<uint8_t> raw;
-    raw.reserve((size_t)h * ((size_t)w * 4 + 1));
-    for (int y = 0; y < h; ++y) {
-        raw.push_back(0);   // filter: none
-        raw.insert(raw.end(), rgba + (size_t)y * w * 4, rgba + (size_t)(y + 1) * w * 4);
-    }
-    std::vector<uint8_t> z = {0x78, 0x01};
-    uint32_t a = 1, b = 0;
-    for (uint8_t c : raw) { a = (a + c) % 65521; b = (b + a) % 65521; }
-    size_t pos = 0;
-    do {
-        size_t n = std::min<size_t>(65535, raw.size() - pos);
-        z.push_back(pos + n == raw.size() ? 1 : 0);
-        z.push_back((uint8_t)(n & 0xFF)); z.push_back((uint8_t)(n >> 8));
-        z.push_back((uint8_t)(~n & 0xFF)); z.push_back((uint8_t)((~n >> 8) & 0xFF));
-        z.insert(z.end(), raw.begin() + (long)pos, raw.begin() + (long)(pos + n));
-        pos += n;
-    } while (pos < raw.size());
-    put_be32(z, (b << 16) | a);
-    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-    std::vector<uint8_t> ihdr;
-    put_be32(ihdr, (uint32_t)w); put_be32(ihdr, (uint32_t)h);
-    ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
-    png_chunk(out, "IHDR", ihdr);
-    png_chunk(out, "IDAT", z);
-    png_chunk(out, "IEND", {});
-    std::ofstream f(path, std::ios::binary);
-    f.write((const char*)out.data(), (std::streamsize)out.size());
-    return (bool)f;
-}
-
 bool write_image(const std::string& path, int w, int h, const uint8_t* rgba)
 {
     if (ends_with(path, ".ppm")) {
@@ -217,7 +157,7 @@ bool write_image(const std::string& path, int w, int h, const uint8_t* rgba)
         f.write((const char*)rgba, (std::streamsize)((size_t)w * h * 4));
         return (bool)f;
     }
-    return write_png(path, w, h, rgba);   // the reference always writes PNG (imagefileio.rs:221)
+    return pngio::write_png(path, w, h, rgba);   // the reference always writes PNG (imagefileio.rs:221)
 }
 
 double now_ms()
@@ -269,8 +209,14 @@ int main(int argc, char** argv)
             staging.resize((size_t)in_w * in_h * 4);
             f.read((char*)staging.data(), (std::streamsize)staging.size());
             if (!f) { warnln("Error reading file '" + args.input_file + "'"); return 1; }
+        } else if (ends_with(args.input_file, ".png")) {
+            std::string perr;
+            if (!pngio::read_png(args.input_file, in_w, in_h, staging, perr)) {
+                warnln("Error reading file '" + args.input_file + "': " + perr);
+                return 1;
+            }
         } else if (!read_ppm(args.input_file, in_w, in_h, staging)) {
-            warnln("Error reading file '" + args.input_file + "': only binary PPM (P6, maxval 255) and raw .rgba are decoded");
+            warnln("Error reading file '" + args.input_file + "': only PNG (8-bit, non-interlaced), binary PPM (P6) and raw .rgba are decoded");
             return 1;
         }
     }
@@ -281,6 +227,10 @@ int main(int argc, char** argv)
         return 1;
     }
     if (has_file) std::printf("File Decode and resize: %.2fms\n", now_ms() - t0);
+    if (args.decode_only) {   // no GPU involved: decode -i, encode -o
+        if (!has_file) { warnln("--decode-only needs -i"); return 1; }
+        return write_image(args.output_file, width, height, staging.data()) ? 0 : 1;
+    }
 
     // create_config, render.rs:100-119
     rf_config* cfg = nullptr;

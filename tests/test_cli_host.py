@@ -1,0 +1,118 @@
+"""The C++ CLI host (reforge_amd/reforge, counterpart of src/main.rs): argument handling and
+the dependency-free PNG reader/writer on CPU; one end-to-end frame on the GPU."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import graph as og
+from oracle import pixel
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "reforge_amd", "reforge")
+
+
+def write_png(path, img, filt):
+    """Reference PNG encoder (zlib level 9, every scanline filter) for the decoder test."""
+    h, w, c = img.shape
+    raw = b""
+    prev = np.zeros((w * c,), np.int32)
+    for y in range(h):
+        cur = img[y].reshape(-1).astype(np.int32)
+        ft = filt(y)
+        a = np.concatenate([np.zeros(c, np.int32), cur[:-c]])
+        cc = np.concatenate([np.zeros(c, np.int32), prev[:-c]])
+        if ft == 0:
+            pred = 0
+        elif ft == 1:
+            pred = a
+        elif ft == 2:
+            pred = prev
+        elif ft == 3:
+            pred = (a + prev) >> 1
+        else:
+            p = a + prev - cc
+            pa, pb, pc = abs(p - a), abs(p - prev), abs(p - cc)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, cc))
+        raw += bytes([ft]) + ((cur - pred) & 255).astype(np.uint8).tobytes()
+        prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    ct = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    with open(path, "wb") as fh:
+        fh.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ct, 0, 0, 0)) +
+                 chunk(b"IDAT", zlib.compress(raw, 9)) + chunk(b"IEND", b""))
+
+
+def run_cli(*args):
+    return subprocess.run([CLI] + list(args), capture_output=True, text=True)
+
+
+@pytest.mark.parametrize("channels", [1, 2, 3, 4])
+def test_png_decoder_and_writer(tmp_path, channels):
+    rng = np.random.RandomState(channels)
+    img = rng.randint(0, 256, (37, 53, channels)).astype(np.uint8)
+    img[5:20] = 77                                       # long matches: dynamic Huffman + back-references
+    src, raw, again = str(tmp_path / "in.png"), str(tmp_path / "out.rgba"), str(tmp_path / "again.png")
+    write_png(src, img, lambda y: y % 5)
+    assert run_cli("-i", src, "-o", raw, "--decode-only").returncode == 0
+    got = np.fromfile(raw, np.uint8).reshape(37, 53, 4)
+    want = np.zeros((37, 53, 4), np.uint8)
+    if channels == 1:
+        want[..., :3], want[..., 3] = img, 255
+    elif channels == 2:
+        want[..., :3], want[..., 3] = img[..., :1], img[..., 1]
+    elif channels == 3:
+        want[..., :3], want[..., 3] = img, 255
+    else:
+        want = img
+    assert (got == want).all()
+    # our own writer (stored deflate) is readable by zlib-based decoders and by ourselves
+    assert run_cli("-i", src, "-o", again, "--decode-only").returncode == 0
+    assert run_cli("-i", again, "-o", raw, "--decode-only").returncode == 0
+    assert (np.fromfile(raw, np.uint8).reshape(37, 53, 4) == want).all()
+    data = open(again, "rb").read()
+    idat = data[data.index(b"IDAT") + 4:data.index(b"IEND") - 8]
+    assert len(zlib.decompress(idat)) == 37 * (53 * 4 + 1)
+
+
+def test_cli_argument_rules(tmp_path):
+    """main.rs:76-83: headless needs -o; a config and a positional shader exclude each other."""
+    r = run_cli()
+    assert r.returncode != 0 and "pass -o" in r.stderr
+    cfg = tmp_path / "p.cfg"
+    cfg.write_text("input -> passthrough -> output")
+    r = run_cli("--config", str(cfg), "sharpen", "-o", str(tmp_path / "o.png"))
+    assert r.returncode == 1 and "Cannot specify both a config and shader file" in r.stderr
+    r = run_cli("-o", str(tmp_path / "o.png"), "--shader-format", "rgba16")
+    assert r.returncode == 2
+    # the default graph reads 'input' (render.rs:115) but no input was given (config.rs:201)
+    r = run_cli("-o", str(tmp_path / "o.png"))
+    assert r.returncode == 1 and "no input image was specified" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end(tmp_path):
+    """reforge -i in.png --config chain.cfg -o out.png == upload_srgb8 -> graph -> download_srgb8 of the oracle."""
+    rgba = pixel.fill_synthetic(160, 90, util.U8, 77)
+    rgba[..., 3] = 255
+    src, dst, cfg = str(tmp_path / "in.png"), str(tmp_path / "out.rgba"), tmp_path / "chain.cfg"
+    write_png(src, rgba, lambda y: 4)
+    cfg.write_text(util.CHAIN3)
+    for fmt_name, fmt in (("rgba32f", util.F32), ("rgba8", util.U8)):
+        r = run_cli("-i", src, "--config", str(cfg), "-o", dst, "--shader-format", fmt_name)
+        assert r.returncode == 0, r.stderr
+        assert "GPU: {blur+grade+sharp: " in r.stderr          # the status line of main.rs:157
+        ref = og.GraphOracle(util.CHAIN3, 160, 90, fmt)
+        ref.upload_srgb8(rgba)
+        ref.execute()
+        assert np.fromfile(dst, np.uint8).reshape(90, 160, 4).tobytes() == ref.download_srgb8().tobytes()
+    # single-shader mode (config.rs:77-90)
+    r = run_cli("-i", src, "sharpen.comp", "-o", dst, "--no-fusion")
+    assert r.returncode == 0 and "GPU: {sharpen: " in r.stderr
