@@ -38,9 +38,15 @@ typedef float4 f4;
 #define RF_DEV __device__ __forceinline__
 
 RF_DEV f4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// four fmaf as two v_pk_fma_f32 (each lane-pair fma is still one single-rounding fmaf): a VALU
+// instruction costs the same issue slot packed or not, and the kernels are issue-sensitive
+typedef float v2f __attribute__((ext_vector_type(2)));
 RF_DEV f4 fma4(float w, f4 v, f4 a)
 {
-    return make_float4(fmaf(w, v.x, a.x), fmaf(w, v.y, a.y), fmaf(w, v.z, a.z), fmaf(w, v.w, a.w));
+    const v2f ww = {w, w};
+    const v2f lo = __builtin_elementwise_fma(ww, v2f{v.x, v.y}, v2f{a.x, a.y});
+    const v2f hi = __builtin_elementwise_fma(ww, v2f{v.z, v.w}, v2f{a.z, a.w});
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
 
 // ---------------------------------------------------------------------------------
@@ -86,7 +92,18 @@ struct PxF32 {
         asm volatile("v_mov_b32 %0, %1" : "=v"(o.w) : "v"(r.w));
         return o;
     }
-    RF_DEV static void store(char* row, unsigned xoff, f4 v) { *reinterpret_cast<f4*>(row + xoff) = v; }
+    RF_DEV static void store(char* row, unsigned xoff, f4 v)
+    {
+#if defined(RF_NT_STORE) && RF_NT_STORE
+        float* p = reinterpret_cast<float*>(row + xoff);
+        __builtin_nontemporal_store(v.x, p);
+        __builtin_nontemporal_store(v.y, p + 1);
+        __builtin_nontemporal_store(v.z, p + 2);
+        __builtin_nontemporal_store(v.w, p + 3);
+#else
+        *reinterpret_cast<f4*>(row + xoff) = v;
+#endif
+    }
     RF_DEV static f4 requant(f4 v) { return v; }
 };
 
@@ -504,7 +521,10 @@ template <class... S> struct StreamArgs {
     ParamPack<S...> params;
 };
 
-constexpr int kWavesPerBlock = 4;
+#ifndef RF_WAVES_PER_BLOCK
+#define RF_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = RF_WAVES_PER_BLOCK;
 
 template <class Px, int PF, class... S>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void stream_kernel(const StreamArgs<S...> A)
