@@ -405,6 +405,7 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
     if (const char* e = std::getenv("RF_ROWS_PER_CHUNK")) g->tune.rows_per_chunk = std::atoi(e);
     if (const char* e = std::getenv("RF_PREFETCH_ROWS")) g->tune.prefetch_rows = std::atoi(e);
     if (const char* e = std::getenv("RF_CONV_PATH")) g->tune.conv_path = std::atoi(e);
+    if (const char* e = std::getenv("RF_NO_ALTERNATE")) g->tune.no_alternate = std::atoi(e);
 
     // per-frame images, streams, events (PipelineGraphFrame::new, Frame::new)
     const size_t pitch = align_up((size_t)opt.width * bytes_per_pixel(opt.format), 256);

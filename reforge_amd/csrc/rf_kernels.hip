@@ -170,7 +170,7 @@ template <int N> RF_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :
 
 struct Sink {
     char* dst;          // address of local row 0
-    size_t pitch;
+    ptrdiff_t pitch;    // negative when the wave walks bottom-up
     unsigned xoff;      // lane's byte offset in a row
     bool lane_ok;       // lane owns an output texel
     int row;            // next output row
@@ -266,7 +266,7 @@ template <int R> struct StHTap {
         for (int i = -R; i <= R; ++i) acc = fma4(p.w[i < 0 ? -i : i], f.t[i + R], acc);
         return acc;
     }
-    template <class Px> RF_DEV static void advance(const Params& p, NoState&, const Lane& L, f4* lds, f4 v, bool, bool, bool, f4& out)
+    template <class Px, bool REV> RF_DEV static void advance(const Params& p, NoState&, const Lane& L, f4* lds, f4 v, bool, bool, bool, f4& out)
     {
         if constexpr (R > 0) {
             lds[L.lane] = v;
@@ -288,7 +288,7 @@ template <int R> struct StVTap {
     struct Params { float w[R + 1]; };
     template <class Px> struct State { f4 win[2 * R + 1]; };
     template <class Px> using Feed = OwnFeed<Px>;
-    template <class Px> RF_DEV static void advance(const Params& p, State<Px>& s, const Lane&, f4*, f4 v, bool real, bool first, bool emit, f4& out)
+    template <class Px, bool REV> RF_DEV static void advance(const Params& p, State<Px>& s, const Lane&, f4*, f4 v, bool real, bool first, bool emit, f4& out)
     {
         const int pushes = first ? 2 * R + 1 : 1;
         for (int q = 0; q < pushes; ++q) {
@@ -299,7 +299,9 @@ template <int R> struct StVTap {
         if (emit) {
             f4 acc = f4_zero();
 #pragma unroll
-            for (int j = -R; j <= R; ++j) acc = fma4(p.w[j < 0 ? -j : j], s.win[j + R], acc);
+            // taps are accumulated in ascending FRAME row order; walking bottom-up the window
+            // holds the rows the other way round
+            for (int j = -R; j <= R; ++j) acc = fma4(p.w[j < 0 ? -j : j], s.win[REV ? R - j : j + R], acc);
             out = acc;
         }
     }
@@ -312,7 +314,7 @@ struct StGrade {
     template <class Px> using State = NoState;
     template <class Px> using Feed = OwnFeed<Px>;
     RF_DEV static float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
-    template <class Px> RF_DEV static void advance(const Params& p, NoState&, const Lane&, f4*, f4 c, bool, bool, bool, f4& out)
+    template <class Px, bool REV> RF_DEV static void advance(const Params& p, NoState&, const Lane&, f4*, f4 c, bool, bool, bool, f4& out)
     {
         float tr = fmaf(c.x, p.slope, p.offset);
         float tg = fmaf(c.y, p.slope, p.offset);
@@ -339,7 +341,7 @@ struct StCross3 {
         w = lds[L.nbr(-1)];
         e = lds[L.nbr(+1)];
     }
-    template <class Px> RF_DEV static void advance(const Params& p, State<Px>& s, const Lane& L, f4* lds, f4 v, bool real, bool first, bool emit, f4& out)
+    template <class Px, bool REV> RF_DEV static void advance(const Params& p, State<Px>& s, const Lane& L, f4* lds, f4 v, bool real, bool first, bool emit, f4& out)
     {
         if (first) {                     // window = [v, v, (next row)]
             s.n = v;
@@ -350,11 +352,12 @@ struct StCross3 {
         const f4 below = real ? v : s.c;
         if (emit) {
             f4 acc = f4_zero();
-            acc = fma4(p.ws, s.n, acc);
+            // frame order N, W, C, E, S: walking bottom-up the older row is the one BELOW
+            acc = fma4(p.ws, REV ? below : s.n, acc);
             acc = fma4(p.ws, s.cw, acc);
             acc = fma4(p.wc, s.c, acc);
             acc = fma4(p.ws, s.ce, acc);
-            acc = fma4(p.ws, below, acc);
+            acc = fma4(p.ws, REV ? s.n : below, acc);
             out = acc;
         }
         s.n = s.c;
@@ -372,7 +375,7 @@ struct StNodeEnd {
     struct Params {};
     template <class Px> using State = NoState;
     template <class Px> using Feed = OwnFeed<Px>;
-    template <class Px> RF_DEV static void advance(const Params&, NoState&, const Lane&, f4*, f4 v, bool, bool, bool, f4& out)
+    template <class Px, bool REV> RF_DEV static void advance(const Params&, NoState&, const Lane&, f4*, f4 v, bool, bool, bool, f4& out)
     {
         out = Px::requant(v);
     }
@@ -392,26 +395,30 @@ template <class... S> struct SumRH { static constexpr int value = 0; };
 template <class S, class... Rest> struct SumRH<S, Rest...> { static constexpr int value = S::RH + SumRH<Rest...>::value; };
 template <class... S> struct SumLDS { static constexpr int value = 0; };
 template <class S, class... Rest> struct SumLDS<S, Rest...> { static constexpr int value = S::LDS_ROWS + SumLDS<Rest...>::value; };
+template <class... S> struct SumRV { static constexpr int value = 0; };
+template <class S, class... Rest> struct SumRV<S, Rest...> { static constexpr int value = S::RV + SumRV<Rest...>::value; };
 template <class S, class...> struct FirstOf { typedef S type; };
 
-template <class Px, int LdsIdx, class... S> struct Chain;
+// REV: the wave walks its chunk bottom-up (rows are addressed with a negated pitch, so the
+// schedule below is unchanged); stages whose tap order depends on the row direction read it.
+template <class Px, bool REV, int LdsIdx, class... S> struct Chain;
 
 // end of the chain: the store
-template <class Px, int LdsIdx> struct Chain<Px, LdsIdx> {
+template <class Px, bool REV, int LdsIdx> struct Chain<Px, REV, LdsIdx> {
     RF_DEV void plan_backward(int oa, int ob, int, int, int& in_a, int& in_b) { in_a = oa; in_b = ob; }
     RF_DEV int plan_forward(int tprev) { return tprev; }
     template <bool STEADY> RF_DEV void step(bool has, f4 v, int it, const Lane&, Sink& k, const ParamPack<>&)
     {
         if (STEADY || has) {
             // exactly ONE vector-memory instruction per emitted row: Source::wait_row counts on it
-            if (k.lane_ok) Px::store(k.dst + (ptrdiff_t)k.row * (ptrdiff_t)k.pitch, k.xoff, v);
+            if (k.lane_ok) Px::store(k.dst + (ptrdiff_t)k.row * k.pitch, k.xoff, v);
             k.row += 1;
             if (!STEADY && k.first_store < 0) k.first_store = it;
         }
     }
 };
 
-template <class Px, int LdsIdx, class S, class... Rest> struct Chain<Px, LdsIdx, S, Rest...> {
+template <class Px, bool REV, int LdsIdx, class S, class... Rest> struct Chain<Px, REV, LdsIdx, S, Rest...> {
     typename S::template State<Px> st;
     // wave-uniform schedule
     int a;        // first input row
@@ -419,7 +426,7 @@ template <class Px, int LdsIdx, class S, class... Rest> struct Chain<Px, LdsIdx,
     int flush;    // replications of the last input row (frame bottom edge)
     int tprev;    // iteration of the upstream stage's last emission
     int cnt;      // input rows consumed
-    Chain<Px, LdsIdx + S::LDS_ROWS, Rest...> next;
+    Chain<Px, REV, LdsIdx + S::LDS_ROWS, Rest...> next;
 
     // given the rows the LAST stage must emit, derive what each stage must emit/consume
     RF_DEV void plan_backward(int oa_last, int ob_last, int lo, int hi, int& in_a, int& in_b)
@@ -446,12 +453,12 @@ template <class Px, int LdsIdx, class S, class... Rest> struct Chain<Px, LdsIdx,
         bool has = false;
         f4 out = f4_zero();
         if constexpr (STEADY) {
-            S::template advance<Px>(P.p, st, L, L.lds + LdsIdx * 64, v, true, false, true, out);
+            S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, v, true, false, true, out);
             cnt += 1;
             has = true;
         } else if constexpr (S::RV == 0) {
             if (has_prev) {              // row-local stage: one row in, one row out, never flushed
-                S::template advance<Px>(P.p, st, L, L.lds + LdsIdx * 64, v, true, cnt == 0, true, out);
+                S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, v, true, cnt == 0, true, out);
                 cnt += 1;
                 has = true;
             }
@@ -459,7 +466,7 @@ template <class Px, int LdsIdx, class S, class... Rest> struct Chain<Px, LdsIdx,
             const bool flushing = !has_prev && it > tprev && it <= tprev + flush;
             if (has_prev || flushing) {
                 has = (a + cnt - S::RV) >= oa;
-                S::template advance<Px>(P.p, st, L, L.lds + LdsIdx * 64, v, has_prev, cnt == 0, has, out);
+                S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, v, has_prev, cnt == 0, has, out);
                 cnt += 1;
             }
         }
@@ -474,7 +481,7 @@ template <class Px, int LdsIdx, class S, class... Rest> struct Chain<Px, LdsIdx,
         f4 out = f4_zero();
         if constexpr (STEADY) {
             if constexpr (std::is_same<Feed, OwnFeed<Px>>::value)
-                S::template advance<Px>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), true, false, true, out);
+                S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), true, false, true, out);
             else
                 out = S::from_taps(P.p, feed);
             cnt += 1;
@@ -486,7 +493,7 @@ template <class Px, int LdsIdx, class S, class... Rest> struct Chain<Px, LdsIdx,
             if constexpr (S::RV == 0) {
                 if (has0) {
                     if constexpr (std::is_same<Feed, OwnFeed<Px>>::value)
-                        S::template advance<Px>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), true, cnt == 0, true, out);
+                        S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), true, cnt == 0, true, out);
                     else
                         out = S::from_taps(P.p, feed);
                     cnt += 1;
@@ -496,7 +503,7 @@ template <class Px, int LdsIdx, class S, class... Rest> struct Chain<Px, LdsIdx,
                 const bool flushing = !has0 && it > tprev && it <= tprev + flush;
                 if (has0 || flushing) {
                     has = (a + cnt - S::RV) >= oa;
-                    S::template advance<Px>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), has0, cnt == 0, has, out);
+                    S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), has0, cnt == 0, has, out);
                     cnt += 1;
                 }
             }
@@ -518,6 +525,8 @@ template <class... S> struct StreamArgs {
     char* dst;
     size_t dst_pitch;
     int W, row_lo, row_hi, y0, y1, rows_per_chunk, n_strips;
+    int n_work;   // workgroups with work = strip groups x chunks (the grid is padded to a multiple of 8)
+    int alternate;   // odd chunks walk bottom-up (halo rows shared through L2)
     ParamPack<S...> params;
 };
 
@@ -526,52 +535,40 @@ template <class... S> struct StreamArgs {
 #endif
 constexpr int kWavesPerBlock = RF_WAVES_PER_BLOCK;
 
-template <class Px, int PF, class... S>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void stream_kernel(const StreamArgs<S...> A)
+// One wave's walk over rows [y0, y1) of its strip.  REV = bottom-up: rows are addressed with
+// negated pitches and mirrored bounds, so the schedule code sees an ordinary top-down walk.
+template <class Px, int PF, bool REV, class... S>
+RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane& L, int wave, char* ring_wave, unsigned ring_lds, int y0, int y1)
 {
     constexpr int RH = SumRH<S...>::value;
-    constexpr int VALID = 64 - 2 * RH;
-    constexpr int LDSR = SumLDS<S...>::value;
     typedef Source<Px, PF> Src;
     typedef typename FirstOf<S...>::type::template Feed<Px> Feed;
-    __shared__ f4 smem[kWavesPerBlock][(LDSR > 0 ? LDSR : 1) * 64];
-    __shared__ __attribute__((aligned(16))) char ring[kWavesPerBlock][Src::SLOTS * Src::SLOT_BYTES];
+    (void)wave;
 
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int strip = (int)blockIdx.x * kWavesPerBlock + wave;
-    if (strip >= A.n_strips) return;                 // wave-uniform; no barriers below
-    const int y0 = A.y0 + (int)blockIdx.y * A.rows_per_chunk;
-    const int y1 = min(y0 + A.rows_per_chunk, A.y1);
-    if (y0 >= y1) return;
-
-    Lane L;
-    L.lane = (int)(threadIdx.x & 63);
-    L.x0 = strip * VALID - RH;
-    L.x = L.x0 + L.lane;
-    L.W = A.W;
-    L.lds = smem[wave];
+    // the walk's own row coordinate v: v = y top-down, v = -y bottom-up
+    const int v0 = REV ? -(y1 - 1) : y0, v1 = REV ? -y0 + 1 : y1;
+    const int lo = REV ? -A.row_hi : A.row_lo, hi = REV ? -A.row_lo : A.row_hi;
 
     Sink k;
     k.dst = A.dst;
-    k.pitch = A.dst_pitch;
+    k.pitch = REV ? -(ptrdiff_t)A.dst_pitch : (ptrdiff_t)A.dst_pitch;
     k.xoff = (unsigned)min(max(L.x, 0), A.W - 1) * (unsigned)Px::BPP;
     k.lane_ok = (L.lane >= RH) && (L.lane < 64 - RH) && (L.x < A.W);
-    k.row = y0;
+    k.row = v0;
     k.first_store = -1;
 
-    Chain<Px, 0, S...> chain;
+    Chain<Px, REV, 0, S...> chain;
     Src src;
     int b0;
-    chain.plan_backward(y0, y1 - 1, A.row_lo, A.row_hi, src.a0, b0);
+    chain.plan_backward(v0, v1 - 1, lo, hi, src.a0, b0);
     src.n0 = b0 - src.a0 + 1;                        // source rows
     const int total = chain.plan_forward(src.n0 - 1) + 1;
 
     // source: rows a0..b0, column clamp(x)
     src.src = A.src + k.xoff;
-    src.pitch = (ptrdiff_t)A.src_pitch;
-    src.ring = ring[wave];
-    src.lds_base = __builtin_amdgcn_readfirstlane(
-        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&ring[0][0]) + (unsigned)wave * (unsigned)(Src::SLOTS * Src::SLOT_BYTES));
+    src.pitch = REV ? -(ptrdiff_t)A.src_pitch : (ptrdiff_t)A.src_pitch;
+    src.ring = ring_wave;
+    src.lds_base = ring_lds;
     src.prologue();
     Feed feed;
     src.wait_row(0, k);
@@ -589,6 +586,52 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void stream_kernel(const Strea
     const int steady_end = src.n0 - PF;
     for (; it < steady_end; ++it) chain.template step_first<true>(true, feed, src, it, L, k, A.params);
     for (; it < total; ++it) chain.template step_first<false>(it < src.n0, feed, src, it, L, k, A.params);
+}
+
+template <class Px, int PF, class... S>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void stream_kernel(const StreamArgs<S...> A)
+{
+    constexpr int RH = SumRH<S...>::value;
+    constexpr int VALID = 64 - 2 * RH;
+    constexpr int LDSR = SumLDS<S...>::value;
+    typedef Source<Px, PF> Src;
+    __shared__ f4 smem[kWavesPerBlock][(LDSR > 0 ? LDSR : 1) * 64];
+    __shared__ __attribute__((aligned(16))) char ring[kWavesPerBlock][Src::SLOTS * Src::SLOT_BYTES];
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // XCD-aware block order (guide T1): blocks are dealt round-robin over the 8 XCDs, so block
+    // b and b+8 share an L2.  Give each XCD a CONTIGUOUS range of work items (strip groups
+    // fastest, then chunks): workgroups that share halo columns or halo rows then share an L2.
+    // Speed only -- any placement gives the same result.
+    const int gx = (A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int q = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (q >= A.n_work) return;
+    const int strip = (q % gx) * kWavesPerBlock + wave;
+    if (strip >= A.n_strips) return;                 // wave-uniform; no barriers below
+    const int chunk = q / gx;
+    const int y0 = A.y0 + chunk * A.rows_per_chunk;
+    const int y1 = min(y0 + A.rows_per_chunk, A.y1);
+    if (y0 >= y1) return;
+
+    Lane L;
+    L.lane = (int)(threadIdx.x & 63);
+    L.x0 = strip * VALID - RH;
+    L.x = L.x0 + L.lane;
+    L.W = A.W;
+    L.lds = smem[wave];
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&ring[0][0]) + (unsigned)wave * (unsigned)(Src::SLOTS * Src::SLOT_BYTES));
+
+    // Odd chunks walk bottom-up: a chunk and its neighbour then read the halo rows they
+    // share at the same moment (both at their start, or both at their end), so the second
+    // read is served by the XCD's L2 instead of the fabric.  Stencil-free pipelines have no
+    // halo and always walk top-down.
+    constexpr bool kHasHalo = SumRV<S...>::value > 0;
+    if (kHasHalo && A.alternate && (chunk & 1))
+        stream_wave<Px, PF, true, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
+    else
+        stream_wave<Px, PF, false, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
 }
 
 // ---------------------------------------------------------------------------------
@@ -922,8 +965,9 @@ static hipError_t launch_stream(Image src, Image dst, const Geom& g, const Strea
     if (rows <= 0 || g.W <= 0) return hipSuccess;
     A.rows_per_chunk = choose_rows_per_chunk(rows, A.n_strips, halo_rows, tune);
     A.params = params;
-    dim3 grid((unsigned)((A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock),
-              (unsigned)((rows + A.rows_per_chunk - 1) / A.rows_per_chunk));
+    A.n_work = ((A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock) * ((rows + A.rows_per_chunk - 1) / A.rows_per_chunk);
+    A.alternate = tune.no_alternate ? 0 : 1;
+    dim3 grid((unsigned)((A.n_work + 7) / 8 * 8));   // 1-D, a multiple of the 8 XCDs (see the kernel's block order)
     // prefetch depth: the template argument is the default; RF_PREFETCH_ROWS=8 selects the
     // deeper ring where it is instantiated (radius <= 4)
     if constexpr (PF == 4) {
