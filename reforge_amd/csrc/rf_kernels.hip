@@ -94,15 +94,10 @@ struct PxF32 {
     }
     RF_DEV static void store(char* row, unsigned xoff, f4 v)
     {
-#if defined(RF_NT_STORE) && RF_NT_STORE
-        float* p = reinterpret_cast<float*>(row + xoff);
-        __builtin_nontemporal_store(v.x, p);
-        __builtin_nontemporal_store(v.y, p + 1);
-        __builtin_nontemporal_store(v.z, p + 2);
-        __builtin_nontemporal_store(v.w, p + 3);
-#else
+        // MUST stay one global_store_dwordx4: the stream kernel's counted vmcnt waits rely on
+        // one vector-memory instruction per stored row (a non-temporal variant was measured:
+        // no gain, and split into four stores it would break the count)
         *reinterpret_cast<f4*>(row + xoff) = v;
-#endif
     }
     RF_DEV static f4 requant(f4 v) { return v; }
 };
@@ -791,6 +786,129 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const char* src, size_
 }
 
 // ---------------------------------------------------------------------------------
+// conv2d, register-blocked VALU formulation.  On gfx950 an f32 MFMA runs at the f32 VECTOR
+// rate (MI355X guide: 64 FLOP/clk/SIMD either way), so the banded MFMA contraction above
+// pays for its zero band entries (35 % at 31x31) with nothing in return; this kernel does
+// only the real taps.  Each lane accumulates 4 consecutive output columns of one row
+// (4 f4 accumulators) and slides a register window along the row: one ds_read_b128 per
+// 8 v_pk_fma_f32.  Tap order is exactly the oracle's (dy outer, dx inner).
+//
+// Workgroup = 8 waves = 128 output columns x 16 rows per step (lane = 32 column groups x
+// 2 rows; two waves per SIMD, which the VALU needs to issue every other cycle), walking down a
+// chunk with the 16+2r input rows in an LDS ring, like the MFMA kernel.  LDS row layout:
+// column c lives at sub-row (c & 3), position (c >> 2), so the 32 lanes of a row read 32
+// CONSECUTIVE texels for any tap (lane lx reads column 4*lx + m: the sub-row m & 3 is the same
+// in every lane); the row pitch is a multiple of 256 B.
+// ---------------------------------------------------------------------------------
+constexpr int kCvStripW = 128;      // output columns per workgroup
+constexpr int kCvStepRows = 16;     // output rows per step
+constexpr int kCvT = 4;             // output columns per lane
+constexpr int kCvSub = 40;          // texels per sub-row: (128 + 30 + 2) / 4; 4 x 40 x 16 B = 2560 B = 10 x 256 B per row
+
+template <class Px, int K>   // K is compile-time: the tap loop unrolls completely, the register window rotates by renaming
+__global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_t src_pitch, char* dst, size_t dst_pitch,
+                                                          int W, int row_lo, int row_hi, int y0, int y1, int rows_per_chunk,
+                                                          int ring, const float* __restrict__ weights)
+{
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    constexpr int KQ = (K + 3) / 4;                               // f4 per padded weight row
+    constexpr int WN = 8;                                         // register window: 4 texels in use + 4 in flight
+    f4* wl = reinterpret_cast<f4*>(dyn_smem);                    // weights, [K][KQ] f4
+    f4* tile = wl + K * KQ;                                       // [ring][4][kCvSub]
+    constexpr int kRowTexels = kCvT * kCvSub;                     // 160 texels = 2560 B per ring row
+    constexpr int r = K / 2;
+    constexpr int xin = kCvStripW + 2 * r;
+    const int tid = (int)threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lx = lane & 31, ly = lane >> 5;
+
+    const int x_out0 = (int)blockIdx.x * kCvStripW;
+    const int cy0 = y0 + (int)blockIdx.y * rows_per_chunk;
+    const int cy1 = min(cy0 + rows_per_chunk, y1);
+    if (cy0 >= cy1) return;
+
+    // weight rows into LDS (a per-tap scalar load from global would stall the wave on every tap)
+    for (int i = tid; i < K * KQ * 4; i += 512) {
+        const int dy = i / (KQ * 4), dx = i % (KQ * 4);
+        reinterpret_cast<float*>(wl)[i] = dx < K ? weights[dy * K + dx] : 0.0f;
+    }
+    const int first_in = cy0 - r;
+    int loaded_to = first_in;
+    for (int ys = cy0; ys < cy1; ys += kCvStepRows) {
+        const int need_to = ys + kCvStepRows + r;
+        const int nrows = need_to - loaded_to;
+        for (int i = tid; i < nrows * xin; i += 512) {
+            const int rr = loaded_to + i / xin, c = i % xin;
+            const int gy = min(max(rr, row_lo), row_hi);
+            const int gx = min(max(x_out0 - r + c, 0), W - 1);
+            const f4 v = Px::decode(Px::load(src + (ptrdiff_t)gy * (ptrdiff_t)src_pitch, (unsigned)gx * (unsigned)Px::BPP));
+            const int slot = (rr - first_in) % ring;
+            tile[slot * kRowTexels + (c & 3) * kCvSub + (c >> 2)] = v;
+        }
+        loaded_to = need_to;
+        __syncthreads();
+
+        f4 acc[kCvT];
+#pragma unroll
+        for (int t = 0; t < kCvT; ++t) acc[t] = f4_zero();
+        int slot = ((ys - cy0) + 2 * wave + ly) % ring;           // ring slot of input row (ys + 2*wave + ly + dy - r)
+        for (int dy = 0; dy < K; ++dy) {
+            const f4* row = tile + slot * kRowTexels + lx;        // texel m of this lane's window: row[(m & 3) * kCvSub + (m >> 2)]
+            const f4* wrow = wl + dy * KQ;                        // same address in every lane: LDS broadcast
+            float wv[KQ * 4];
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) {
+                const f4 q = wrow[i];
+                wv[4 * i] = q.x; wv[4 * i + 1] = q.y; wv[4 * i + 2] = q.z; wv[4 * i + 3] = q.w;
+            }
+            f4 win[WN];
+#pragma unroll
+            for (int m = 0; m < WN; ++m) win[m] = row[(m & 3) * kCvSub + (m >> 2)];
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+#pragma unroll
+                for (int t = 0; t < kCvT; ++t) acc[t] = fma4(wv[dx], win[(dx + t) % WN], acc[t]);
+                // texel dx is done: its register takes texel dx + WN (needed 4 taps from now)
+                if (dx + WN <= K - 1 + kCvT - 1) {
+                    const int m = dx + WN;
+                    win[dx % WN] = row[(m & 3) * kCvSub + (m >> 2)];
+                }
+            }
+            slot = slot + 1 == ring ? 0 : slot + 1;
+        }
+        const int oy = ys + 2 * wave + ly;
+        if (oy < cy1) {
+            char* orow = dst + (ptrdiff_t)oy * (ptrdiff_t)dst_pitch;
+#pragma unroll
+            for (int t = 0; t < kCvT; ++t) {
+                const int ox = x_out0 + kCvT * lx + t;
+                if (ox < W) Px::store(orow, (unsigned)ox * (unsigned)Px::BPP, acc[t]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <class Px, int K = 9>
+static hipError_t launch_conv_valu(int k, dim3 grid, size_t lds, hipStream_t stream, const char* src, size_t src_pitch, char* dst,
+                                   size_t dst_pitch, int W, int row_lo, int row_hi, int y0, int y1, int rpc, int ring, const float* weights)
+{
+    if constexpr (K > 2 * kMaxRadius + 1) {
+        return hipErrorInvalidValue;
+    } else {
+        if (k != K) return launch_conv_valu<Px, K + 2>(k, grid, lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0, y1, rpc, ring, weights);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_valu_kernel<Px, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv2d_valu_kernel<Px, K>), grid, dim3(512), lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0, y1, rpc,
+                           ring, weights);
+        return hipGetLastError();
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Synthetic inputs, identical to rfo_fill_* in the oracle
 // ---------------------------------------------------------------------------------
 RF_DEV uint32_t hash32(uint32_t seed, uint32_t idx, uint32_t c)
@@ -1090,6 +1208,26 @@ static hipError_t launch_conv_mfma(int steps, dim3 grid, size_t lds, hipStream_t
     }
 }
 
+// Rows per chunk for the conv kernels: the chunk count is chosen so that strips x chunks fills
+// whole rounds of the `slots` workgroups the chip holds at once (a 60-strip frame cut into 13
+// chunks runs 780 workgroups = 3.05 rounds of 256 and wastes a quarter of the last one).
+static int conv_rows_per_chunk(int rows, int strips, int slots, int step, int min_rows)
+{
+    int best_c = 1;
+    double best_eff = 0.0;
+    for (int rounds = 2; rounds <= 8; ++rounds) {
+        int c = rounds * slots / strips;
+        if (c < 1) c = 1;
+        int rpc = ((rows + c - 1) / c + step - 1) / step * step;
+        if (rpc < min_rows) continue;
+        const int wgs = strips * ((rows + rpc - 1) / rpc);
+        const double eff = (double)wgs / (double)((wgs + slots - 1) / slots * slots);
+        if (eff > best_eff + 0.02) { best_eff = eff; best_c = c; }
+    }
+    int rpc = ((rows + best_c - 1) / best_c + step - 1) / step * step;
+    return rpc < min_rows ? min_rows : rpc;
+}
+
 static bool is_gauss(const Op& o, int r) { return o.kind == OP_GAUSSIAN && o.radius == r; }
 
 // index of the fused pattern matching ops[0..n), -1 if none
@@ -1143,16 +1281,24 @@ static hipError_t launch_ops_px(const Op* ops, int n, Image src, Image dst, cons
                 const int rows = g.y1 - g.y0;
                 if (rows <= 0 || g.W <= 0) return hipSuccess;
                 // large kernels run on the matrix cores; small ones keep the 16x16 LDS-tile kernel
+                const int rows_cv = g.y1 - g.y0;
+                if (tune.conv_path == 3 && K >= 9 && rows_cv > 0 && g.W > 0) {
+                    const int ring = (kCvStepRows + 2 * op.radius + 3) & ~3;
+                    const size_t lds = ((size_t)ring * kCvT * kCvSub + (size_t)K * ((K + 3) / 4)) * sizeof(f4);
+                    const int strips = (g.W + kCvStripW - 1) / kCvStripW;
+                    int rpc = conv_rows_per_chunk(rows_cv, strips, 256, kCvStepRows, 2 * kCvStepRows);   // one 124 KiB workgroup per CU
+                    if (tune.rows_per_chunk > 0) rpc = (tune.rows_per_chunk + kCvStepRows - 1) / kCvStepRows * kCvStepRows;
+                    dim3 grid((unsigned)strips, (unsigned)((rows_cv + rpc - 1) / rpc));
+                    return launch_conv_valu<Px>(K, grid, lds, stream, static_cast<const char*>(src.base), src.pitch, static_cast<char*>(dst.base),
+                                                dst.pitch, g.W, g.row_lo, g.row_hi, g.y0, g.y1, rpc, ring, op.dev_weights);
+                }
                 const bool mfma = tune.conv_path == 2 || (tune.conv_path != 1 && K >= 9);
                 if (mfma) {
                     const int pitch = conv_mfma_pitch(op.radius), ring = conv_mfma_ring(op.radius);
                     const size_t lds = ((size_t)K * kConvWRow + (size_t)ring * pitch) * sizeof(float);
                     const int strips = (g.W + kConvStripW - 1) / kConvStripW;
                     // ~4 workgroups per CU in flight; chunks are whole steps of 8 rows
-                    int chunks = (256 * 8 + strips - 1) / strips;
-                    int rpc = (rows + chunks - 1) / chunks;
-                    rpc = (rpc + kConvStepRows - 1) / kConvStepRows * kConvStepRows;
-                    if (rpc < 4 * kConvStepRows) rpc = 4 * kConvStepRows;
+                    int rpc = conv_rows_per_chunk(rows, strips, 512, kConvStepRows, 4 * kConvStepRows);   // two 70 KiB workgroups per CU
                     if (tune.rows_per_chunk > 0) rpc = (tune.rows_per_chunk + kConvStepRows - 1) / kConvStepRows * kConvStepRows;
                     dim3 grid((unsigned)strips, (unsigned)((rows + rpc - 1) / rpc));
                     return launch_conv_mfma<Px>((16 + 2 * op.radius + 3) / 4, grid, lds, stream, static_cast<const char*>(src.base), src.pitch,

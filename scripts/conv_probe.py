@@ -12,7 +12,7 @@ for K in (9, 15, 31):
         for (W, H) in ((97, 50), (64, 8), (130, 70)):
             x = util.synthetic(W, H, fmt)
             want = util.run_oracle(text, x)
-            for path in ("1", "2"):
+            for path in ("1", "2", "3"):
                 os.environ["RF_CONV_PATH"] = path
                 got = util.run_hip(ctx, text, x)
                 ok = got.tobytes() == want.tobytes()
@@ -21,7 +21,7 @@ for K in (9, 15, 31):
                     print("MISMATCH K=%d fmt=%d %dx%d path=%s n=%d first=%s got=%s want=%s" % (K, fmt, W, H, path, len(d), d[0], got[tuple(d[0])], want[tuple(d[0])]), flush=True)
     print("K=%d parity checked" % K, flush=True)
 text = "input -> conv2d -> output\nconv2d: conv2d { ksize: 31, sigma: 5.0 }"
-for path in ("1", "2"):
+for path in ("1", "2", "3"):
     os.environ["RF_CONV_PATH"] = path
     for (W, H) in ((1920, 1080), (7680, 4320)):
         g = rf.Graph(ctx, rf.Config(text), W, H, util.F32)

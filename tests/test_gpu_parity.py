@@ -167,6 +167,23 @@ def test_conv2d_31x31_and_custom_weights(ctx):
         util.assert_same(util.run_hip(ctx, text, x, weights={"conv2d": w}), util.run_oracle(text, x, {"conv2d": w}), "conv31 custom")
 
 
+@pytest.mark.parametrize("path", ["1", "2", "3"])
+def test_conv2d_every_kernel_path(ctx, path, monkeypatch):
+    """The three conv2d kernels (1 = 16x16 LDS tile, 2 = banded MFMA, 3 = register-blocked VALU)
+    are all bit-identical to the oracle: ragged widths around the 64/128-column strips, heights
+    around the 8/16-row steps, frame edges inside the halo."""
+    monkeypatch.setenv("RF_CONV_PATH", path)
+    for K, sigma in ((9, 1.5), (13, 2.0), (21, 3.5), (31, 5.0)):
+        text = "input -> conv2d -> output\nconv2d: conv2d { ksize: %d, sigma: %.1f }" % (K, sigma)
+        rng = np.random.RandomState(K)
+        w = rng.uniform(-0.03, 0.03, (K, K)).astype(np.float32)
+        for fmt in (util.F32, util.U8):
+            for W, H in ((7, 5), (65, 9), (129, 17), (200, 45)):
+                x = util.synthetic(W, H, fmt, seed=K * 100 + W)
+                util.assert_same(util.run_hip(ctx, text, x, weights={"conv2d": w}), util.run_oracle(text, x, {"conv2d": w}),
+                                 "conv path %s K=%d %dx%d fmt=%d" % (path, K, W, H, fmt))
+
+
 # ---- the sRGB boundary (render.rs:264-313, :406-433) ------------------------------------
 def test_srgb_identity_and_lut(ctx):
     c = np.zeros((4, 256, 4), np.uint8)
