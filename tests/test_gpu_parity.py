@@ -167,6 +167,23 @@ def test_conv2d_31x31_and_custom_weights(ctx):
         util.assert_same(util.run_hip(ctx, text, x, weights={"conv2d": w}), util.run_oracle(text, x, {"conv2d": w}), "conv31 custom")
 
 
+def test_non_finite_texels_propagate_like_the_oracle(ctx):
+    """inf / nan / -0 / subnormal texels through the stencil and point stages: the same texels
+    are NaN on both sides and every other texel is bit-identical (NaN payloads are not compared;
+    the clamp of the colour grade maps NaN to 0 on both sides)."""
+    x = util.synthetic(90, 40, util.F32, seed=99)
+    x[5, 7] = [np.inf, -np.inf, np.nan, 1.0]
+    x[20, 60] = [-0.0, 1e-42, -1e-42, 3e38]
+    x[39, 89] = [np.nan, 0.5, np.inf, -np.inf]
+    for name in ("gaussian5", "gaussian9", "sharpen", "grade", "chain3", "passthrough"):
+        want = util.run_oracle(NODES[name], x)
+        for flags in (0, NF):
+            got = util.run_hip(ctx, NODES[name], x, flags=flags)
+            assert (np.isnan(got) == np.isnan(want)).all(), name
+            ok = np.isnan(want) | (got.view(np.uint32) == want.view(np.uint32))
+            assert ok.all(), "%s flags=%d: %d finite texels differ" % (name, flags, (~ok).sum())
+
+
 @pytest.mark.parametrize("path", ["1", "2", "3"])
 def test_conv2d_every_kernel_path(ctx, path, monkeypatch):
     """The three conv2d kernels (1 = 16x16 LDS tile, 2 = banded MFMA, 3 = register-blocked VALU)
