@@ -1,0 +1,112 @@
+// rf_device.h -- device-side basics shared by the gfx950 kernel files: the texel type, the
+// packed fma, and the two texel formats (what imageLoad / imageStore do on a storage image,
+// shaders/passthrough.comp:9,:12).  Numerics: every multiply-add in the kernels is an explicit
+// fmaf in the oracle's order and the files are compiled with -ffp-contract=off, so results are
+// bit-identical to oracle/rf_oracle.c for finite inputs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "rf_kernels.h"
+
+namespace rf {
+
+typedef float4 f4;
+
+#define RF_DEV __device__ __forceinline__
+
+RF_DEV f4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// four fmaf as two v_pk_fma_f32 (each lane-pair fma is still one single-rounding fmaf): a VALU
+// instruction costs the same issue slot packed or not, and the kernels are issue-sensitive
+typedef float v2f __attribute__((ext_vector_type(2)));
+RF_DEV f4 fma4(float w, f4 v, f4 a)
+{
+    const v2f ww = {w, w};
+    const v2f lo = __builtin_elementwise_fma(ww, v2f{v.x, v.y}, v2f{a.x, a.y});
+    const v2f hi = __builtin_elementwise_fma(ww, v2f{v.z, v.w}, v2f{a.z, a.w});
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
+// ---------------------------------------------------------------------------------
+// Texel formats: what imageLoad/imageStore do (shaders/passthrough.comp:9,:12)
+// ---------------------------------------------------------------------------------
+// c / 255 correctly rounded, without the ~12-instruction IEEE division sequence: one Newton
+// step on q = c * fl(1/255) gives the correctly rounded quotient for all 256 codes
+// (tests/test_gpu_parity.py::test_unorm8_decode_all_codes checks every code against the
+// oracle's true division).
+RF_DEV float unorm8_to_f32(unsigned c)
+{
+    const float r = 1.0f / 255.0f;
+    const float x = (float)c;
+    const float q = x * r;
+    const float e = fmaf(-q, 255.0f, x);
+    return fmaf(e, r, q);
+}
+RF_DEV unsigned f32_to_unorm8(float v)
+{
+    // clamp (NaN -> 0), x255, round to nearest even
+    v = (v > 0.0f) ? v : 0.0f;
+    v = (v > 1.0f) ? 1.0f : v;
+    return (unsigned)rintf(v * 255.0f);
+}
+
+struct PxF32 {
+    typedef f4 Raw;
+    static constexpr int BPP = 16;
+    static constexpr bool QUANT = false;
+    RF_DEV static Raw load(const char* row, unsigned xoff) { return *reinterpret_cast<const f4*>(row + xoff); }
+    RF_DEV static f4 decode(Raw r) { return r; }
+    // Take a row out of the prefetch ring into registers of its own.  A real v_mov (the asm
+    // is opaque to the optimiser) ends the ring slot's live range HERE, so the refill that
+    // follows loads in place and the slot keeps its registers around the loop; without it
+    // the compiler renames, copies the slots at the back edge and drains every load in
+    // flight with s_waitcnt vmcnt(0) to do so.
+    RF_DEV static f4 take(Raw r)
+    {
+        f4 o;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(o.x) : "v"(r.x));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(o.y) : "v"(r.y));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(o.z) : "v"(r.z));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(o.w) : "v"(r.w));
+        return o;
+    }
+    RF_DEV static void store(char* row, unsigned xoff, f4 v)
+    {
+        // MUST stay one global_store_dwordx4: the stream kernel's counted vmcnt waits rely on
+        // one vector-memory instruction per stored row (a non-temporal variant was measured:
+        // no gain, and split into four stores it would break the count)
+        *reinterpret_cast<f4*>(row + xoff) = v;
+    }
+    RF_DEV static f4 requant(f4 v) { return v; }
+};
+
+struct PxU8 {
+    typedef unsigned Raw;
+    static constexpr int BPP = 4;
+    static constexpr bool QUANT = true;
+    RF_DEV static Raw load(const char* row, unsigned xoff) { return *reinterpret_cast<const unsigned*>(row + xoff); }
+    RF_DEV static f4 decode(Raw r)
+    {
+        return make_float4(unorm8_to_f32(r & 255u), unorm8_to_f32((r >> 8) & 255u),
+                           unorm8_to_f32((r >> 16) & 255u), unorm8_to_f32(r >> 24));
+    }
+    RF_DEV static f4 take(Raw r) { return decode(r); }   // the conversion already leaves the ring slot dead
+    RF_DEV static unsigned pack(f4 v)
+    {
+        return f32_to_unorm8(v.x) | (f32_to_unorm8(v.y) << 8) | (f32_to_unorm8(v.z) << 16) |
+               (f32_to_unorm8(v.w) << 24);
+    }
+    RF_DEV static void store(char* row, unsigned xoff, f4 v) { *reinterpret_cast<unsigned*>(row + xoff) = pack(v); }
+    // what a store followed by a load of the next node does to a value
+    RF_DEV static f4 requant(f4 v) { return decode(pack(v)); }
+};
+
+// dense KxK convolution launch (rf_conv.hip), called from launch_ops
+hipError_t launch_conv2d(int fmt, const Op& op, Image src, Image dst, const Geom& g, const StreamTuning& tune, hipStream_t stream);
+
+}  // namespace rf

@@ -1,4 +1,4 @@
-// rf_kernels.h -- host-side launch interface of the gfx950 kernels (rf_kernels.hip).
+// rf_kernels.h -- host-side launch interface of the gfx950 kernels (rf_stream.hip, rf_conv.hip, rf_misc.hip).
 //
 // These replace the reference's GLSL compute shaders (shaders/*.comp, of which only
 // passthrough.comp exists) and the per-node vkCmdDispatch of

@@ -1,0 +1,755 @@
+// rf_stream.hip -- the streaming stage-pipeline kernel for gfx950 (CDNA4, wave64): every stencil / point node of the reforge
+// render-graph path.  They replace shaders/*.comp + the per-node vkCmdDispatch of
+// src/vulkan/command.rs:166-242.
+//
+// Design (DESIGN.md "Kernels"): the stencil/point nodes are HBM-bound (32 B/px for an
+// rgba32f node), so the kernel is built to move every input row across the fabric
+// once and keep everything else on chip:
+//
+//   * WAVE-AUTONOMOUS STREAMING PIPELINE.  Each 64-lane wave owns a column strip
+//     64 pixels wide (one 16-byte texel per lane: one 1 KiB fully coalesced
+//     global_load_dwordx4 per row) and walks DOWN a chunk of rows.  A node is a short
+//     list of row stages (horizontal taps, vertical taps, point op, 3x3 cross); a
+//     fused chain of nodes is simply a longer list.  Vertical taps keep a rolling
+//     window of rows in VGPRs; horizontal taps exchange the current row between
+//     lanes through a wave-private 1 KiB LDS row (halo = the wave's own edge lanes),
+//     so there is no workgroup barrier anywhere in the kernel -- LDS operations of
+//     one wave execute in order.
+//   * Input rows are prefetched PF rows ahead into a register ring (static indices
+//     via an unrolled loop) so each wave keeps PF KiB in flight.
+//   * Clamp-to-edge is applied where a stage READS (row index and lane index are
+//     clamped to the image), which is what makes chained stages bit-identical to
+//     running the nodes one full-frame pass at a time.
+//
+// Numerics: every multiply-add is an explicit fmaf in the oracle's tap order; this
+// file is compiled with -ffp-contract=off, so results are bit-identical to
+// oracle/rf_oracle.c for finite inputs.
+#include "rf_device.h"
+
+namespace rf {
+
+// ---------------------------------------------------------------------------------
+// Per-lane context of a streaming wave
+// ---------------------------------------------------------------------------------
+struct Lane {
+    int lane;   // 0..63
+    int x;      // frame column this lane stands for (may lie outside [0,W) in the halo)
+    int x0;     // column of lane 0
+    int W;
+    f4* lds;    // wave-private LDS rows, 64 texels each
+    // LDS slot holding column clamp(x+dx) -- clamp-to-edge at the frame border, and
+    // kept inside the wave's row for the halo lanes (whose results are discarded)
+    RF_DEV int nbr(int dx) const
+    {
+        int c = min(max(x + dx, 0), W - 1) - x0;
+        return min(max(c, 0), 63);
+    }
+};
+
+// LDS operations of one wave execute in issue order, so a wave-private exchange
+// needs no s_barrier: only the compiler has to be told not to reorder.
+RF_DEV void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------
+// Source: the wave's input rows, streamed global -> LDS by LDS-DMA (global_load_lds_*:
+// no VGPR destination) into a wave-private ring of PF row slots, PF rows ahead.
+//
+// Why hand-written: with compiler-visible loads hipcc drains EVERY load in flight
+// (s_waitcnt vmcnt(0)) at each use, because loads and stores share vmcnt on gfx9 and its
+// wait-count pass treats mixed pending events as out of order.  The DMA is issued from an
+// asm statement (invisible to that pass) and waited for with a COUNTED vmcnt: vector
+// memory operations retire in issue order, and a wave issues exactly one DMA per input
+// row and one store per output row, in a fixed program order (see wait_row).
+// ---------------------------------------------------------------------------------
+template <int N> RF_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+struct Sink {
+    char* dst;          // address of local row 0
+    ptrdiff_t pitch;    // negative when the wave walks bottom-up
+    unsigned xoff;      // lane's byte offset in a row
+    bool lane_ok;       // lane owns an output texel
+    int row;            // next output row
+    int first_store;    // iteration of the first store, -1 before it (wave-uniform)
+};
+
+template <class Px, int PF> struct Source {
+    static_assert(PF >= 2, "the ring needs at least two slots");
+    static constexpr int SLOTS = PF;
+    static constexpr int SLOT_BYTES = 64 * Px::BPP;
+    const char* src;      // address of local row 0, already offset by the lane's column
+    ptrdiff_t pitch;
+    int a0, n0;           // first source row, number of source rows
+    unsigned lds_base;    // LDS byte address of slot 0 (wave-uniform)
+    const char* ring;     // the same ring through a generic pointer
+
+    RF_DEV const char* slot(int r) const { return ring + (size_t)(r % SLOTS) * SLOT_BYTES; }
+
+    // DMA source row r into slot r % PF.  Program order inside iteration `it` is
+    //   [first stage consumes row it] -> issue(it+PF) -> wait_row(it+1) -> ... -> store
+    RF_DEV void issue(int r) const
+    {
+        const char* g = src + (ptrdiff_t)(a0 + r) * pitch;
+        const unsigned dst = lds_base + (unsigned)(r % SLOTS) * (unsigned)SLOT_BYTES;
+        unsigned keep;
+        if constexpr (Px::BPP == 16)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+    }
+    RF_DEV void prologue() const
+    {
+        for (int r = 0; r < PF && r < n0; ++r) issue(r);
+    }
+    // Wait until row r has landed, leaving younger operations in flight.  Younger than
+    // row r's DMA at this point: the DMAs of rows r+1 .. r+PF-1 (when they exist) and, once
+    // the pipeline emits a row per iteration, the stores of the PF-1 iterations in between.
+    RF_DEV void wait_row(int r, const Sink& k) const
+    {
+        if (n0 - 1 - r >= PF - 1) {
+            if (k.first_store >= 0 && k.first_store <= r - PF) wait_vmcnt<2 * PF - 2>();
+            else wait_vmcnt<PF - 1>();
+        } else {
+            wait_vmcnt<0>();
+        }
+    }
+};
+
+// what the first stage is handed each iteration, fetched from the ring one iteration
+// ahead so the LDS latency hides behind the previous row's arithmetic
+template <class Px> struct OwnFeed {      // the lane's own texel
+    typename Px::Raw nxt;
+    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane& L)
+    {
+        nxt = *reinterpret_cast<const typename Px::Raw*>(s.slot(r) + (size_t)L.lane * Px::BPP);
+    }
+    RF_DEV f4 own() const { return Px::decode(nxt); }
+};
+template <int R> struct TapFeed {         // rgba32f: the 2R+1 horizontal taps, straight from the DMA ring
+    f4 t[2 * R + 1];
+    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane& L)
+    {
+        const f4* row = reinterpret_cast<const f4*>(s.slot(r));
+#pragma unroll
+        for (int i = -R; i <= R; ++i) t[i + R] = row[L.nbr(i)];
+    }
+    RF_DEV f4 own() const { return t[R]; }
+};
+
+// ---------------------------------------------------------------------------------
+// Row stages.  advance() is called once per row entering the stage:
+//   v      the row's texel for this lane (undefined when !real)
+//   real   a new input row; false = the newest row repeated (clamp-to-edge below the frame)
+//   first  the stage's first row: it primes the whole window (clamp-to-edge above the frame,
+//          or rows that are shifted out again before anything is emitted)
+//   emit   the window's centre row is wanted downstream (wave-uniform, from the schedule)
+// ---------------------------------------------------------------------------------
+struct NoState {};
+
+// horizontal taps of the separable gaussian: sum_i w[|i|] * in[x+i], ascending i
+template <int R> struct StHTap {
+    static constexpr int RV = 0, RH = R, LDS_ROWS = (R > 0) ? 1 : 0;
+    struct Params { float w[R + 1]; };
+    template <class Px> using State = NoState;
+    // as the FIRST stage of an rgba32f pipeline the taps come straight from the DMA ring
+    template <class Px> using Feed = typename std::conditional<Px::QUANT, OwnFeed<Px>, TapFeed<R>>::type;
+    RF_DEV static f4 from_taps(const Params& p, const TapFeed<R>& f)
+    {
+        f4 acc = f4_zero();
+#pragma unroll
+        for (int i = -R; i <= R; ++i) acc = fma4(p.w[i < 0 ? -i : i], f.t[i + R], acc);
+        return acc;
+    }
+    template <class Px, bool REV> RF_DEV static void advance(const Params& p, NoState&, const Lane& L, f4* lds, f4 v, bool, bool, bool, f4& out)
+    {
+        if constexpr (R > 0) {
+            lds[L.lane] = v;
+            wave_sync();
+        }
+        f4 acc = f4_zero();
+#pragma unroll
+        for (int i = -R; i <= R; ++i) {
+            f4 t = (i == 0) ? v : lds[L.nbr(i)];
+            acc = fma4(p.w[i < 0 ? -i : i], t, acc);
+        }
+        out = acc;
+    }
+};
+
+// vertical taps: sum_j w[|j|] * tmp[y+j], ascending j; the window lives in VGPRs
+template <int R> struct StVTap {
+    static constexpr int RV = R, RH = 0, LDS_ROWS = 0;
+    struct Params { float w[R + 1]; };
+    template <class Px> struct State { f4 win[2 * R + 1]; };
+    template <class Px> using Feed = OwnFeed<Px>;
+    template <class Px, bool REV> RF_DEV static void advance(const Params& p, State<Px>& s, const Lane&, f4*, f4 v, bool real, bool first, bool emit, f4& out)
+    {
+        const int pushes = first ? 2 * R + 1 : 1;
+        for (int q = 0; q < pushes; ++q) {
+#pragma unroll
+            for (int i = 0; i < 2 * R; ++i) s.win[i] = s.win[i + 1];
+            if (real) s.win[2 * R] = v;
+        }
+        if (emit) {
+            f4 acc = f4_zero();
+#pragma unroll
+            // taps are accumulated in ascending FRAME row order; walking bottom-up the window
+            // holds the rows the other way round
+            for (int j = -R; j <= R; ++j) acc = fma4(p.w[j < 0 ? -j : j], s.win[REV ? R - j : j + R], acc);
+            out = acc;
+        }
+    }
+};
+
+// colour grade point op
+struct StGrade {
+    static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
+    struct Params { float slope, offset, saturation; };
+    template <class Px> using State = NoState;
+    template <class Px> using Feed = OwnFeed<Px>;
+    RF_DEV static float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+    template <class Px, bool REV> RF_DEV static void advance(const Params& p, NoState&, const Lane&, f4*, f4 c, bool, bool, bool, f4& out)
+    {
+        float tr = fmaf(c.x, p.slope, p.offset);
+        float tg = fmaf(c.y, p.slope, p.offset);
+        float tb = fmaf(c.z, p.slope, p.offset);
+        float luma = fmaf(0.0722f, tb, fmaf(0.7152f, tg, 0.2126f * tr));
+        out = make_float4(clamp01(fmaf(p.saturation, tr - luma, luma)), clamp01(fmaf(p.saturation, tg - luma, luma)),
+                          clamp01(fmaf(p.saturation, tb - luma, luma)), c.w);
+    }
+};
+
+// 3x3 sharpen cross [0,s,0; s,c,s; 0,s,0], taps in ascending (y outer, x inner) order.
+// The horizontal neighbours of a row are fetched through LDS when the row ARRIVES and
+// are first used one iteration later, when that row is the centre: the LDS round trip
+// hides behind a whole iteration instead of stalling the wave.
+struct StCross3 {
+    static constexpr int RV = 1, RH = 1, LDS_ROWS = 1;
+    struct Params { float wc, ws; };
+    template <class Px> struct State { f4 n, c, cw, ce; };   // rows y-1, y and y's left/right neighbours
+    template <class Px> using Feed = OwnFeed<Px>;
+    RF_DEV static void exchange(const Lane& L, f4* lds, f4 v, f4& w, f4& e)
+    {
+        lds[L.lane] = v;
+        wave_sync();
+        w = lds[L.nbr(-1)];
+        e = lds[L.nbr(+1)];
+    }
+    template <class Px, bool REV> RF_DEV static void advance(const Params& p, State<Px>& s, const Lane& L, f4* lds, f4 v, bool real, bool first, bool emit, f4& out)
+    {
+        if (first) {                     // window = [v, v, (next row)]
+            s.n = v;
+            s.c = v;
+            exchange(L, lds, v, s.cw, s.ce);
+            return;
+        }
+        const f4 below = real ? v : s.c;
+        if (emit) {
+            f4 acc = f4_zero();
+            // frame order N, W, C, E, S: walking bottom-up the older row is the one BELOW
+            acc = fma4(p.ws, REV ? below : s.n, acc);
+            acc = fma4(p.ws, s.cw, acc);
+            acc = fma4(p.wc, s.c, acc);
+            acc = fma4(p.ws, s.ce, acc);
+            acc = fma4(p.ws, REV ? s.n : below, acc);
+            out = acc;
+        }
+        s.n = s.c;
+        if (real) {
+            s.c = v;
+            exchange(L, lds, v, s.cw, s.ce);
+        }
+    }
+};
+
+// node boundary inside a fused chain: the store + load the unfused graph performs
+// (UNORM8 re-quantisation for rgba8, nothing for rgba32f)
+struct StNodeEnd {
+    static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
+    struct Params {};
+    template <class Px> using State = NoState;
+    template <class Px> using Feed = OwnFeed<Px>;
+    template <class Px, bool REV> RF_DEV static void advance(const Params&, NoState&, const Lane&, f4*, f4 v, bool, bool, bool, f4& out)
+    {
+        out = Px::requant(v);
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// Parameter pack (kernel argument) and the stage chain (per-wave state)
+// ---------------------------------------------------------------------------------
+template <class... S> struct ParamPack;
+template <> struct ParamPack<> {};
+template <class S, class... Rest> struct ParamPack<S, Rest...> {
+    typename S::Params p;
+    ParamPack<Rest...> rest;
+};
+
+template <class... S> struct SumRH { static constexpr int value = 0; };
+template <class S, class... Rest> struct SumRH<S, Rest...> { static constexpr int value = S::RH + SumRH<Rest...>::value; };
+template <class... S> struct SumLDS { static constexpr int value = 0; };
+template <class S, class... Rest> struct SumLDS<S, Rest...> { static constexpr int value = S::LDS_ROWS + SumLDS<Rest...>::value; };
+template <class... S> struct SumRV { static constexpr int value = 0; };
+template <class S, class... Rest> struct SumRV<S, Rest...> { static constexpr int value = S::RV + SumRV<Rest...>::value; };
+template <class S, class...> struct FirstOf { typedef S type; };
+
+// REV: the wave walks its chunk bottom-up (rows are addressed with a negated pitch, so the
+// schedule below is unchanged); stages whose tap order depends on the row direction read it.
+template <class Px, bool REV, int LdsIdx, class... S> struct Chain;
+
+// end of the chain: the store
+template <class Px, bool REV, int LdsIdx> struct Chain<Px, REV, LdsIdx> {
+    RF_DEV void plan_backward(int oa, int ob, int, int, int& in_a, int& in_b) { in_a = oa; in_b = ob; }
+    RF_DEV int plan_forward(int tprev) { return tprev; }
+    template <bool STEADY> RF_DEV void step(bool has, f4 v, int it, const Lane&, Sink& k, const ParamPack<>&)
+    {
+        if (STEADY || has) {
+            // exactly ONE vector-memory instruction per emitted row: Source::wait_row counts on it
+            if (k.lane_ok) Px::store(k.dst + (ptrdiff_t)k.row * k.pitch, k.xoff, v);
+            k.row += 1;
+            if (!STEADY && k.first_store < 0) k.first_store = it;
+        }
+    }
+};
+
+template <class Px, bool REV, int LdsIdx, class S, class... Rest> struct Chain<Px, REV, LdsIdx, S, Rest...> {
+    typename S::template State<Px> st;
+    // wave-uniform schedule
+    int a;        // first input row
+    int oa;       // first output row
+    int flush;    // replications of the last input row (frame bottom edge)
+    int tprev;    // iteration of the upstream stage's last emission
+    int cnt;      // input rows consumed
+    Chain<Px, REV, LdsIdx + S::LDS_ROWS, Rest...> next;
+
+    // given the rows the LAST stage must emit, derive what each stage must emit/consume
+    RF_DEV void plan_backward(int oa_last, int ob_last, int lo, int hi, int& in_a, int& in_b)
+    {
+        int need_a, need_b;
+        next.plan_backward(oa_last, ob_last, lo, hi, need_a, need_b);
+        oa = need_a;
+        a = max(lo, need_a - S::RV);
+        int b = min(hi, need_b + S::RV);
+        flush = need_b + S::RV - b;
+        cnt = 0;
+        in_a = a;
+        in_b = b;
+    }
+    RF_DEV int plan_forward(int tp)
+    {
+        tprev = tp;
+        return next.plan_forward(tp + flush);
+    }
+    // A row (or a flush tick) enters this stage.  STEADY = every stage receives a real row,
+    // is past its first row and emits: the schedule tests fold away at compile time.
+    template <bool STEADY> RF_DEV void step(bool has_prev, f4 v, int it, const Lane& L, Sink& k, const ParamPack<S, Rest...>& P)
+    {
+        bool has = false;
+        f4 out = f4_zero();
+        if constexpr (STEADY) {
+            S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, v, true, false, true, out);
+            cnt += 1;
+            has = true;
+        } else if constexpr (S::RV == 0) {
+            if (has_prev) {              // row-local stage: one row in, one row out, never flushed
+                S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, v, true, cnt == 0, true, out);
+                cnt += 1;
+                has = true;
+            }
+        } else {
+            const bool flushing = !has_prev && it > tprev && it <= tprev + flush;
+            if (has_prev || flushing) {
+                has = (a + cnt - S::RV) >= oa;
+                S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, v, has_prev, cnt == 0, has, out);
+                cnt += 1;
+            }
+        }
+        next.template step<STEADY>(has, out, it, L, k, P.rest);
+    }
+    // first stage: the row comes from the source feed; once it is consumed its ring slot is
+    // refilled and the NEXT row's values are fetched into registers
+    template <bool STEADY, class Feed, class Src>
+    RF_DEV void step_first(bool has0, Feed& feed, const Src& src, int it, const Lane& L, Sink& k, const ParamPack<S, Rest...>& P)
+    {
+        bool has = false;
+        f4 out = f4_zero();
+        if constexpr (STEADY) {
+            if constexpr (std::is_same<Feed, OwnFeed<Px>>::value)
+                S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), true, false, true, out);
+            else
+                out = S::from_taps(P.p, feed);
+            cnt += 1;
+            has = true;
+            src.issue(it + Src::SLOTS);
+            wait_vmcnt<2 * Src::SLOTS - 2>();
+            feed.fetch(src, it + 1, L);
+        } else {
+            if constexpr (S::RV == 0) {
+                if (has0) {
+                    if constexpr (std::is_same<Feed, OwnFeed<Px>>::value)
+                        S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), true, cnt == 0, true, out);
+                    else
+                        out = S::from_taps(P.p, feed);
+                    cnt += 1;
+                    has = true;
+                }
+            } else {
+                const bool flushing = !has0 && it > tprev && it <= tprev + flush;
+                if (has0 || flushing) {
+                    has = (a + cnt - S::RV) >= oa;
+                    S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), has0, cnt == 0, has, out);
+                    cnt += 1;
+                }
+            }
+            if (has0) {
+                if (it + Src::SLOTS < src.n0) src.issue(it + Src::SLOTS);
+                if (it + 1 < src.n0) {
+                    src.wait_row(it + 1, k);
+                    feed.fetch(src, it + 1, L);
+                }
+            }
+        }
+        next.template step<STEADY>(has, out, it, L, k, P.rest);
+    }
+};
+
+template <class... S> struct StreamArgs {
+    const char* src;
+    size_t src_pitch;
+    char* dst;
+    size_t dst_pitch;
+    int W, row_lo, row_hi, y0, y1, rows_per_chunk, n_strips;
+    int n_work;   // workgroups with work = strip groups x chunks (the grid is padded to a multiple of 8)
+    int alternate;   // odd chunks walk bottom-up (halo rows shared through L2)
+    ParamPack<S...> params;
+};
+
+#ifndef RF_WAVES_PER_BLOCK
+#define RF_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = RF_WAVES_PER_BLOCK;
+
+// One wave's walk over rows [y0, y1) of its strip.  REV = bottom-up: rows are addressed with
+// negated pitches and mirrored bounds, so the schedule code sees an ordinary top-down walk.
+template <class Px, int PF, bool REV, class... S>
+RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane& L, int wave, char* ring_wave, unsigned ring_lds, int y0, int y1)
+{
+    constexpr int RH = SumRH<S...>::value;
+    typedef Source<Px, PF> Src;
+    typedef typename FirstOf<S...>::type::template Feed<Px> Feed;
+    (void)wave;
+
+    // the walk's own row coordinate v: v = y top-down, v = -y bottom-up
+    const int v0 = REV ? -(y1 - 1) : y0, v1 = REV ? -y0 + 1 : y1;
+    const int lo = REV ? -A.row_hi : A.row_lo, hi = REV ? -A.row_lo : A.row_hi;
+
+    Sink k;
+    k.dst = A.dst;
+    k.pitch = REV ? -(ptrdiff_t)A.dst_pitch : (ptrdiff_t)A.dst_pitch;
+    k.xoff = (unsigned)min(max(L.x, 0), A.W - 1) * (unsigned)Px::BPP;
+    k.lane_ok = (L.lane >= RH) && (L.lane < 64 - RH) && (L.x < A.W);
+    k.row = v0;
+    k.first_store = -1;
+
+    Chain<Px, REV, 0, S...> chain;
+    Src src;
+    int b0;
+    chain.plan_backward(v0, v1 - 1, lo, hi, src.a0, b0);
+    src.n0 = b0 - src.a0 + 1;                        // source rows
+    const int total = chain.plan_forward(src.n0 - 1) + 1;
+
+    // source: rows a0..b0, column clamp(x)
+    src.src = A.src + k.xoff;
+    src.pitch = REV ? -(ptrdiff_t)A.src_pitch : (ptrdiff_t)A.src_pitch;
+    src.ring = ring_wave;
+    src.lds_base = ring_lds;
+    src.prologue();
+    Feed feed;
+    src.wait_row(0, k);
+    feed.fetch(src, 0, L);
+
+    // Three phases: a generic loop while the pipeline primes, a branch-free STEADY loop while
+    // every stage takes a real row and emits one (and the counted waits are in their steady
+    // form: the PF-1 previous iterations all stored, the next PF rows all exist), and the
+    // generic loop again for the tail and the bottom-edge flush.
+    int it = 0;
+    while (it < total && !(k.first_store >= 0 && it + 1 - PF >= k.first_store)) {
+        chain.template step_first<false>(it < src.n0, feed, src, it, L, k, A.params);
+        ++it;
+    }
+    const int steady_end = src.n0 - PF;
+    for (; it < steady_end; ++it) chain.template step_first<true>(true, feed, src, it, L, k, A.params);
+    for (; it < total; ++it) chain.template step_first<false>(it < src.n0, feed, src, it, L, k, A.params);
+}
+
+template <class Px, int PF, class... S>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void stream_kernel(const StreamArgs<S...> A)
+{
+    constexpr int RH = SumRH<S...>::value;
+    constexpr int VALID = 64 - 2 * RH;
+    constexpr int LDSR = SumLDS<S...>::value;
+    typedef Source<Px, PF> Src;
+    __shared__ f4 smem[kWavesPerBlock][(LDSR > 0 ? LDSR : 1) * 64];
+    __shared__ __attribute__((aligned(16))) char ring[kWavesPerBlock][Src::SLOTS * Src::SLOT_BYTES];
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // XCD-aware block order (guide T1): blocks are dealt round-robin over the 8 XCDs, so block
+    // b and b+8 share an L2.  Give each XCD a CONTIGUOUS range of work items (strip groups
+    // fastest, then chunks): workgroups that share halo columns or halo rows then share an L2.
+    // Speed only -- any placement gives the same result.
+    const int gx = (A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int q = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (q >= A.n_work) return;
+    const int strip = (q % gx) * kWavesPerBlock + wave;
+    if (strip >= A.n_strips) return;                 // wave-uniform; no barriers below
+    const int chunk = q / gx;
+    const int y0 = A.y0 + chunk * A.rows_per_chunk;
+    const int y1 = min(y0 + A.rows_per_chunk, A.y1);
+    if (y0 >= y1) return;
+
+    Lane L;
+    L.lane = (int)(threadIdx.x & 63);
+    L.x0 = strip * VALID - RH;
+    L.x = L.x0 + L.lane;
+    L.W = A.W;
+    L.lds = smem[wave];
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&ring[0][0]) + (unsigned)wave * (unsigned)(Src::SLOTS * Src::SLOT_BYTES));
+
+    // Odd chunks walk bottom-up: a chunk and its neighbour then read the halo rows they
+    // share at the same moment (both at their start, or both at their end), so the second
+    // read is served by the XCD's L2 instead of the fabric.  Stencil-free pipelines have no
+    // halo and always walk top-down.
+    constexpr bool kHasHalo = SumRV<S...>::value > 0;
+    if (kHasHalo && A.alternate && (chunk & 1))
+        stream_wave<Px, PF, true, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
+    else
+        stream_wave<Px, PF, false, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
+}
+
+// ---------------------------------------------------------------------------------
+// Host side: op list -> stage list -> kernel instantiation
+// ---------------------------------------------------------------------------------
+static int choose_rows_per_chunk(int rows, int n_strips, int halo_rows, const StreamTuning& tune)
+{
+    if (tune.rows_per_chunk > 0) return tune.rows_per_chunk;
+    // aim for ~12 waves per CU over 256 CUs, but keep the re-read of the vertical halo
+    // (2*halo_rows per chunk) under ~10 % of a chunk
+    const int target_waves = 256 * 12;
+    int chunks = (target_waves + n_strips - 1) / n_strips;
+    if (chunks < 1) chunks = 1;
+    int rpc = (rows + chunks - 1) / chunks;
+    // measured on MI355X (3840x2160, fused 3-stage chain, 6 halo rows per chunk): 48-row chunks
+    // 49 us, 32-row 51 us, 64..90-row 54-56 us, 135-row 62 us -- more, shorter chunks win until
+    // the re-read of the vertical halo (2*halo_rows per chunk) passes ~12 % of a chunk
+    int min_rpc = halo_rows > 0 ? 16 * halo_rows : 8;
+    if (rpc < min_rpc) rpc = min_rpc;
+    // large frames: many short chunks beat a few long ones (16384^2 5-stage chain: 64..128-row
+    // chunks 76k Mpx/s, 1490-row chunks 67k) -- waves queue behind each other and even out
+    const int cap = min_rpc > 128 ? min_rpc : 128;
+    if (rpc > cap) rpc = cap;
+    if (rpc > rows) rpc = rows;
+    if (rpc < 1) rpc = 1;
+    return rpc;
+}
+
+template <class Px, int PF, class... S>
+static hipError_t launch_stream(Image src, Image dst, const Geom& g, const StreamTuning& tune, hipStream_t stream,
+                                const ParamPack<S...>& params, int halo_rows)
+{
+    constexpr int RH = SumRH<S...>::value;
+    constexpr int VALID = 64 - 2 * RH;
+    static_assert(VALID > 0, "horizontal halo too wide for a 64-lane strip");
+    StreamArgs<S...> A;
+    A.src = static_cast<const char*>(src.base);
+    A.src_pitch = src.pitch;
+    A.dst = static_cast<char*>(dst.base);
+    A.dst_pitch = dst.pitch;
+    A.W = g.W;
+    A.row_lo = g.row_lo;
+    A.row_hi = g.row_hi;
+    A.y0 = g.y0;
+    A.y1 = g.y1;
+    A.n_strips = (g.W + VALID - 1) / VALID;
+    const int rows = g.y1 - g.y0;
+    if (rows <= 0 || g.W <= 0) return hipSuccess;
+    A.rows_per_chunk = choose_rows_per_chunk(rows, A.n_strips, halo_rows, tune);
+    A.params = params;
+    A.n_work = ((A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock) * ((rows + A.rows_per_chunk - 1) / A.rows_per_chunk);
+    A.alternate = tune.no_alternate ? 0 : 1;
+    dim3 grid((unsigned)((A.n_work + 7) / 8 * 8));   // 1-D, a multiple of the 8 XCDs (see the kernel's block order)
+    // prefetch depth: the template argument is the default; RF_PREFETCH_ROWS=8 selects the
+    // deeper ring where it is instantiated (radius <= 4)
+    if constexpr (PF == 4) {
+        if (tune.prefetch_rows == 8) {
+            hipLaunchKernelGGL((stream_kernel<Px, 8, S...>), grid, dim3(64 * kWavesPerBlock), 0, stream, A);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((stream_kernel<Px, PF, S...>), grid, dim3(64 * kWavesPerBlock), 0, stream, A);
+    return hipGetLastError();
+}
+
+// ---- op -> params helpers -------------------------------------------------------
+template <int R> static typename StHTap<R>::Params htap_params(const Op& op)
+{
+    typename StHTap<R>::Params p;
+    for (int i = 0; i <= R; ++i) p.w[i] = op.w[i];
+    return p;
+}
+template <int R> static typename StVTap<R>::Params vtap_params(const Op& op)
+{
+    typename StVTap<R>::Params p;
+    for (int i = 0; i <= R; ++i) p.w[i] = op.w[i];
+    return p;
+}
+static StGrade::Params grade_params(const Op& op) { return {op.slope, op.offset, op.saturation}; }
+static StCross3::Params cross_params(const Op& op) { return {op.wc, op.ws}; }
+
+constexpr int PF_DEFAULT = 4;
+
+template <class Px> static hipError_t run_passthrough(Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<StNodeEnd> P;
+    return launch_stream<Px, PF_DEFAULT, StNodeEnd>(s, d, g, t, st, P, 0);
+}
+
+template <class Px, int R> static hipError_t run_gauss(const Op& op, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<StHTap<R>, StVTap<R>> P;
+    P.p = htap_params<R>(op);
+    P.rest.p = vtap_params<R>(op);
+    return launch_stream<Px, (R <= 4 ? PF_DEFAULT : 2), StHTap<R>, StVTap<R>>(s, d, g, t, st, P, R);
+}
+
+template <class Px, int R = 0>
+static hipError_t run_gauss_any(const Op& op, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    if constexpr (R > kMaxRadius) {
+        return hipErrorInvalidValue;
+    } else {
+        if (op.radius == R) return run_gauss<Px, R>(op, s, d, g, t, st);
+        return run_gauss_any<Px, R + 1>(op, s, d, g, t, st);
+    }
+}
+
+template <class Px> static hipError_t run_grade(const Op& op, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<StGrade> P;
+    P.p = grade_params(op);
+    return launch_stream<Px, PF_DEFAULT, StGrade>(s, d, g, t, st, P, 0);
+}
+
+template <class Px> static hipError_t run_sharpen(const Op& op, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<StCross3> P;
+    P.p = cross_params(op);
+    return launch_stream<Px, PF_DEFAULT, StCross3>(s, d, g, t, st, P, 1);
+}
+
+// ---- fused catalogue ------------------------------------------------------------
+// gaussian(R) -> grade
+template <class Px, int R> static hipError_t run_gauss_grade(const Op* o, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<StHTap<R>, StVTap<R>, StNodeEnd, StGrade> P;
+    P.p = htap_params<R>(o[0]);
+    P.rest.p = vtap_params<R>(o[0]);
+    P.rest.rest.rest.p = grade_params(o[1]);
+    return launch_stream<Px, PF_DEFAULT, StHTap<R>, StVTap<R>, StNodeEnd, StGrade>(s, d, g, t, st, P, R);
+}
+// grade -> sharpen
+template <class Px> static hipError_t run_grade_sharpen(const Op* o, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<StGrade, StNodeEnd, StCross3> P;
+    P.p = grade_params(o[0]);
+    P.rest.rest.p = cross_params(o[1]);
+    return launch_stream<Px, PF_DEFAULT, StGrade, StNodeEnd, StCross3>(s, d, g, t, st, P, 1);
+}
+// gaussian(R) -> grade -> sharpen
+template <class Px, int R> static hipError_t run_gauss_grade_sharpen(const Op* o, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<StHTap<R>, StVTap<R>, StNodeEnd, StGrade, StNodeEnd, StCross3> P;
+    P.p = htap_params<R>(o[0]);
+    P.rest.p = vtap_params<R>(o[0]);
+    P.rest.rest.rest.p = grade_params(o[1]);
+    P.rest.rest.rest.rest.rest.p = cross_params(o[2]);
+    return launch_stream<Px, PF_DEFAULT, StHTap<R>, StVTap<R>, StNodeEnd, StGrade, StNodeEnd, StCross3>(s, d, g, t, st, P, R + 1);
+}
+
+static bool is_gauss(const Op& o, int r) { return o.kind == OP_GAUSSIAN && o.radius == r; }
+
+// index of the fused pattern matching ops[0..n), -1 if none
+static int fused_pattern(const Op* o, int n)
+{
+    if (n == 2 && is_gauss(o[0], 2) && o[1].kind == OP_GRADE) return 0;
+    if (n == 2 && is_gauss(o[0], 4) && o[1].kind == OP_GRADE) return 1;
+    if (n == 2 && o[0].kind == OP_GRADE && o[1].kind == OP_SHARPEN) return 2;
+    if (n == 3 && is_gauss(o[0], 2) && o[1].kind == OP_GRADE && o[2].kind == OP_SHARPEN) return 3;
+    if (n == 3 && is_gauss(o[0], 4) && o[1].kind == OP_GRADE && o[2].kind == OP_SHARPEN) return 4;
+    return -1;
+}
+
+bool stream_supported(const Op* ops, int n)
+{
+    if (n <= 0 || n > kMaxFusedOps) return false;
+    if (n == 1) return true;
+    return fused_pattern(ops, n) >= 0;
+}
+
+int ops_radius(const Op* ops, int n)
+{
+    int r = 0;
+    for (int i = 0; i < n; ++i) {
+        switch (ops[i].kind) {
+            case OP_GAUSSIAN: r += ops[i].radius; break;
+            case OP_SHARPEN: r += 1; break;
+            case OP_CONV2D: r += ops[i].radius; break;
+            default: break;
+        }
+    }
+    return r;
+}
+
+template <class Px>
+static hipError_t launch_ops_px(const Op* ops, int n, Image src, Image dst, const Geom& g, const StreamTuning& tune,
+                                hipStream_t stream)
+{
+    if (n == 1) {
+        const Op& op = ops[0];
+        switch (op.kind) {
+            case OP_PASSTHROUGH: return run_passthrough<Px>(src, dst, g, tune, stream);
+            case OP_GAUSSIAN:
+                if (op.radius < 0 || op.radius > kMaxRadius) return hipErrorInvalidValue;
+                return run_gauss_any<Px>(op, src, dst, g, tune, stream);
+            case OP_GRADE: return run_grade<Px>(op, src, dst, g, tune, stream);
+            case OP_SHARPEN: return run_sharpen<Px>(op, src, dst, g, tune, stream);
+            case OP_CONV2D: return launch_conv2d(Px::QUANT ? kFmtRGBA8 : kFmtRGBA32F, op, src, dst, g, tune, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    switch (fused_pattern(ops, n)) {
+        case 0: return run_gauss_grade<Px, 2>(ops, src, dst, g, tune, stream);
+        case 1: return run_gauss_grade<Px, 4>(ops, src, dst, g, tune, stream);
+        case 2: return run_grade_sharpen<Px>(ops, src, dst, g, tune, stream);
+        case 3: return run_gauss_grade_sharpen<Px, 2>(ops, src, dst, g, tune, stream);
+        case 4: return run_gauss_grade_sharpen<Px, 4>(ops, src, dst, g, tune, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_ops(int fmt, const Op* ops, int n, Image src, Image dst, const Geom& g, const StreamTuning& tune,
+                      hipStream_t stream)
+{
+    if (fmt == kFmtRGBA8) return launch_ops_px<PxU8>(ops, n, src, dst, g, tune, stream);
+    if (fmt == kFmtRGBA32F) return launch_ops_px<PxF32>(ops, n, src, dst, g, tune, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace rf
