@@ -202,7 +202,14 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events on the launch's own stream -------------
     rows = g.rows
-    per_launch = g.time_launches(min(args.steps, 100))
+    # One launch per frame: two events around a run of back-to-back frames on the launch's
+    # stream (an event pair around EVERY launch would put a marker packet between kernels and
+    # inflate each by ~2 us).  Several launches per frame: a pair per launch, to tell them apart.
+    n_ev = max(20, min(args.steps * fps, 400))
+    if len(launches) == 1:
+        per_launch = [(launches[0]["label"], g.time_frames(n_ev) / n_ev)]
+    else:
+        per_launch = g.time_launches(min(n_ev, 100))
     dom = max(range(len(per_launch)), key=lambda i: per_launch[i][1])
     dom_label, dom_ms = per_launch[dom]
     if args.workload == "conv31_8k":

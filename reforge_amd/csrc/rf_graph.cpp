@@ -435,8 +435,8 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
             f.join.push_back(e);
         }
         HIP_TRY(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(f.done, f.stream));   // fences are created SIGNALED (frame.rs:47)
+        // the frame fence (Frame.fence, frame.rs:47, created SIGNALED) is the slot's stream itself:
+        // an idle stream synchronises immediately
         if (timers) {
             for (size_t k = 0; k < g->launches.size(); ++k) {
                 hipEvent_t a, b;
@@ -484,7 +484,6 @@ extern "C" void rf_graph_destroy(rf_graph* g)
         for (auto e : f.t1) (void)hipEventDestroy(e);
         for (auto e : f.join) (void)hipEventDestroy(e);
         if (f.fork) (void)hipEventDestroy(f.fork);
-        if (f.done) (void)hipEventDestroy(f.done);
         for (auto s : f.aux) (void)hipStreamDestroy(s);
         if (f.stream) (void)hipStreamDestroy(f.stream);
     }
@@ -710,10 +709,9 @@ extern "C" rf_status rf_graph_execute(rf_graph* g, int frame_slot)
     FrameSlot* f;
     rf_status st = slot_of(g, frame_slot, &f, "rf_graph_execute");
     if (st != RF_OK) return st;
-    st = submit_frame(g, *f);
-    if (st != RF_OK) return st;
-    HIP_TRY(hipEventRecord(f->done, f->stream));
-    return RF_OK;
+    // the fence of this slot is the slot's own stream (every side stream joins it before the
+    // frame ends): no event packet between consecutive frames
+    return submit_frame(g, *f);
 }
 
 extern "C" rf_status rf_graph_wait(rf_graph* g, int frame_slot)
@@ -721,7 +719,7 @@ extern "C" rf_status rf_graph_wait(rf_graph* g, int frame_slot)
     FrameSlot* f;
     rf_status st = slot_of(g, frame_slot, &f, "rf_graph_wait");
     if (st != RF_OK) return st;
-    HIP_TRY(hipEventSynchronize(f->done));
+    HIP_TRY(hipStreamSynchronize(f->stream));
     return RF_OK;
 }
 
@@ -790,7 +788,7 @@ extern "C" rf_status rf_graph_node_times(rf_graph* g, int frame_slot, const char
     const int cap = *n;
     *n = 0;
     if (!f->timed_once) return RF_OK;   // no frame recorded yet (current_query_index == 0, vkutils.rs:107-109)
-    HIP_TRY(hipEventSynchronize(f->done));
+    HIP_TRY(hipStreamSynchronize(f->stream));
     std::vector<std::pair<std::string, float>> rows;
     for (size_t k = 0; k < g->launches.size(); ++k) {
         float t = 0.f;
@@ -844,7 +842,6 @@ extern "C" rf_status rf_graph_time_frames(rf_graph* g, int iters, float* total_m
             if (s2 != RF_OK) return s2;
         }
         HIP_TRY(hipEventRecord(e1, f->stream));
-        HIP_TRY(hipEventRecord(f->done, f->stream));
         HIP_TRY(hipEventSynchronize(e1));
         HIP_TRY(hipEventElapsedTime(total_ms, e0, e1));
         return RF_OK;
@@ -913,8 +910,7 @@ extern "C" rf_status rf_graph_time_launches(rf_graph* g, int iters, float* avg_m
             rf_status s2 = issue_frame(g, *f, true);
             if (s2 != RF_OK) return s2;
         }
-        HIP_TRY(hipEventRecord(f->done, f->stream));
-        HIP_TRY(hipEventSynchronize(f->done));
+        HIP_TRY(hipStreamSynchronize(f->stream));
         for (size_t k = 0; k < nl; ++k) {
             double sum = 0.0;
             for (int it = 0; it < iters; ++it) {

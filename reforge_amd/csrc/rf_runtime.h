@@ -74,7 +74,7 @@ struct FrameSlot {
     std::vector<hipStream_t> aux;            // side streams for multi-node layers
     hipEvent_t fork = nullptr;
     std::vector<hipEvent_t> join;
-    hipEvent_t done = nullptr;               // Frame.fence (frame.rs:47)
+
     std::vector<hipEvent_t> t0, t1;          // GpuTimer query pairs, one per launch
     bool timed_once = false;
     hipGraphExec_t graph_exec = nullptr;
