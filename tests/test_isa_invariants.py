@@ -1,0 +1,112 @@
+"""CPU: invariants of the generated gfx950 code that the stream kernel's correctness rests on.
+
+The kernel waits for its LDS-DMA rows with a COUNTED `s_waitcnt vmcnt(N)` (rf_stream.hip,
+Source::wait_row): that is only right if, per row, a wave issues exactly one vector-memory load
+(the DMA) and one vector-memory store, in a fixed order.  hipcc cross-compiles without a GPU,
+so the assembly is checked here: every steady loop of every stream_kernel instantiation has
+exactly one `global_load_lds_*`, exactly one `global_store_*`, no other vector-memory
+instruction, and the kernels use no scratch and no workgroup barrier."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "reforge_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def stream_asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "rf_stream.s"
+    subprocess.check_call([HIPCC, "-S", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                           "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(CSRC, "rf_stream.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    return out.read_text().split("\n")
+
+
+def kernels(lines):
+    """name -> list of instruction lines (labels kept) for every stream_kernel function"""
+    out, name, body = {}, None, []
+    for l in lines:
+        m = re.match(r"^(_ZN2rf13stream_kernel\w+):", l)
+        if m:
+            name, body = m.group(1), []
+            continue
+        if name is not None:
+            body.append(l)
+            if "s_endpgm" in l:
+                out[name] = body
+                name = None
+    return out
+
+
+def prefetch_depth(name):
+    return int(re.search(r"stream_kernelINS_\w+?ELi(\d+)E", name).group(1))
+
+
+def steady_loops(body, pf=4):
+    """instruction lists of the loops whose wait is the steady counted form vmcnt(2*PF-2)"""
+    steady, warm = "vmcnt(%d)" % (2 * pf - 2), "vmcnt(%d)" % (pf - 1)
+    spans = []                                # (header line, last back-branch line) of every loop
+    for h, l in enumerate(body):
+        if not re.match(r"^\.LBB\d+_\d+:.*Loop Header", l):
+            continue
+        label = l.split(":")[0]
+        back = [k for k in range(h, len(body)) if re.search(r"s_c?branch\w*\s+" + re.escape(label) + r"\b", body[k])]
+        if back:
+            spans.append((h, back[-1]))
+    loops = []
+    for i, l in enumerate(body):
+        if "s_waitcnt " + steady not in l:
+            continue
+        inside = [(h, e) for h, e in spans if h < i <= e]
+        if not inside:
+            continue
+        h, e = max(inside)                    # innermost enclosing loop
+        text = "\n".join(body[h:e + 1])
+        if warm in text or "vmcnt(0)" in text:
+            continue                          # the generic (priming / tail) loop carries all three waits
+        loops.append([x.strip() for x in body[h + 1:e + 1] if x.strip() and not x.strip().startswith((";", "."))])
+    return loops
+
+
+def test_stream_kernels_keep_the_counted_wait_contract(stream_asm):
+    ks = kernels(stream_asm)
+    assert len(ks) >= 40                      # every node type / fused pattern / format / prefetch depth
+    checked = 0
+    for name, body in ks.items():
+        text = "\n".join(body)
+        assert "s_barrier" not in text, name                    # wave-autonomous: no workgroup barrier
+        assert "scratch_" not in text, name                     # no spills
+        assert re.search(r"global_load_lds_dword(x4)?\b", text), name
+        assert not re.search(r"\bglobal_load_dword", text.replace("global_load_lds_dword", "")), name   # the DMA is the only load
+        pf = prefetch_depth(name)
+        for loop in steady_loops(body, pf):
+            ops = [x.split()[0] for x in loop]
+            vmem = [o for o in ops if o.startswith(("global_", "buffer_", "flat_"))]
+            assert sorted(vmem) in (["global_load_lds_dword", "global_store_dword"],
+                                    ["global_load_lds_dwordx4", "global_store_dwordx4"]), (name, vmem)
+            # program order inside an iteration: DMA issue, then the counted wait, then the store
+            i_dma = next(k for k, o in enumerate(ops) if o.startswith("global_load_lds"))
+            i_wait = next(k for k, x in enumerate(loop) if "vmcnt(%d)" % (2 * pf - 2) in x)
+            i_store = next(k for k, o in enumerate(ops) if o.startswith("global_store"))
+            assert i_dma < i_wait < i_store, name
+            checked += 1
+    assert checked >= len(ks)                 # at least one steady loop each (two when the pipeline has a halo)
+
+
+def test_fused_chain_steady_loop_is_lean(stream_asm):
+    """The 3-stage rgba32f chain: all 68 fmaf per row are packed (v_pk_fma_f32), and the loop
+    stays near 110 instructions (it was ~250 before the steady-state split)."""
+    ks = kernels(stream_asm)
+    name = [n for n in ks if "PxF32ELi4E" in n and "StHTapILi2E" in n and "StCross3" in n and "StGrade" in n]
+    assert len(name) == 1
+    loops = steady_loops(ks[name[0]])
+    assert len(loops) == 2                    # top-down and bottom-up walks
+    for loop in loops:
+        ops = [x.split()[0] for x in loop]
+        assert ops.count("v_pk_fma_f32") >= 30
+        assert len(ops) <= 130, len(ops)
