@@ -138,17 +138,12 @@ rf_status exchange_rows(rf_graph* g, const DeviceImage& img, int r, hipStream_t 
 
 bool exchange_mode(const rf_graph* g) { return g->ctx->world > 1 && !(g->opt.flags & RF_GRAPH_NO_HALO_XCHG); }
 
-rf_status run_launch(rf_graph* g, FrameSlot& f, size_t li, hipStream_t stream, bool timers)
+// the kernel(s) of one launch over output rows [y0, y1) of `geo`
+rf_status launch_rows(rf_graph* g, FrameSlot& f, const Launch& L, Geom geo, int y0, int y1, hipStream_t stream)
 {
-    const Launch& L = g->launches[li];
-    if (exchange_mode(g) && L.radius > 0) {
-        for (const auto& s : L.src) {
-            rf_status st = exchange_rows(g, f.images.at(s), L.radius, stream);
-            if (st != RF_OK) return st;
-        }
-    }
-    if (timers) HIP_TRY(hipEventRecord(f.t0[li], stream));
-    const Geom geo = launch_geom(g, L);
+    if (y1 <= y0) return RF_OK;
+    geo.y0 = y0;
+    geo.y1 = y1;
     const DeviceImage& dst = f.images.at(L.dst);
     if (L.ops.size() == 1 && L.ops[0].kind == OP_MIX) {
         HIP_TRY(launch_mix(g->opt.format, f.images.at(L.src[0]).view(), f.images.at(L.src[1]).view(), dst.view(), geo,
@@ -156,6 +151,50 @@ rf_status run_launch(rf_graph* g, FrameSlot& f, size_t li, hipStream_t stream, b
     } else {
         HIP_TRY(launch_ops(g->opt.format, L.ops.data(), (int)L.ops.size(), f.images.at(L.src[0]).view(), dst.view(), geo,
                            g->tune, stream));
+    }
+    return RF_OK;
+}
+
+// One launch of the frame.  In exchange mode a stencil launch is split so that the halo flies
+// while the interior computes: the rows that read no ghost row start at once on
+// the launch's stream, the neighbour exchange runs on the slot's comm stream behind an event,
+// and the r top + r bottom rows follow once the ghost rows have landed.  RF_FORCE_SPLIT=1
+// takes the same three-part path on a single rank (no exchange) so the geometry is testable
+// on one GPU.
+rf_status run_launch(rf_graph* g, FrameSlot& f, size_t li, hipStream_t stream, bool timers)
+{
+    const Launch& L = g->launches[li];
+    const Geom geo = launch_geom(g, L);
+    const bool xchg = exchange_mode(g) && L.radius > 0;
+    const int r = L.radius;
+    const bool split = (xchg || (g->force_split && r > 0)) && (geo.y1 - geo.y0) > 4 * r;
+    if (timers) HIP_TRY(hipEventRecord(f.t0[li], stream));
+    if (!split) {
+        if (xchg) {
+            for (const auto& s : L.src) {
+                rf_status st = exchange_rows(g, f.images.at(s), r, stream);
+                if (st != RF_OK) return st;
+            }
+        }
+        rf_status st = launch_rows(g, f, L, geo, geo.y0, geo.y1, stream);
+        if (st != RF_OK) return st;
+    } else {
+        if (xchg) {
+            HIP_TRY(hipEventRecord(f.src_ready, stream));            // everything that wrote src is ordered before this
+            HIP_TRY(hipStreamWaitEvent(f.comm, f.src_ready, 0));
+            for (const auto& s : L.src) {
+                rf_status st = exchange_rows(g, f.images.at(s), r, f.comm);
+                if (st != RF_OK) return st;
+            }
+            HIP_TRY(hipEventRecord(f.halo_ready, f.comm));
+        }
+        rf_status st = launch_rows(g, f, L, geo, geo.y0 + r, geo.y1 - r, stream);   // reads rows [y0, y1): no ghost row
+        if (st != RF_OK) return st;
+        if (xchg) HIP_TRY(hipStreamWaitEvent(stream, f.halo_ready, 0));
+        st = launch_rows(g, f, L, geo, geo.y0, geo.y0 + r, stream);
+        if (st != RF_OK) return st;
+        st = launch_rows(g, f, L, geo, geo.y1 - r, geo.y1, stream);
+        if (st != RF_OK) return st;
     }
     if (timers) HIP_TRY(hipEventRecord(f.t1[li], stream));
     return RF_OK;
@@ -405,6 +444,7 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
     if (const char* e = std::getenv("RF_ROWS_PER_CHUNK")) g->tune.rows_per_chunk = std::atoi(e);
     if (const char* e = std::getenv("RF_PREFETCH_ROWS")) g->tune.prefetch_rows = std::atoi(e);
     if (const char* e = std::getenv("RF_CONV_PATH")) g->tune.conv_path = std::atoi(e);
+    if (const char* e = std::getenv("RF_FORCE_SPLIT")) g->force_split = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_NO_ALTERNATE")) g->tune.no_alternate = std::atoi(e);
 
     // per-frame images, streams, events (PipelineGraphFrame::new, Frame::new)
@@ -435,6 +475,11 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
             f.join.push_back(e);
         }
         HIP_TRY(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
+        if (exchange_mode(g) || g->force_split) {
+            HIP_TRY(hipStreamCreateWithFlags(&f.comm, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&f.src_ready, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&f.halo_ready, hipEventDisableTiming));
+        }
         // the frame fence (Frame.fence, frame.rs:47, created SIGNALED) is the slot's stream itself:
         // an idle stream synchronises immediately
         if (timers) {
@@ -484,6 +529,9 @@ extern "C" void rf_graph_destroy(rf_graph* g)
         for (auto e : f.t1) (void)hipEventDestroy(e);
         for (auto e : f.join) (void)hipEventDestroy(e);
         if (f.fork) (void)hipEventDestroy(f.fork);
+        if (f.src_ready) (void)hipEventDestroy(f.src_ready);
+        if (f.halo_ready) (void)hipEventDestroy(f.halo_ready);
+        if (f.comm) (void)hipStreamDestroy(f.comm);
         for (auto s : f.aux) (void)hipStreamDestroy(s);
         if (f.stream) (void)hipStreamDestroy(f.stream);
     }

@@ -74,6 +74,8 @@ struct FrameSlot {
     std::vector<hipStream_t> aux;            // side streams for multi-node layers
     hipEvent_t fork = nullptr;
     std::vector<hipEvent_t> join;
+    hipStream_t comm = nullptr;              // halo exchange runs here while interior rows compute
+    hipEvent_t src_ready = nullptr, halo_ready = nullptr;
 
     std::vector<hipEvent_t> t0, t1;          // GpuTimer query pairs, one per launch
     bool timed_once = false;
@@ -96,6 +98,7 @@ struct rf_graph {
     std::string output_image;          // allocated name rf:final-output resolves to
     int need_input = 0;                // ghost rows of the input the frame reads
     rf::StreamTuning tune;
+    bool force_split = false;          // RF_FORCE_SPLIT=1: interior/boundary split without an exchange (tests)
     uint8_t* d_staging = nullptr;      // RGBA8 staging rows (render.rs:552-564)
     size_t staging_bytes = 0;
     std::vector<std::string> time_names;   // scratch for rf_graph_node_times

@@ -342,6 +342,19 @@ def test_row_strips_overfetch_on_one_gpu(text, world, flags):
         util.assert_same(np.concatenate(strips, axis=0), want, "world=%d flags=%d fmt=%d" % (world, flags, fmt))
 
 
+def test_interior_boundary_split(ctx, monkeypatch):
+    """Exchange mode overlaps the halo exchange with the interior rows by issuing a stencil
+    launch in three parts (interior, top r rows, bottom r rows).  RF_FORCE_SPLIT=1 takes that
+    path on one rank without the exchange: the three parts must tile the frame exactly."""
+    monkeypatch.setenv("RF_FORCE_SPLIT", "1")
+    for fmt in (util.F32, util.U8):
+        x = util.synthetic(211, 157, fmt, seed=5)
+        for text in (util.CHAIN3, util.CHAIN5, util.DIAMOND, NODES["gaussian_r7"], NODES["conv9"]):
+            want = util.run_oracle(text, x)
+            for flags in (0, NF, rf.RF_GRAPH_TIMERS):
+                util.assert_same(util.run_hip(ctx, text, x, flags=flags), want, "split flags=%d" % flags)
+
+
 def test_exchange_mode_needs_a_communicator():
     c = rf.Context(0, 0, 2, None)
     with pytest.raises(rf.RfError) as e:
