@@ -442,7 +442,6 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
                                             " is smaller than the halo " + std::to_string(g->ghost));
 
     if (const char* e = std::getenv("RF_ROWS_PER_CHUNK")) g->tune.rows_per_chunk = std::atoi(e);
-    if (const char* e = std::getenv("RF_PREFETCH_ROWS")) g->tune.prefetch_rows = std::atoi(e);
     if (const char* e = std::getenv("RF_CONV_PATH")) g->tune.conv_path = std::atoi(e);
     if (const char* e = std::getenv("RF_FORCE_SPLIT")) g->force_split = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_NO_ALTERNATE")) g->tune.no_alternate = std::atoi(e);

@@ -59,7 +59,6 @@ struct Geom {
 // Tuning knobs (0 = heuristic).  Read once from the environment by rf_graph.
 struct StreamTuning {
     int rows_per_chunk = 0;   // RF_ROWS_PER_CHUNK
-    int prefetch_rows = 0;    // RF_PREFETCH_ROWS: 0 = the kernel's default (4), 8 = deeper ring
     int no_alternate = 0;     // RF_NO_ALTERNATE=1: every chunk walks top-down
     int conv_path = 0;        // RF_CONV_PATH: 0 = by kernel size (MFMA from 9x9), 1 = LDS-tile VALU, 2 = MFMA
 };

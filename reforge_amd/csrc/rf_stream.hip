@@ -585,14 +585,6 @@ static hipError_t launch_stream(Image src, Image dst, const Geom& g, const Strea
     A.n_work = ((A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock) * ((rows + A.rows_per_chunk - 1) / A.rows_per_chunk);
     A.alternate = tune.no_alternate ? 0 : 1;
     dim3 grid((unsigned)((A.n_work + 7) / 8 * 8));   // 1-D, a multiple of the 8 XCDs (see the kernel's block order)
-    // prefetch depth: the template argument is the default; RF_PREFETCH_ROWS=8 selects the
-    // deeper ring where it is instantiated (radius <= 4)
-    if constexpr (PF == 4) {
-        if (tune.prefetch_rows == 8) {
-            hipLaunchKernelGGL((stream_kernel<Px, 8, S...>), grid, dim3(64 * kWavesPerBlock), 0, stream, A);
-            return hipGetLastError();
-        }
-    }
     hipLaunchKernelGGL((stream_kernel<Px, PF, S...>), grid, dim3(64 * kWavesPerBlock), 0, stream, A);
     return hipGetLastError();
 }
@@ -654,53 +646,109 @@ template <class Px> static hipError_t run_sharpen(const Op& op, Image s, Image d
     return launch_stream<Px, PF_DEFAULT, StCross3>(s, d, g, t, st, P, 1);
 }
 
-// ---- fused catalogue ------------------------------------------------------------
-// gaussian(R) -> grade
-template <class Px, int R> static hipError_t run_gauss_grade(const Op* o, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
-{
-    ParamPack<StHTap<R>, StVTap<R>, StNodeEnd, StGrade> P;
-    P.p = htap_params<R>(o[0]);
-    P.rest.p = vtap_params<R>(o[0]);
-    P.rest.rest.rest.p = grade_params(o[1]);
-    return launch_stream<Px, PF_DEFAULT, StHTap<R>, StVTap<R>, StNodeEnd, StGrade>(s, d, g, t, st, P, R);
-}
-// grade -> sharpen
-template <class Px> static hipError_t run_grade_sharpen(const Op* o, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
-{
-    ParamPack<StGrade, StNodeEnd, StCross3> P;
-    P.p = grade_params(o[0]);
-    P.rest.rest.p = cross_params(o[1]);
-    return launch_stream<Px, PF_DEFAULT, StGrade, StNodeEnd, StCross3>(s, d, g, t, st, P, 1);
-}
-// gaussian(R) -> grade -> sharpen
-template <class Px, int R> static hipError_t run_gauss_grade_sharpen(const Op* o, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
-{
-    ParamPack<StHTap<R>, StVTap<R>, StNodeEnd, StGrade, StNodeEnd, StCross3> P;
-    P.p = htap_params<R>(o[0]);
-    P.rest.p = vtap_params<R>(o[0]);
-    P.rest.rest.rest.p = grade_params(o[1]);
-    P.rest.rest.rest.rest.rest.p = cross_params(o[2]);
-    return launch_stream<Px, PF_DEFAULT, StHTap<R>, StVTap<R>, StNodeEnd, StGrade, StNodeEnd, StCross3>(s, d, g, t, st, P, R + 1);
-}
+// ---- fused chains -----------------------------------------------------------------
+// A fused launch is the concatenation of its nodes' stage lists with a StNodeEnd between
+// nodes.  Fusable node kinds: gaussian5 (G2), gaussian9 (G4), colour grade, sharpen.  Every
+// pair of them is instantiated, plus the triple gaussian -> grade -> sharpen of the BASELINE
+// chains; anything else runs one launch per node.
+template <class... S> struct TL {};
+template <class A, class B> struct Concat;
+template <class... A, class... B> struct Concat<TL<A...>, TL<B...>> { typedef TL<A..., B...> type; };
+template <class A, class B> struct Join { typedef typename Concat<typename Concat<A, TL<StNodeEnd>>::type, B>::type type; };
 
-static bool is_gauss(const Op& o, int r) { return o.kind == OP_GAUSSIAN && o.radius == r; }
+template <int CODE> struct NodeTL;
+template <> struct NodeTL<0> { typedef TL<StHTap<2>, StVTap<2>> type; };
+template <> struct NodeTL<1> { typedef TL<StHTap<4>, StVTap<4>> type; };
+template <> struct NodeTL<2> { typedef TL<StGrade> type; };
+template <> struct NodeTL<3> { typedef TL<StCross3> type; };
 
-// index of the fused pattern matching ops[0..n), -1 if none
-static int fused_pattern(const Op* o, int n)
+static int node_code(const Op& o)
 {
-    if (n == 2 && is_gauss(o[0], 2) && o[1].kind == OP_GRADE) return 0;
-    if (n == 2 && is_gauss(o[0], 4) && o[1].kind == OP_GRADE) return 1;
-    if (n == 2 && o[0].kind == OP_GRADE && o[1].kind == OP_SHARPEN) return 2;
-    if (n == 3 && is_gauss(o[0], 2) && o[1].kind == OP_GRADE && o[2].kind == OP_SHARPEN) return 3;
-    if (n == 3 && is_gauss(o[0], 4) && o[1].kind == OP_GRADE && o[2].kind == OP_SHARPEN) return 4;
+    if (o.kind == OP_GAUSSIAN && o.radius == 2) return 0;
+    if (o.kind == OP_GAUSSIAN && o.radius == 4) return 1;
+    if (o.kind == OP_GRADE) return 2;
+    if (o.kind == OP_SHARPEN) return 3;
     return -1;
+}
+
+// parameters of a stage from the op of the node it belongs to
+template <int R> static void set_params(typename StHTap<R>::Params& p, const Op& op) { p = htap_params<R>(op); }
+template <int R> static void set_params(typename StVTap<R>::Params& p, const Op& op) { p = vtap_params<R>(op); }
+static void set_params(StGrade::Params& p, const Op& op) { p = grade_params(op); }
+static void set_params(StCross3::Params& p, const Op& op) { p = cross_params(op); }
+
+static void fill_params(ParamPack<>&, const Op*, int) {}
+template <class... Rest> static void fill_params(ParamPack<StNodeEnd, Rest...>& P, const Op* ops, int i) { fill_params(P.rest, ops, i + 1); }
+template <int R, class... Rest> static void fill_params(ParamPack<StHTap<R>, Rest...>& P, const Op* ops, int i)
+{
+    set_params<R>(P.p, ops[i]);
+    fill_params(P.rest, ops, i);
+}
+template <int R, class... Rest> static void fill_params(ParamPack<StVTap<R>, Rest...>& P, const Op* ops, int i)
+{
+    set_params<R>(P.p, ops[i]);
+    fill_params(P.rest, ops, i);
+}
+template <class... Rest> static void fill_params(ParamPack<StGrade, Rest...>& P, const Op* ops, int i)
+{
+    set_params(P.p, ops[i]);
+    fill_params(P.rest, ops, i);
+}
+template <class... Rest> static void fill_params(ParamPack<StCross3, Rest...>& P, const Op* ops, int i)
+{
+    set_params(P.p, ops[i]);
+    fill_params(P.rest, ops, i);
+}
+
+template <class Px, class... S>
+static hipError_t launch_list(TL<S...>, const Op* ops, int n, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    ParamPack<S...> P;
+    fill_params(P, ops, 0);
+    return launch_stream<Px, PF_DEFAULT, S...>(s, d, g, t, st, P, ops_radius(ops, n));
+}
+
+template <class Px, int C0>
+static hipError_t launch_pair(const Op* o, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    typedef typename NodeTL<C0>::type A;
+    switch (node_code(o[1])) {
+        case 0: return launch_list<Px>(typename Join<A, NodeTL<0>::type>::type{}, o, 2, s, d, g, t, st);
+        case 1: return launch_list<Px>(typename Join<A, NodeTL<1>::type>::type{}, o, 2, s, d, g, t, st);
+        case 2: return launch_list<Px>(typename Join<A, NodeTL<2>::type>::type{}, o, 2, s, d, g, t, st);
+        case 3: return launch_list<Px>(typename Join<A, NodeTL<3>::type>::type{}, o, 2, s, d, g, t, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <class Px>
+static hipError_t launch_fused(const Op* o, int n, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
+{
+    if (n == 2) {
+        switch (node_code(o[0])) {
+            case 0: return launch_pair<Px, 0>(o, s, d, g, t, st);
+            case 1: return launch_pair<Px, 1>(o, s, d, g, t, st);
+            case 2: return launch_pair<Px, 2>(o, s, d, g, t, st);
+            case 3: return launch_pair<Px, 3>(o, s, d, g, t, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (n == 3 && node_code(o[1]) == 2 && node_code(o[2]) == 3) {
+        typedef typename Join<NodeTL<2>::type, NodeTL<3>::type>::type Tail;   // grade -> sharpen
+        if (node_code(o[0]) == 0) return launch_list<Px>(typename Join<NodeTL<0>::type, Tail>::type{}, o, 3, s, d, g, t, st);
+        if (node_code(o[0]) == 1) return launch_list<Px>(typename Join<NodeTL<1>::type, Tail>::type{}, o, 3, s, d, g, t, st);
+    }
+    return hipErrorInvalidValue;
 }
 
 bool stream_supported(const Op* ops, int n)
 {
     if (n <= 0 || n > kMaxFusedOps) return false;
     if (n == 1) return true;
-    return fused_pattern(ops, n) >= 0;
+    for (int i = 0; i < n; ++i)
+        if (node_code(ops[i]) < 0) return false;
+    if (n == 2) return true;
+    return n == 3 && ops[0].kind == OP_GAUSSIAN && node_code(ops[1]) == 2 && node_code(ops[2]) == 3;
 }
 
 int ops_radius(const Op* ops, int n)
@@ -734,14 +782,7 @@ static hipError_t launch_ops_px(const Op* ops, int n, Image src, Image dst, cons
             default: return hipErrorInvalidValue;
         }
     }
-    switch (fused_pattern(ops, n)) {
-        case 0: return run_gauss_grade<Px, 2>(ops, src, dst, g, tune, stream);
-        case 1: return run_gauss_grade<Px, 4>(ops, src, dst, g, tune, stream);
-        case 2: return run_grade_sharpen<Px>(ops, src, dst, g, tune, stream);
-        case 3: return run_gauss_grade_sharpen<Px, 2>(ops, src, dst, g, tune, stream);
-        case 4: return run_gauss_grade_sharpen<Px, 4>(ops, src, dst, g, tune, stream);
-        default: return hipErrorInvalidValue;
-    }
+    return launch_fused<Px>(ops, n, src, dst, g, tune, stream);
 }
 
 hipError_t launch_ops(int fmt, const Op* ops, int n, Image src, Image dst, const Geom& g, const StreamTuning& tune,

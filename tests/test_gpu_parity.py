@@ -119,6 +119,26 @@ def test_node_parity_ragged_sizes(ctx, name, fmt):
         util.assert_same(util.run_hip(ctx, NODES[name], x, flags=NF), want, "%s %dx%d unfused" % (name, W, H))
 
 
+PAIR_TYPES = {
+    "g5": ("gaussian5", "{ sigma: 1.1 }"), "g9": ("gaussian9", "{ sigma: 2.2 }"),
+    "gr": ("colour_grade", "{ slope: 0.9, offset: 0.04, saturation: 1.4 }"), "sh": ("sharpen", "{ amount: 0.7 }"),
+}
+
+
+@pytest.mark.parametrize("first", sorted(PAIR_TYPES))
+@pytest.mark.parametrize("second", sorted(PAIR_TYPES))
+def test_every_fused_pair(ctx, first, second):
+    """Every pair of fusable node kinds runs as ONE launch and equals node-at-a-time execution
+    and the oracle, for both formats, across chunk seams (both walk directions)."""
+    text = "input -> n1 -> n2 -> output\nn1: %s %s\nn2: %s %s" % (PAIR_TYPES[first] + PAIR_TYPES[second])
+    assert rf.Plan(rf.Config(text), 0).launches() == ["n1+n2"]
+    for fmt in (util.F32, util.U8):
+        x = util.synthetic(157, 83, fmt, seed=31)
+        want = util.run_oracle(text, x)
+        util.assert_same(util.run_hip(ctx, text, x, rows_per_chunk=11), want, "%s+%s fused" % (first, second))
+        util.assert_same(util.run_hip(ctx, text, x, flags=NF), want, "%s+%s unfused" % (first, second))
+
+
 @pytest.mark.parametrize("rows_per_chunk", [1, 2, 3, 7, 16, 1000])
 @pytest.mark.parametrize("name", ["gaussian9", "chain3", "chain5", "sharpen"])
 def test_chunk_seams(ctx, name, rows_per_chunk):
