@@ -374,9 +374,14 @@ template <class Px, bool REV, int LdsIdx, class S, class... Rest> struct Chain<P
     }
     // first stage: the row comes from the source feed; once it is consumed its ring slot is
     // refilled and the NEXT row's values are fetched into registers
-    template <bool STEADY, class Feed, class Src>
+    // MODE 0: generic (schedule tests).  Modes 1-3 are branch-free: every stage takes a real row
+    // and emits one.  1 = rows still being issued, stores of the last PF iterations not all
+    // there yet (wait on the loads alone); 2 = the steady state; 3 = every row issued already
+    // (the last PF source rows): nothing to issue, plain wait.
+    template <int MODE, class Feed, class Src>
     RF_DEV void step_first(bool has0, Feed& feed, const Src& src, int it, const Lane& L, Sink& k, const ParamPack<S, Rest...>& P)
     {
+        constexpr bool STEADY = MODE != 0;
         bool has = false;
         f4 out = f4_zero();
         if constexpr (STEADY) {
@@ -386,9 +391,17 @@ template <class Px, bool REV, int LdsIdx, class S, class... Rest> struct Chain<P
                 out = S::from_taps(P.p, feed);
             cnt += 1;
             has = true;
-            src.issue(it + Src::SLOTS);
-            wait_vmcnt<2 * Src::SLOTS - 2>();
-            feed.fetch(src, it + 1, L);
+            if constexpr (MODE == 3) {
+                if (it + 1 < src.n0) {
+                    wait_vmcnt<0>();
+                    feed.fetch(src, it + 1, L);
+                }
+            } else {
+                src.issue(it + Src::SLOTS);
+                if constexpr (MODE == 1) wait_vmcnt<Src::SLOTS - 1>();
+                else wait_vmcnt<2 * Src::SLOTS - 2>();
+                feed.fetch(src, it + 1, L);
+            }
         } else {
             if constexpr (S::RV == 0) {
                 if (has0) {
@@ -474,18 +487,24 @@ RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane& L, int wave, char
     src.wait_row(0, k);
     feed.fetch(src, 0, L);
 
-    // Three phases: a generic loop while the pipeline primes, a branch-free STEADY loop while
-    // every stage takes a real row and emits one (and the counted waits are in their steady
-    // form: the PF-1 previous iterations all stored, the next PF rows all exist), and the
-    // generic loop again for the tail and the bottom-edge flush.
+    // Phases: the generic loop (per-stage schedule tests) until the pipeline has emitted its
+    // first row -- from then on every stage takes a real row and emits one for as long as
+    // source rows arrive, and the branch-free modes run: 1 while the stores of the last PF
+    // iterations are not all there yet, 2 the steady state, 3 the last PF source rows (nothing
+    // left to issue) -- and the generic loop again for the bottom-edge flush.
     int it = 0;
-    while (it < total && !(k.first_store >= 0 && it + 1 - PF >= k.first_store)) {
-        chain.template step_first<false>(it < src.n0, feed, src, it, L, k, A.params);
+    while (it < total && k.first_store < 0) {
+        chain.template step_first<0>(it < src.n0, feed, src, it, L, k, A.params);
         ++it;
     }
-    const int steady_end = src.n0 - PF;
-    for (; it < steady_end; ++it) chain.template step_first<true>(true, feed, src, it, L, k, A.params);
-    for (; it < total; ++it) chain.template step_first<false>(it < src.n0, feed, src, it, L, k, A.params);
+    if (k.first_store >= 0) {
+        const int steady_end = src.n0 - PF;                      // iterations with a row left to issue
+        const int warm_end = min(k.first_store + PF, steady_end);
+        for (; it < warm_end; ++it) chain.template step_first<1>(true, feed, src, it, L, k, A.params);
+        for (; it < steady_end; ++it) chain.template step_first<2>(true, feed, src, it, L, k, A.params);
+        for (; it < src.n0; ++it) chain.template step_first<3>(true, feed, src, it, L, k, A.params);
+    }
+    for (; it < total; ++it) chain.template step_first<0>(it < src.n0, feed, src, it, L, k, A.params);
 }
 
 template <class Px, int PF, class... S>
