@@ -89,11 +89,14 @@ def cpu_baseline(text, W, H, seed, budget_s=12.0):
     all_v, all_reps = leg(cores, rows)
     one_v, one_reps = leg(1, min(rows, 540))
     pixel.set_threads(1)
+    import ctypes.util
+    vk = ctypes.util.find_library("vulkan")     # the reference itself would need a Vulkan loader + lavapipe
     return {
         "value": round(all_v, 2), "unit": "Mpx/s", "cores": cores, "kind": "port",
         "sample": "%d x %d rgba32f frame, whole chain, %d repetitions after one warm-up (oracle/rf_oracle.c, OpenMP over rows)" % (W, rows, all_reps),
         "single_thread_value": round(one_v, 2),
         "single_thread_sample": "%d x %d rows, %d repetitions" % (W, min(rows, 540), one_reps),
+        "lavapipe": "unavailable (no libvulkan on this box)" if vk is None else "libvulkan present (%s), no reference build to drive it" % vk,
     }
 
 

@@ -6,7 +6,8 @@
 // Kept from the reference: the flags of `Args` (main.rs:43-71), the config/shader
 // exclusivity check (main.rs:80-83), get_dim (utils.rs:56-74), the default graph
 // (render.rs:115), single-shader mode (config.rs:77-90), headless = one frame then
-// encode (main.rs:220-224), the status line (main.rs:157).
+// encode (main.rs:220-224), the status line (main.rs:157), and -- with --frames N --watch --
+// the windowed loop's live reload of the config (render.rs:121-165,:497-519; main.rs:139-143).
 // Out of scope: the winit/swapchain window (no display on an MI355X box) and the
 // ffmpeg codecs -- images are read as PNG (host/png_io.h), binary PPM (P6) or raw RGBA8 and
 // written as PNG (stored deflate), PPM or raw RGBA8, chosen by file extension.
@@ -18,7 +19,10 @@
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <sys/stat.h>
 
 #include "png_io.h"
 #include "rfhip.h"
@@ -38,6 +42,8 @@ struct Args {   // main.rs:43-71
     long synthetic_seed = -1;
     int frames = 1;
     bool no_fusion = false, hipgraph = false;
+    bool watch = false;         // poll the config's mtime every frame and rebuild the graph when it changes
+    int frame_interval_ms = 0;
 };
 
 void usage()
@@ -59,6 +65,8 @@ void usage()
         "      --no-fusion                    One kernel launch per node, as the reference dispatches\n"
         "      --decode-only                  Decode -i and re-encode to -o without touching the GPU\n"
         "      --hipgraph                     Replay the frame as one hipGraph\n"
+        "      --watch                        With --frames: live-reload the config when its mtime changes, status line per frame\n"
+        "      --frame-interval-ms <MS>       With --frames: sleep between frames\n"
         "  -h, --help                         Print help\n",
         stderr);
 }
@@ -87,6 +95,8 @@ bool parse_args(int argc, char** argv, Args& a)
         else if (s == "--decode-only") a.decode_only = true;
         else if (s == "--no-fusion") a.no_fusion = true;
         else if (s == "--hipgraph") a.hipgraph = true;
+        else if (s == "--watch") a.watch = true;
+        else if (s == "--frame-interval-ms") { if (!val(v)) return false; a.frame_interval_ms = std::atoi(v.c_str()); }
         else if (!s.empty() && s[0] == '-') { warnln("error: unexpected argument '" + s + "'"); return false; }
         else if (a.shader_file_path.empty()) a.shader_file_path = s;
         else { warnln("error: unexpected argument '" + s + "'"); return false; }
@@ -158,6 +168,14 @@ bool write_image(const std::string& path, int w, int h, const uint8_t* rgba)
         return (bool)f;
     }
     return pngio::write_png(path, w, h, rgba);   // the reference always writes PNG (imagefileio.rs:221)
+}
+
+// utils::get_modified_time, utils.rs:33-42: whole seconds, 0 when the file cannot be reached
+uint64_t modified_time(const std::string& path)
+{
+    struct stat st;
+    if (::stat(path.c_str(), &st) != 0) return 0;
+    return (uint64_t)st.st_mtime;
 }
 
 double now_ms()
@@ -232,25 +250,31 @@ int main(int argc, char** argv)
         return write_image(args.output_file, width, height, staging.data()) ? 0 : 1;
     }
 
-    // create_config, render.rs:100-119
-    rf_config* cfg = nullptr;
-    if (!args.config.empty()) {
-        std::ifstream f(args.config);
-        std::stringstream ss;
-        ss << f.rdbuf();
-        if (!f) { warnln("Error reading file '" + args.config + "'"); warnln("Unable to create config"); return 1; }
-        if (ss.str().empty()) { warnln("File was empty: " + args.config); warnln("Unable to create config"); return 1; }
-        if (rf_config_parse(ss.str().c_str(), has_input, &cfg) != RF_OK) { warnln(rf_last_error()); warnln("Unable to create config"); return 1; }
-    } else if (!args.shader_file_path.empty()) {
-        std::string stem = args.shader_file_path;   // config.rs:79: file stem
-        size_t slash = stem.find_last_of('/');
-        if (slash != std::string::npos) stem = stem.substr(slash + 1);
-        size_t dot = stem.find_last_of('.');
-        if (dot != std::string::npos) stem = stem.substr(0, dot);
-        if (rf_config_single(stem.c_str(), has_input, &cfg) != RF_OK) { warnln(rf_last_error()); return 1; }
-    } else {
-        if (rf_config_parse("input -> passthrough -> output", has_input, &cfg) != RF_OK) { warnln(rf_last_error()); return 1; }
-    }
+    // create_config, render.rs:100-119 (nullptr + warning on a user error)
+    auto create_config = [&]() -> rf_config* {
+        rf_config* c = nullptr;
+        if (!args.config.empty()) {
+            std::ifstream f(args.config);
+            std::stringstream ss;
+            ss << f.rdbuf();
+            if (!f) { warnln("Error reading file '" + args.config + "'"); return nullptr; }
+            if (ss.str().empty()) { warnln("File was empty: " + args.config); return nullptr; }
+            if (rf_config_parse(ss.str().c_str(), has_input, &c) != RF_OK) { warnln(rf_last_error()); return nullptr; }
+        } else if (!args.shader_file_path.empty()) {
+            std::string stem = args.shader_file_path;   // config.rs:79: file stem
+            size_t slash = stem.find_last_of('/');
+            if (slash != std::string::npos) stem = stem.substr(slash + 1);
+            size_t dot = stem.find_last_of('.');
+            if (dot != std::string::npos) stem = stem.substr(0, dot);
+            if (rf_config_single(stem.c_str(), has_input, &c) != RF_OK) { warnln(rf_last_error()); return nullptr; }
+        } else if (rf_config_parse("input -> passthrough -> output", has_input, &c) != RF_OK) {
+            warnln(rf_last_error());
+            return nullptr;
+        }
+        return c;
+    };
+    rf_config* cfg = create_config();
+    if (!cfg) { warnln("Unable to create config"); return 1; }   // render.rs:543
 
     rf_ctx* ctx = nullptr;
     RF_CHECK(rf_ctx_create(0, &ctx));
@@ -264,17 +288,78 @@ int main(int argc, char** argv)
     rf_graph* graph = nullptr;
     RF_CHECK(rf_graph_create(ctx, cfg, &opt, &graph));
 
-    // render_fn, main.rs:134-182, headless
-    if (has_file) RF_CHECK(rf_graph_upload_srgb8(graph, staging.data(), (size_t)width * 4));
-    else if (args.synthetic_seed >= 0) RF_CHECK(rf_graph_fill_synthetic(graph, (uint32_t)args.synthetic_seed));
+    // record_initial_image_load (render.rs:264-313), once per graph
+    auto load_input = [&]() -> rf_status {
+        if (has_file) return rf_graph_upload_srgb8(graph, staging.data(), (size_t)width * 4);
+        if (args.synthetic_seed >= 0) return rf_graph_fill_synthetic(graph, (uint32_t)args.synthetic_seed);
+        return RF_OK;
+    };
+    // config_changed + recreate_graph (render.rs:121-165): mtime in whole seconds as
+    // utils.rs:33-42; a config that does not parse or plan keeps the old graph running
+    uint64_t last_mtime = args.config.empty() ? 0 : modified_time(args.config);
+    auto trigger_reloads = [&]() -> bool {
+        if (args.config.empty()) return false;
+        const uint64_t m = modified_time(args.config);
+        if (m == 0) {
+            if (last_mtime != 0) warnln("Unable to access config file: " + args.config);
+            last_mtime = 0;
+            return false;
+        }
+        if (m == last_mtime) return false;
+        last_mtime = m;
+        rf_config* c2 = create_config();
+        if (!c2) return false;
+        (void)rf_graph_wait(graph, 0);
+        rf_graph* g2 = nullptr;
+        if (rf_graph_create(ctx, c2, &opt, &g2) != RF_OK) {
+            warnln(rf_last_error());
+            rf_config_destroy(c2);
+            return false;
+        }
+        rf_graph_destroy(graph);
+        rf_config_destroy(cfg);
+        graph = g2;
+        cfg = c2;
+        return true;
+    };
+
+    // render_fn, main.rs:134-182, headless: --frames iterations of the windowed loop's body
+    RF_CHECK(load_input());
     RF_CHECK(rf_graph_wait(graph, 0));
-    double t_frame = now_ms();
-    for (int i = 0; i < (args.frames < 1 ? 1 : args.frames); ++i) RF_CHECK(rf_graph_execute(graph, 0));
-    RF_CHECK(rf_graph_wait(graph, 0));
-    double frame_ms = (now_ms() - t_frame) / (double)(args.frames < 1 ? 1 : args.frames);
+    const int frames = args.frames < 1 ? 1 : args.frames;
+    const double t_start = now_ms();
+    double timer = t_start, avg_ms = 0.0, sum_ms = 0.0;
     char times[4096] = "";
+    for (int i = 0; i < frames; ++i) {
+        if (args.frame_interval_ms > 0) {   // pace the loop like a display would, so the config can be edited while it runs
+            RF_CHECK(rf_graph_wait(graph, 0));
+            std::this_thread::sleep_for(std::chrono::milliseconds(args.frame_interval_ms));
+        }
+        if (args.watch && trigger_reloads()) {
+            std::fputs("\r\x1b[2K", stderr);   // main.rs:141
+            RF_CHECK(load_input());
+        }
+        if (args.watch || frames == 1) {
+            rf_status ts = rf_graph_set_time(graph, (float)((now_ms() - t_start) / 1e3));   // update_ubos, render.rs:212-223
+            if (ts != RF_OK) { warnln(rf_last_error()); return 1; }
+        }
+        if (args.watch) {   // the status line of every frame, main.rs:150-157
+            const double elapsed = now_ms() - timer;
+            timer = now_ms();
+            avg_ms = avg_ms - avg_ms / 60.0 + elapsed / 60.0;   // utils::moving_avg, utils.rs:76-82
+            if (opt.flags & RF_GRAPH_TIMERS) {
+                RF_CHECK(rf_graph_wait(graph, 0));
+                if (i > 0) RF_CHECK(rf_graph_times_string(graph, 0, times, sizeof(times)));
+            }
+            std::fprintf(stderr, "\rFrame: %5.2fms, Frame-Avg: %5.2fms, GPU: {%s}", elapsed, avg_ms, times);
+        }
+        RF_CHECK(rf_graph_execute(graph, 0));
+    }
+    RF_CHECK(rf_graph_wait(graph, 0));
+    sum_ms = now_ms() - t_start;
+    const double frame_ms = sum_ms / (double)frames;
     if (opt.flags & RF_GRAPH_TIMERS) RF_CHECK(rf_graph_times_string(graph, 0, times, sizeof(times)));
-    std::fprintf(stderr, "\rFrame: %5.2fms, Frame-Avg: %5.2fms, GPU: {%s}\n", frame_ms, frame_ms, times);   // main.rs:157
+    std::fprintf(stderr, "\rFrame: %5.2fms, Frame-Avg: %5.2fms, GPU: {%s}\n", frame_ms, args.watch ? avg_ms : frame_ms, times);   // main.rs:157
 
     staging.resize((size_t)width * height * 4);
     RF_CHECK(rf_graph_download_srgb8(graph, 0, staging.data(), (size_t)width * 4));

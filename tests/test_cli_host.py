@@ -116,3 +116,46 @@ def test_cli_end_to_end(tmp_path):
     # single-shader mode (config.rs:77-90)
     r = run_cli("-i", src, "sharpen.comp", "-o", dst, "--no-fusion")
     assert r.returncode == 0 and "GPU: {sharpen: " in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_live_reload(tmp_path):
+    """--frames N --watch is the windowed loop of main.rs:134-182 without the window: the config's
+    mtime is polled every frame (render.rs:138-165); a config that does not parse leaves the old
+    graph running (render.rs:121-136), a good one replaces it, and the last frame is what -o gets."""
+    import time
+    rgba = pixel.fill_synthetic(96, 64, util.U8, 78)
+    rgba[..., 3] = 255
+    src, dst, cfg, log = str(tmp_path / "in.png"), str(tmp_path / "out.rgba"), tmp_path / "live.cfg", tmp_path / "err.log"
+    write_png(src, rgba, lambda y: 0)
+    cfg.write_text("input -> passthrough -> output")
+    t0 = int(os.path.getmtime(cfg))
+
+    def wait_for(text, seconds=60.0):
+        end = time.time() + seconds
+        while time.time() < end:
+            if text in log.read_text(errors="replace"):
+                return True
+            time.sleep(0.01)
+        return False
+
+    with open(log, "wb") as err:
+        p = subprocess.Popen([CLI, "-i", src, "--config", str(cfg), "-o", dst, "--frames", "160", "--watch",
+                              "--frame-interval-ms", "25"], stderr=err)
+        try:
+            assert wait_for("GPU: {passthrough: ")                 # the loop runs and prints main.rs:157's line
+            cfg.write_text("input -> -> output")
+            os.utime(cfg, (t0 + 2, t0 + 2))                        # mtime has whole-second resolution (utils.rs:33-42)
+            assert wait_for("Unrecognized token")
+            assert p.poll() is None                                # still rendering with the old graph
+            cfg.write_text("input -> sharp -> output\nsharp: sharpen { amount: 0.75 }")
+            os.utime(cfg, (t0 + 4, t0 + 4))
+            assert wait_for("GPU: {sharp: ")
+            assert p.wait(timeout=120) == 0
+        finally:
+            if p.poll() is None:
+                p.kill()
+    ref = og.GraphOracle("input -> sharp -> output\nsharp: sharpen { amount: 0.75 }", 96, 64, util.F32)
+    ref.upload_srgb8(rgba)
+    ref.execute()
+    assert np.fromfile(dst, np.uint8).reshape(64, 96, 4).tobytes() == ref.download_srgb8().tobytes()
