@@ -668,8 +668,8 @@ template <class Px> static hipError_t run_sharpen(const Op& op, Image s, Image d
 // ---- fused chains -----------------------------------------------------------------
 // A fused launch is the concatenation of its nodes' stage lists with a StNodeEnd between
 // nodes.  Fusable node kinds: gaussian5 (G2), gaussian9 (G4), colour grade, sharpen.  Every
-// pair of them is instantiated, plus the triple gaussian -> grade -> sharpen of the BASELINE
-// chains; anything else runs one launch per node.
+// pair of them is instantiated, plus the triple gaussian -> grade -> sharpen and the whole
+// 5-stage chain of the BASELINE configs; anything else runs one launch per node.
 template <class... S> struct TL {};
 template <class A, class B> struct Concat;
 template <class... A, class... B> struct Concat<TL<A...>, TL<B...>> { typedef TL<A..., B...> type; };
@@ -740,6 +740,15 @@ static hipError_t launch_pair(const Op* o, Image s, Image d, const Geom& g, cons
     }
 }
 
+static bool is_chain5(const Op* o, int n)
+{
+    static const int pattern[5] = {0, 2, 3, 1, 2};
+    if (n != 5) return false;
+    for (int i = 0; i < 5; ++i)
+        if (node_code(o[i]) != pattern[i]) return false;
+    return true;
+}
+
 template <class Px>
 static hipError_t launch_fused(const Op* o, int n, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
 {
@@ -757,6 +766,11 @@ static hipError_t launch_fused(const Op* o, int n, Image s, Image d, const Geom&
         if (node_code(o[0]) == 0) return launch_list<Px>(typename Join<NodeTL<0>::type, Tail>::type{}, o, 3, s, d, g, t, st);
         if (node_code(o[0]) == 1) return launch_list<Px>(typename Join<NodeTL<1>::type, Tail>::type{}, o, 3, s, d, g, t, st);
     }
+    if (is_chain5(o, n)) {   // gaussian5 -> grade -> sharpen -> gaussian9 -> grade: BASELINE configs[3], one read and one write for five nodes
+        typedef typename Join<NodeTL<0>::type, typename Join<NodeTL<2>::type, NodeTL<3>::type>::type>::type Head;
+        typedef typename Join<NodeTL<1>::type, NodeTL<2>::type>::type Tail;
+        return launch_list<Px>(typename Join<Head, Tail>::type{}, o, 5, s, d, g, t, st);
+    }
     return hipErrorInvalidValue;
 }
 
@@ -767,7 +781,8 @@ bool stream_supported(const Op* ops, int n)
     for (int i = 0; i < n; ++i)
         if (node_code(ops[i]) < 0) return false;
     if (n == 2) return true;
-    return n == 3 && ops[0].kind == OP_GAUSSIAN && node_code(ops[1]) == 2 && node_code(ops[2]) == 3;
+    if (n == 3) return ops[0].kind == OP_GAUSSIAN && node_code(ops[1]) == 2 && node_code(ops[2]) == 3;
+    return is_chain5(ops, n);
 }
 
 int ops_radius(const Op* ops, int n)

@@ -178,6 +178,12 @@ def test_fusion_groups():
     assert p.launches() == ["blur+grade+sharp"] and p.layers() == [["blur+grade+sharp"]]
     assert p.images() == ["rf:file-input", "rf:final-output"] and p.aliases() == {}
     p = rf.Plan(rf.Config(util.CHAIN5), 0)
+    assert p.launches() == ["blur+grade+sharp+wide+finish"]        # the whole BASELINE 5-stage chain is one launch
+    assert p.halo_schedule(True) == ([7], [0], 0, 7)               # one exchange of 2+1+4 rows instead of three
+    assert p.halo_schedule(False) == ([7], [0], 7, 7)              # over-fetch: the strip's input carries the 7 rows
+    # any other long chain splits greedily into the longest supported prefixes
+    other = util.CHAIN5_SPLIT
+    p = rf.Plan(rf.Config(other), 0)
     assert p.launches() == ["blur+grade+sharp", "wide+finish"]
     # a fused chain is planned as one node: the aliasing plan is recomputed on the fused
     # graph, so its output can never land on the image it reads

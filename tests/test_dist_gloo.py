@@ -129,6 +129,10 @@ def test_halo_schedules_kat():
     assert [l["radius"] for l in p.launch_info()] == [2, 0, 1, 4, 0]
     assert p.halo_schedule(True) == ([2, 0, 1, 4, 0], [0, 0, 0, 0, 0], 0, 4)
     assert p.halo_schedule(False) == ([7, 5, 5, 4, 0], [5, 5, 4, 0, 0], 7, 7)
-    p = rf.Plan(rf.Config(util.CHAIN5), 0)
-    assert [l["radius"] for l in p.launch_info()] == [3, 4]
-    assert p.halo_schedule(False) == ([7, 4], [4, 0], 7, 7)
+    p = rf.Plan(rf.Config(util.CHAIN5), 0)                      # the whole chain is one launch
+    assert [l["radius"] for l in p.launch_info()] == [7]
+    assert p.halo_schedule(False) == ([7], [0], 7, 7)
+    two = util.CHAIN5.replace("gaussian9    { sigma: 2.0 }", "gaussian5    { sigma: 2.0 }")   # splits 3 + 2
+    p = rf.Plan(rf.Config(two), 0)
+    assert [l["radius"] for l in p.launch_info()] == [3, 2]
+    assert p.halo_schedule(False) == ([5, 2], [2, 0], 5, 5)

@@ -100,6 +100,7 @@ NODES = {
     "conv9": "input -> conv2d -> output\nconv2d: conv2d { ksize: 9, sigma: 2.0 }",
     "chain3": util.CHAIN3,
     "chain5": util.CHAIN5,
+    "chain5_split": util.CHAIN5_SPLIT,
     "diamond": util.DIAMOND,
     "inplace": "input -> gaussian5 -> colour_grade:image -> sharpen -> output\n"
                "gaussian5: gaussian5 { sigma: 1.2 }\ncolour_grade: colour_grade { slope: 0.8, offset: 0.1, saturation: 1.5 }\n"
@@ -155,7 +156,7 @@ def test_medium_frame_all_paths(ctx):
     """640x360: large enough for several workgroups per strip row and many chunks."""
     for fmt in (util.F32, util.U8):
         x = util.synthetic(640, 360, fmt)
-        for text in (util.CHAIN3, util.CHAIN5, util.DIAMOND):
+        for text in (util.CHAIN3, util.CHAIN5, util.CHAIN5_SPLIT, util.DIAMOND):
             want = util.run_oracle(text, x)
             for flags in (0, NF, rf.RF_GRAPH_HIPGRAPH, NF | rf.RF_GRAPH_HIPGRAPH, rf.RF_GRAPH_TIMERS):
                 util.assert_same(util.run_hip(ctx, text, x, flags=flags), want, "flags=%d" % flags)
@@ -339,7 +340,7 @@ def test_render_host_mirror(ctx, tmp_path):
 
 # ---- row strips on real kernels (one GPU standing in for N ranks) --------------------------
 @pytest.mark.parametrize("text,world,flags", [
-    (util.CHAIN5, 2, 0), (util.CHAIN5, 3, NF), (util.CHAIN3, 4, 0), (util.DIAMOND, 2, 0),
+    (util.CHAIN5, 2, 0), (util.CHAIN5, 3, NF), (util.CHAIN5_SPLIT, 3, 0), (util.CHAIN3, 4, 0), (util.DIAMOND, 2, 0),
 ])
 def test_row_strips_overfetch_on_one_gpu(text, world, flags):
     """The N>1 path of rf_graph.cpp in over-fetch mode (RF_GRAPH_NO_HALO_XCHG: strips carry

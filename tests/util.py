@@ -28,6 +28,9 @@ wide:   gaussian9    { sigma: 2.0 }
 finish: colour_grade { slope: 0.95, offset: 0.01, saturation: 0.9 }
 """
 
+# same shape with a gaussian5 in the middle: fuses as 3 + 2 launches (two fused launches per frame)
+CHAIN5_SPLIT = CHAIN5.replace("gaussian9    { sigma: 2.0 }", "gaussian5    { sigma: 2.0 }")
+
 DIAMOND = """
 input -> blur -> mixer:input_image0
 input -> sharp -> mixer:input_image1
