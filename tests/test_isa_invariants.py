@@ -102,7 +102,7 @@ def test_fused_chain_steady_loop_is_lean(stream_asm):
     """The 3-stage rgba32f chain: all 68 fmaf per row are packed (v_pk_fma_f32), and the loop
     stays near 110 instructions (it was ~250 before the steady-state split)."""
     ks = kernels(stream_asm)
-    name = [n for n in ks if "PxF32ELi4E" in n and "StHTapILi2E" in n and "StCross3" in n and "StGrade" in n]
+    name = [n for n in ks if "PxF32ELi4E" in n and "StHTapILi2E" in n and "StGrade" in n and "StCross3EEEEv" in n]   # ends at the sharpen
     assert len(name) == 1
     loops = steady_loops(ks[name[0]])
     assert len(loops) == 2                    # top-down and bottom-up walks
