@@ -1,15 +1,17 @@
-// rf_conv.hip -- dense KxK convolution kernels (conv2d node) for gfx950: a 16x16 LDS-tile
-// VALU kernel for small K, the banded contraction on v_mfma_f32_16x16x4_f32 (default from
-// 9x9), and a register-blocked VALU kernel.  All three are bit-identical to the oracle's
-// (dy outer, dx inner) fmaf chain.  See DESIGN.md section 6.2.
+// rf_conv.hip -- dense KxK convolution kernels (conv2d node) for gfx950: the register-blocked
+// VALU kernel (default), the banded contraction on v_mfma_f32_16x16x4_f32 (RF_CONV_PATH=2,
+// K >= 9) and a plain 16x16 LDS-tile kernel (RF_CONV_PATH=1; K = 1).  All three are
+// bit-identical to the oracle's (dy outer, dx inner) fmaf chain.  See DESIGN.md section 6.2.
+#include <type_traits>
+
 #include "rf_device.h"
 
 namespace rf {
 
 // ---------------------------------------------------------------------------------
 // conv2d: dense KxK correlation on a 16x16 output tile with an LDS halo tile.
-// First (VALU) version: one output texel per thread, taps from LDS in the oracle's
-// order.  The MFMA/Toeplitz formulation is the planned replacement.
+// One output texel per thread, taps from LDS in the oracle's order: the simple baseline the
+// other two kernels are measured against (8.4 ms at 31x31 8K).
 // ---------------------------------------------------------------------------------
 template <class Px>
 __global__ __launch_bounds__(256) void conv2d_tile_kernel(const char* src, size_t src_pitch, char* dst, size_t dst_pitch,
@@ -63,102 +65,184 @@ __global__ __launch_bounds__(256) void conv2d_tile_kernel(const char* src, size_
 // finite inputs.  (A non-finite texel poisons the whole 16-column tile row it feeds instead
 // of only the K columns around it: 0 * inf = NaN.)
 //
-// Data movement: one workgroup (4 waves = 64 output columns) walks DOWN a chunk of rows 8
-// output rows at a time, keeping the 8+2r input rows it needs in an LDS ring (row pitch = 8
-// mod 32 dwords so the 16 (row,channel) x 2 (k) operand reads of a lane group hit 32 banks);
-// each step loads only the 8 new rows, so an input row is fetched once per strip.
+// Data movement: one workgroup (4 waves = 64 output columns) walks DOWN a chunk of rows 16
+// output rows at a time, keeping the 16+2r input rows it needs in an LDS ring; each step loads
+// only the 16 new rows, so an input row is fetched once per strip.  Software pipelining:
+//  * the ring is stored TRANSPOSED: a row is 16 sub-rows (column & 3, channel) of 24 dwords,
+//    so the A operands of four consecutive k-steps of a lane are 4 consecutive dwords: one
+//    ds_read_b128 instead of four ds_read_b32 (3 per M-tile per weight row at 31x31);
+//  * a wave owns 4 M-tiles (16 output rows x 16 columns): the B operand (band of the weight
+//    row) is read once for 4 tiles;
+//  * operands of weight row dy+1 are read into a second register set while the 48 MFMAs of
+//    row dy issue (sched_group_barrier pins the interleave: 1 LDS read, 2 MFMAs, ...) --
+//    left to itself hipcc sinks each operand read next to its MFMA and every group of 4 MFMAs
+//    waits a full LDS latency (the first version of this kernel: MFMA pipe 76 % busy, this
+//    one 84 %, rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES);
+//  * the 16 input rows of the NEXT step are fetched from global into registers before the
+//    weight-row loop and written to the ring after it.
 // ---------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kConvStripW = 64;     // output columns per workgroup
-constexpr int kConvStepRows = 8;    // output rows per step (2 M-tiles of 4 rows per wave)
 constexpr int kConvWRow = 64;       // dwords per padded weight row: 15 zeros, K taps, zeros
+constexpr int kCm2StepRows = 16;                 // output rows per step: 4 M-tiles of 4 rows per wave
+constexpr int kCm2NQ = 24;                       // dwords per sub-row: (64 + 30 + 2) / 4 columns
+constexpr int kCm2Pitch = 16 * kCm2NQ + 4;       // dwords per ring row (4 mod 32: the rows of a lane group spread over the banks)
 
-static int conv_mfma_pitch(int r) { return (((kConvStripW + 2 * r) * 4 + 31) & ~31) + 8; }   // dwords, = 8 mod 32
-static int conv_mfma_ring(int r) { return (kConvStepRows + 2 * r + 3) & ~3; }
-
-template <class Px, int STEPS>   // STEPS = MFMA k-steps per weight row = ceil((16 + 2r) / 4), compile-time so the row unrolls
+template <class Px, int STEPS>
 __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const char* src, size_t src_pitch, char* dst, size_t dst_pitch,
-                                                          int W, int row_lo, int row_hi, int y0, int y1, int rows_per_chunk,
-                                                          int K, int pitch, int ring, const float* __restrict__ weights)
+                                                           int W, int row_lo, int row_hi, int y0, int y1, int rows_per_chunk,
+                                                           int K, const float* __restrict__ weights)
 {
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    constexpr int G = (STEPS + 3) / 4;                            // ds_read_b128 per M-tile per weight row
+    constexpr int MT = kCm2StepRows / 4;                          // M-tiles per wave
     float* wpad = reinterpret_cast<float*>(dyn_smem);            // [K][64]
-    float* tile = wpad + K * kConvWRow;                           // [ring][pitch]
+    float* tile = wpad + K * kConvWRow;                           // [ring][kCm2Pitch]
     const int r = K / 2;
-    const int xin = kConvStripW + 2 * r;                          // input columns of the strip
+    const int ring = kCm2StepRows + 2 * r;
+    const int xin = kConvStripW + 2 * r;
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int j = lane & 15, kq = lane >> 4;                      // B: column j, k index kq;  A: row i = lane&15, k index kq
-    const int a_yy = (lane & 15) >> 2, a_c = lane & 3;
+    const int j = lane & 15, kq = lane >> 4;
+    const int a_yy = j >> 2, a_c = j & 3;
 
     const int x_out0 = (int)blockIdx.x * kConvStripW;
     const int cy0 = y0 + (int)blockIdx.y * rows_per_chunk;
     const int cy1 = min(cy0 + rows_per_chunk, y1);
     if (cy0 >= cy1) return;
 
-    // padded weight rows: wpad[dy][15 + t] = w[dy][t]
     for (int i = tid; i < K * kConvWRow; i += 256) {
         int dy = i / kConvWRow, t = i % kConvWRow - 15;
         wpad[i] = (t >= 0 && t < K) ? weights[dy * K + t] : 0.0f;
     }
-
-    // columns beyond the strip's last input column are multiplied by zero band entries: they
-    // must be finite, so the whole ring starts as zeros
-    for (int i = tid; i < ring * pitch; i += 256) tile[i] = 0.0f;
+    for (int i = tid; i < ring * kCm2Pitch; i += 256) tile[i] = 0.0f;   // pad columns meet zero band entries: must be finite
     __syncthreads();
 
-    const int first_in = cy0 - r;                                 // frame row held by ring offset 0
-    int loaded_to = first_in;                                     // rows [first_in, loaded_to) are in the ring
-    for (int ys = cy0; ys < cy1; ys += kConvStepRows) {
-        // stage the rows this step needs that are not in the ring yet (clamp-to-edge on load)
-        const int need_to = ys + kConvStepRows + r;
-        const int nrows = need_to - loaded_to;
-        for (int i = tid; i < nrows * xin; i += 256) {
-            const int rr = loaded_to + i / xin, xx = i % xin;
-            const int gy = min(max(rr, row_lo), row_hi);
-            const int gx = min(max(x_out0 - r + xx, 0), W - 1);
-            const f4 v = Px::decode(Px::load(src + (ptrdiff_t)gy * (ptrdiff_t)src_pitch, (unsigned)gx * (unsigned)Px::BPP));
-            const int slot = (rr - first_in) % ring;
-            *reinterpret_cast<f4*>(tile + slot * pitch + xx * 4) = v;
-        }
-        loaded_to = need_to;
-        __syncthreads();
+    const int first_in = cy0 - r;
+    auto fetch = [&](int rr, int xx) -> f4 {
+        const int gy = min(max(rr, row_lo), row_hi);
+        const int gx = min(max(x_out0 - r + xx, 0), W - 1);
+        return Px::decode(Px::load(src + (ptrdiff_t)gy * (ptrdiff_t)src_pitch, (unsigned)gx * (unsigned)Px::BPP));
+    };
+    auto put = [&](int rr, int xx, const f4& v) {
+        float* q = tile + ((rr - first_in) % ring) * kCm2Pitch + ((xx & 3) * 4) * kCm2NQ + (xx >> 2);
+        q[0] = v.x;
+        q[kCm2NQ] = v.y;
+        q[2 * kCm2NQ] = v.z;
+        q[3 * kCm2NQ] = v.w;
+    };
+    // first fill: the ring's worth of rows of step 0
+    int loaded_to = cy0 + kCm2StepRows + r;
+    for (int i = tid; i < ring * xin; i += 256) put(first_in + i / xin, i % xin, fetch(first_in + i / xin, i % xin));
+    __syncthreads();
 
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        // ring slot of input row (ys + 4m + yy + dy - r) = ((ys - cy0) + 4m + yy + dy) mod ring
-        int slot0 = ((ys - cy0) + a_yy) % ring;
-        int slot1 = ((ys - cy0) + 4 + a_yy) % ring;
-        const int a_col = (16 * wave + kq) * 4 + a_c;              // dword offset of (column 16w+k, channel c)
-        const float* bptr = wpad + 15 + kq - j;
-        for (int dy = 0; dy < K; ++dy) {
-            const float* a0 = tile + slot0 * pitch + a_col;
-            const float* a1 = tile + slot1 * pitch + a_col;
-            const float* b = bptr + dy * kConvWRow;
-            // all operand reads of the weight row are issued ahead of its MFMAs
-            float bv[STEPS], av0[STEPS], av1[STEPS];
+    constexpr int NPF = (kCm2StepRows * (kConvStripW + 2 * kMaxRadius) + 255) / 256;   // texels per thread of a 16-row refill
+    const int a_off = (kq * 4 + a_c) * kCm2NQ + 4 * wave;         // dword offset of this lane's A run inside a ring row
+    const float* bbase = wpad + 15 + kq - j;
+
+    for (int ys = cy0; ys < cy1; ys += kCm2StepRows) {
+        const bool has_next = ys + kCm2StepRows < cy1;
+        f4 pf[NPF];
+        if (has_next) {
 #pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                bv[s] = b[4 * s];
-                av0[s] = a0[16 * s];
-                av1[s] = a1[16 * s];
+            for (int q = 0; q < NPF; ++q) {
+                const int i = tid + 256 * q;
+                if (i < kCm2StepRows * xin) pf[q] = fetch(loaded_to + i / xin, i % xin);
             }
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[s], bv[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[s], bv[s], acc1, 0, 0, 0);
-            }
-            slot0 = slot0 + 1 == ring ? 0 : slot0 + 1;
-            slot1 = slot1 + 1 == ring ? 0 : slot1 + 1;
         }
-        // D: column j = lane&15, row i = 4*(lane>>4) + reg  =>  output row yy = lane>>4, channel = reg
+
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 A[2][MT][G];
+        float B[2][STEPS];
+        int slot[MT];                                              // ring slot the NEXT operand read takes, per M-tile
+#pragma unroll
+        for (int m = 0; m < MT; ++m) slot[m] = ((ys - cy0) + 4 * m + a_yy) % ring;
+        int dy_load = 0;
+        auto load = [&](auto bufc) {
+            constexpr int buf = decltype(bufc)::value;
+            const float* b = bbase + dy_load * kConvWRow;
+#pragma unroll
+            for (int s2 = 0; s2 < STEPS; ++s2) B[buf][s2] = b[4 * s2];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const f32x4* a = reinterpret_cast<const f32x4*>(tile + slot[m] * kCm2Pitch + a_off);
+#pragma unroll
+                for (int g = 0; g < G; ++g) A[buf][m][g] = a[g];
+                slot[m] = slot[m] + 1 == ring ? 0 : slot[m] + 1;
+            }
+            ++dy_load;
+        };
+        auto mma = [&](auto bufc) {
+            constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+            for (int s2 = 0; s2 < STEPS; ++s2) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[buf][m][s2 >> 2][s2 & 3], B[buf][s2], acc[m], 0, 0, 0);
+            }
+        };
+        auto interleave = [&]() {   // 1 LDS read, 2 MFMAs, ... : the reads of the next row ride in the shadow of this row's MFMAs
+#pragma unroll
+            for (int q = 0; q < MT * G + (STEPS + 1) / 2; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        };
+        typedef std::integral_constant<int, 0> B0;
+        typedef std::integral_constant<int, 1> B1;
+        load(B0{});
+        for (int dy = 0; dy + 2 < K; dy += 2) {
+            load(B1{});
+            mma(B0{});
+            interleave();
+            load(B0{});
+            mma(B1{});
+            interleave();
+        }
+        mma(B0{});                                                 // K is odd: the last weight row sits in set 0
+
+        // D: column j = lane & 15, row 4*(lane >> 4) + reg  =>  output row kq of the M-tile, channel = reg
         const int ox = x_out0 + 16 * wave + j;
-        const int oy0 = ys + kq, oy1 = ys + 4 + kq;
         if (ox < W) {
-            if (oy0 < cy1) Px::store(dst + (ptrdiff_t)oy0 * (ptrdiff_t)dst_pitch, (unsigned)ox * (unsigned)Px::BPP, make_float4(acc0[0], acc0[1], acc0[2], acc0[3]));
-            if (oy1 < cy1) Px::store(dst + (ptrdiff_t)oy1 * (ptrdiff_t)dst_pitch, (unsigned)ox * (unsigned)Px::BPP, make_float4(acc1[0], acc1[1], acc1[2], acc1[3]));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int oy = ys + 4 * m + kq;
+                if (oy < cy1) Px::store(dst + (ptrdiff_t)oy * (ptrdiff_t)dst_pitch, (unsigned)ox * (unsigned)Px::BPP, make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]));
+            }
         }
-        __syncthreads();      // the next step overwrites the oldest rows
+        __syncthreads();      // every wave is done with the 16 oldest rows
+        if (has_next) {
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) {
+                const int i = tid + 256 * q;
+                if (i < kCm2StepRows * xin) put(loaded_to + i / xin, i % xin, pf[q]);
+            }
+            loaded_to += kCm2StepRows;
+        }
+        __syncthreads();
+    }
+}
+
+template <class Px, int STEPS = 5>
+static hipError_t launch_conv_mfma(int steps, dim3 grid, size_t lds, hipStream_t stream, const char* src, size_t src_pitch, char* dst,
+                                    size_t dst_pitch, int W, int row_lo, int row_hi, int y0, int y1, int rpc, int K, const float* weights)
+{
+    if constexpr (STEPS > 12) {
+        return hipErrorInvalidValue;
+    } else {
+        if (steps != STEPS)
+            return launch_conv_mfma<Px, STEPS + 1>(steps, grid, lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0, y1, rpc, K, weights);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<Px, STEPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv2d_mfma_kernel<Px, STEPS>), grid, dim3(256), lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0,
+                           y1, rpc, K, weights);
+        return hipGetLastError();
     }
 }
 
@@ -166,21 +250,25 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const char* src, size_
 // conv2d, register-blocked VALU formulation.  On gfx950 an f32 MFMA runs at the f32 VECTOR
 // rate (MI355X guide: 64 FLOP/clk/SIMD either way), so the banded MFMA contraction above
 // pays for its zero band entries (35 % at 31x31) with nothing in return; this kernel does
-// only the real taps.  Each lane accumulates 4 consecutive output columns of one row
-// (4 f4 accumulators) and slides a register window along the row: one ds_read_b128 per
-// 8 v_pk_fma_f32.  Tap order is exactly the oracle's (dy outer, dx inner).
+// only the real taps.  Each lane accumulates 8 consecutive output columns of one row
+// (8 f4 accumulators) and slides a register window along the row: one ds_read_b128 (1 KiB per
+// wave = 8 LDS cycles) per 16 v_pk_fma_f32 (64 issue cycles), so the four SIMDs of a CU together
+// keep the LDS pipe half busy -- with 4 columns per lane the kernel was LDS-bound at half the
+// VALU rate.  Tap order is exactly the oracle's (dy outer, dx inner).
 //
-// Workgroup = 8 waves = 128 output columns x 16 rows per step (lane = 32 column groups x
-// 2 rows; two waves per SIMD, which the VALU needs to issue every other cycle), walking down a
-// chunk with the 16+2r input rows in an LDS ring, like the MFMA kernel.  LDS row layout:
-// column c lives at sub-row (c & 3), position (c >> 2), so the 32 lanes of a row read 32
-// CONSECUTIVE texels for any tap (lane lx reads column 4*lx + m: the sub-row m & 3 is the same
+// Workgroup = 8 waves = 128 output columns x 32 rows per step (lane = 16 column groups x
+// 4 rows; two waves per SIMD, which the VALU needs to issue every other cycle), walking down a
+// chunk with the 32+2r input rows in an LDS ring, like the MFMA kernel.  LDS row layout:
+// column c lives at sub-row (c & 7), position (c >> 3), so the 16 lanes of a row read 16
+// CONSECUTIVE texels for any tap (lane lx reads column 8*lx + m: the sub-row m & 7 is the same
 // in every lane); the row pitch is a multiple of 256 B.
 // ---------------------------------------------------------------------------------
 constexpr int kCvStripW = 128;      // output columns per workgroup
-constexpr int kCvStepRows = 16;     // output rows per step
-constexpr int kCvT = 4;             // output columns per lane
-constexpr int kCvSub = 40;          // texels per sub-row: (128 + 30 + 2) / 4; 4 x 40 x 16 B = 2560 B = 10 x 256 B per row
+constexpr int kCvStepRows = 32;     // output rows per step
+constexpr int kCvT = 8;             // output columns per lane
+constexpr int kCvSub = 20;          // texels per sub-row: (128 + 30 + 2) / 8; 8 x 20 x 16 B = 2560 B = 10 x 256 B per row
+constexpr int kCvLanesX = kCvStripW / kCvT;     // 16
+constexpr int kCvLanesY = 64 / kCvLanesX;       // 4 rows per wave
 
 template <class Px, int K>   // K is compile-time: the tap loop unrolls completely, the register window rotates by renaming
 __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_t src_pitch, char* dst, size_t dst_pitch,
@@ -189,7 +277,7 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
 {
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     constexpr int KQ = (K + 3) / 4;                               // f4 per padded weight row
-    constexpr int WN = 8;                                         // register window: 4 texels in use + 4 in flight
+    constexpr int WN = kCvT + 4;                                  // register window: kCvT texels in use + 4 in flight
     f4* wl = reinterpret_cast<f4*>(dyn_smem);                    // weights, [K][KQ] f4
     f4* tile = wl + K * KQ;                                       // [ring][4][kCvSub]
     constexpr int kRowTexels = kCvT * kCvSub;                     // 160 texels = 2560 B per ring row
@@ -197,7 +285,7 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
     constexpr int xin = kCvStripW + 2 * r;
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int lx = lane & 31, ly = lane >> 5;
+    const int lx = lane & (kCvLanesX - 1), ly = lane / kCvLanesX;
 
     const int x_out0 = (int)blockIdx.x * kCvStripW;
     const int cy0 = y0 + (int)blockIdx.y * rows_per_chunk;
@@ -220,7 +308,7 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
             const int gx = min(max(x_out0 - r + c, 0), W - 1);
             const f4 v = Px::decode(Px::load(src + (ptrdiff_t)gy * (ptrdiff_t)src_pitch, (unsigned)gx * (unsigned)Px::BPP));
             const int slot = (rr - first_in) % ring;
-            tile[slot * kRowTexels + (c & 3) * kCvSub + (c >> 2)] = v;
+            tile[slot * kRowTexels + (c % kCvT) * kCvSub + (c / kCvT)] = v;
         }
         loaded_to = need_to;
         __syncthreads();
@@ -228,9 +316,9 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
         f4 acc[kCvT];
 #pragma unroll
         for (int t = 0; t < kCvT; ++t) acc[t] = f4_zero();
-        int slot = ((ys - cy0) + 2 * wave + ly) % ring;           // ring slot of input row (ys + 2*wave + ly + dy - r)
+        int slot = ((ys - cy0) + kCvLanesY * wave + ly) % ring;   // ring slot of input row (ys + 4*wave + ly + dy - r)
         for (int dy = 0; dy < K; ++dy) {
-            const f4* row = tile + slot * kRowTexels + lx;        // texel m of this lane's window: row[(m & 3) * kCvSub + (m >> 2)]
+            const f4* row = tile + slot * kRowTexels + lx;        // texel m of this lane's window: row[(m % T) * kCvSub + m / T]
             const f4* wrow = wl + dy * KQ;                        // same address in every lane: LDS broadcast
             float wv[KQ * 4];
 #pragma unroll
@@ -240,7 +328,7 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
             }
             f4 win[WN];
 #pragma unroll
-            for (int m = 0; m < WN; ++m) win[m] = row[(m & 3) * kCvSub + (m >> 2)];
+            for (int m = 0; m < WN; ++m) win[m] = row[(m % kCvT) * kCvSub + m / kCvT];
 #pragma unroll
             for (int dx = 0; dx < K; ++dx) {
 #pragma unroll
@@ -248,12 +336,12 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
                 // texel dx is done: its register takes texel dx + WN (needed 4 taps from now)
                 if (dx + WN <= K - 1 + kCvT - 1) {
                     const int m = dx + WN;
-                    win[dx % WN] = row[(m & 3) * kCvSub + (m >> 2)];
+                    win[dx % WN] = row[(m % kCvT) * kCvSub + m / kCvT];
                 }
             }
             slot = slot + 1 == ring ? 0 : slot + 1;
         }
-        const int oy = ys + 2 * wave + ly;
+        const int oy = ys + kCvLanesY * wave + ly;
         if (oy < cy1) {
             char* orow = dst + (ptrdiff_t)oy * (ptrdiff_t)dst_pitch;
 #pragma unroll
@@ -266,7 +354,7 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
     }
 }
 
-template <class Px, int K = 9>
+template <class Px, int K = 3>
 static hipError_t launch_conv_valu(int k, dim3 grid, size_t lds, hipStream_t stream, const char* src, size_t src_pitch, char* dst,
                                    size_t dst_pitch, int W, int row_lo, int row_hi, int y0, int y1, int rpc, int ring, const float* weights)
 {
@@ -281,30 +369,6 @@ static hipError_t launch_conv_valu(int k, dim3 grid, size_t lds, hipStream_t str
         }
         hipLaunchKernelGGL((conv2d_valu_kernel<Px, K>), grid, dim3(512), lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0, y1, rpc,
                            ring, weights);
-        return hipGetLastError();
-    }
-}
-
-// k-steps 5..12 cover 9x9 (r = 4 -> 6) .. 31x31 (r = 15 -> 12); smaller kernels use the tile kernel
-template <class Px, int STEPS = 5>
-static hipError_t launch_conv_mfma(int steps, dim3 grid, size_t lds, hipStream_t stream, const char* src, size_t src_pitch, char* dst,
-                                   size_t dst_pitch, int W, int row_lo, int row_hi, int y0, int y1, int rpc, int K, int pitch, int ring,
-                                   const float* weights)
-{
-    if constexpr (STEPS > 12) {
-        return hipErrorInvalidValue;
-    } else {
-        if (steps != STEPS)
-            return launch_conv_mfma<Px, STEPS + 1>(steps, grid, lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0, y1, rpc, K,
-                                                   pitch, ring, weights);
-        static bool attr_set = false;   // more than 64 KiB of dynamic LDS needs the attribute
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<Px, STEPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((conv2d_mfma_kernel<Px, STEPS>), grid, dim3(256), lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0,
-                           y1, rpc, K, pitch, ring, weights);
         return hipGetLastError();
     }
 }
@@ -325,6 +389,7 @@ static int conv_rows_per_chunk(int rows, int strips, int slots, int step, int mi
         const double eff = (double)wgs / (double)((wgs + slots - 1) / slots * slots);
         if (eff > best_eff + 0.02) { best_eff = eff; best_c = c; }
     }
+    if (best_eff == 0.0) return min_rows;   // small frame: every candidate is shorter than min_rows
     int rpc = ((rows + best_c - 1) / best_c + step - 1) / step * step;
     return rpc < min_rows ? min_rows : rpc;
 }
@@ -336,30 +401,31 @@ static hipError_t launch_conv2d_px(const Op& op, Image src, Image dst, const Geo
     if (op.radius < 0 || op.radius > kMaxRadius || !op.dev_weights) return hipErrorInvalidValue;
     const int rows = g.y1 - g.y0;
     if (rows <= 0 || g.W <= 0) return hipSuccess;
-    // large kernels run on the matrix cores; small ones keep the 16x16 LDS-tile kernel
-    const int rows_cv = g.y1 - g.y0;
-    if (tune.conv_path == 3 && K >= 9 && rows_cv > 0 && g.W > 0) {
-        const int ring = (kCvStepRows + 2 * op.radius + 3) & ~3;
+    // conv_path 0 (auto): the register-blocked VALU kernel from 7x7 (31x31 at 8K: 3.0 ms, the MFMA
+    // kernel 3.1 ms; 15x15 at 4K: 0.21 vs 0.30 ms -- the band wastes more the smaller K is), the
+    // 16x16 LDS tile below that (3x3 at 4K: 59 us vs 77 us).  1: tile; 2: banded contraction on
+    // the matrix cores (K >= 9); 3: VALU.
+    const bool mfma = tune.conv_path == 2 && K >= 9;
+    const bool valu = !mfma && tune.conv_path != 1 && K >= 3 && (K >= 7 || tune.conv_path != 0);
+    if (valu) {
+        const int ring = kCvStepRows + 2 * op.radius;
         const size_t lds = ((size_t)ring * kCvT * kCvSub + (size_t)K * ((K + 3) / 4)) * sizeof(f4);
         const int strips = (g.W + kCvStripW - 1) / kCvStripW;
-        int rpc = conv_rows_per_chunk(rows_cv, strips, 256, kCvStepRows, 2 * kCvStepRows);   // one 124 KiB workgroup per CU
+        int rpc = conv_rows_per_chunk(rows, strips, 256, kCvStepRows, 2 * kCvStepRows);   // one workgroup (up to 159 KiB of LDS) per CU
         if (tune.rows_per_chunk > 0) rpc = (tune.rows_per_chunk + kCvStepRows - 1) / kCvStepRows * kCvStepRows;
-        dim3 grid((unsigned)strips, (unsigned)((rows_cv + rpc - 1) / rpc));
+        dim3 grid((unsigned)strips, (unsigned)((rows + rpc - 1) / rpc));
         return launch_conv_valu<Px>(K, grid, lds, stream, static_cast<const char*>(src.base), src.pitch, static_cast<char*>(dst.base),
                                     dst.pitch, g.W, g.row_lo, g.row_hi, g.y0, g.y1, rpc, ring, op.dev_weights);
     }
-    const bool mfma = tune.conv_path == 2 || (tune.conv_path != 1 && K >= 9);
     if (mfma) {
-        const int pitch = conv_mfma_pitch(op.radius), ring = conv_mfma_ring(op.radius);
-        const size_t lds = ((size_t)K * kConvWRow + (size_t)ring * pitch) * sizeof(float);
+        const int ring = kCm2StepRows + 2 * op.radius;
+        const size_t lds = ((size_t)K * kConvWRow + (size_t)ring * kCm2Pitch) * sizeof(float);
         const int strips = (g.W + kConvStripW - 1) / kConvStripW;
-        // ~4 workgroups per CU in flight; chunks are whole steps of 8 rows
-        int rpc = conv_rows_per_chunk(rows, strips, 512, kConvStepRows, 4 * kConvStepRows);   // two 70 KiB workgroups per CU
-        if (tune.rows_per_chunk > 0) rpc = (tune.rows_per_chunk + kConvStepRows - 1) / kConvStepRows * kConvStepRows;
+        int rpc = conv_rows_per_chunk(rows, strips, 512, kCm2StepRows, 2 * kCm2StepRows);   // two 80 KiB workgroups per CU
+        if (tune.rows_per_chunk > 0) rpc = (tune.rows_per_chunk + kCm2StepRows - 1) / kCm2StepRows * kCm2StepRows;
         dim3 grid((unsigned)strips, (unsigned)((rows + rpc - 1) / rpc));
         return launch_conv_mfma<Px>((16 + 2 * op.radius + 3) / 4, grid, lds, stream, static_cast<const char*>(src.base), src.pitch,
-                                    static_cast<char*>(dst.base), dst.pitch, g.W, g.row_lo, g.row_hi, g.y0, g.y1, rpc, K, pitch,
-                                    ring, op.dev_weights);
+                                    static_cast<char*>(dst.base), dst.pitch, g.W, g.row_lo, g.row_hi, g.y0, g.y1, rpc, K, op.dev_weights);
     }
     const int TW = 16 + 2 * op.radius;
     size_t lds = (size_t)TW * TW * sizeof(f4) + (size_t)K * K * sizeof(float);

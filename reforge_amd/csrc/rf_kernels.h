@@ -60,7 +60,7 @@ struct Geom {
 struct StreamTuning {
     int rows_per_chunk = 0;   // RF_ROWS_PER_CHUNK
     int no_alternate = 0;     // RF_NO_ALTERNATE=1: every chunk walks top-down
-    int conv_path = 0;        // RF_CONV_PATH: 0 = by kernel size (MFMA from 9x9), 1 = LDS-tile VALU, 2 = MFMA
+    int conv_path = 0;        // RF_CONV_PATH: 0 = register-blocked VALU kernel, 1 = 16x16 LDS tile, 2 = MFMA (K >= 9), 3 = VALU
 };
 
 // true if `ops[0..n)` can run as ONE streaming launch (a fused pipeline)

@@ -6,7 +6,7 @@ import reforge_amd as rf
 from tests import util
 
 ctx = rf.Context(0)
-for K in (9, 15, 31):
+for K in (3, 5, 9, 15, 31):
     text = "input -> conv2d -> output\nconv2d: conv2d { ksize: %d, sigma: %.1f }" % (K, K / 6.0)
     for fmt in (util.F32, util.U8):
         for (W, H) in ((97, 50), (64, 8), (130, 70)):
@@ -29,4 +29,15 @@ for path in ("1", "2", "3"):
         g.execute(); g.wait()
         ms = g.time_frames(3) / 3
         print(json.dumps({"path": path, "W": W, "H": H, "ms": ms, "Mpx_s": W * H / ms / 1e3, "TFLOPs": 2 * 961 * 4 * W * H / ms / 1e9}), flush=True)
+        g.close()
+
+for K in (3, 7, 9, 15):
+    text = "input -> conv2d -> output\nconv2d: conv2d { ksize: %d, sigma: %.1f }" % (K, K / 6.0)
+    for path in ("1", "2", "3"):
+        os.environ["RF_CONV_PATH"] = path
+        g = rf.Graph(ctx, rf.Config(text), 3840, 2160, util.F32)
+        g.fill_synthetic(5)
+        g.execute(); g.wait()
+        ms = g.time_frames(5) / 5
+        print(json.dumps({"K": K, "path": path, "ms_4k": ms}), flush=True)
         g.close()

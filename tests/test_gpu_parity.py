@@ -209,14 +209,16 @@ def test_non_finite_texels_propagate_like_the_oracle(ctx):
 def test_conv2d_every_kernel_path(ctx, path, monkeypatch):
     """The three conv2d kernels (1 = 16x16 LDS tile, 2 = banded MFMA, 3 = register-blocked VALU)
     are all bit-identical to the oracle: ragged widths around the 64/128-column strips, heights
-    around the 8/16-row steps, frame edges inside the halo."""
+    around the 16/32-row steps (several steps per chunk: the register-prefetched ring refill),
+    frame edges inside the halo.  K < 9 has no MFMA kernel: path 2 then takes the VALU kernel."""
     monkeypatch.setenv("RF_CONV_PATH", path)
-    for K, sigma in ((9, 1.5), (13, 2.0), (21, 3.5), (31, 5.0)):
+    monkeypatch.setenv("RF_ROWS_PER_CHUNK", "64")
+    for K, sigma in ((3, 0.8), (5, 1.0), (9, 1.5), (13, 2.0), (21, 3.5), (31, 5.0)):
         text = "input -> conv2d -> output\nconv2d: conv2d { ksize: %d, sigma: %.1f }" % (K, sigma)
         rng = np.random.RandomState(K)
         w = rng.uniform(-0.03, 0.03, (K, K)).astype(np.float32)
         for fmt in (util.F32, util.U8):
-            for W, H in ((7, 5), (65, 9), (129, 17), (200, 45)):
+            for W, H in ((7, 5), (65, 9), (129, 17), (200, 45), (131, 150)):
                 x = util.synthetic(W, H, fmt, seed=K * 100 + W)
                 util.assert_same(util.run_hip(ctx, text, x, weights={"conv2d": w}), util.run_oracle(text, x, {"conv2d": w}),
                                  "conv path %s K=%d %dx%d fmt=%d" % (path, K, W, H, fmt))
