@@ -264,6 +264,20 @@ def main():
         "chain_algorithmic_bytes_per_px": n_nodes * 2 * BPP,
         "launch_ms": {k: round(v, 5) for k, v in per_launch},
     }
+    if args.workload == "conv31_8k" and world == 1:
+        # both large-K kernels, timed the same way (the default is the VALU one; RF_CONV_PATH=2 selects MFMA)
+        paths = {}
+        for name, env in (("valu", "3"), ("mfma", "2")):
+            os.environ["RF_CONV_PATH"] = env
+            g2 = rf.Graph(ctx, rf.Config(text), W, H, rf.RF_FORMAT_RGBA32F, num_frames=1, flags=flags)
+            g2.fill_synthetic(seed)
+            g2.execute(0)
+            g2.wait(0)
+            ms = g2.time_frames(5) / 5
+            paths[name] = {"ms": round(ms, 4), "useful_tflops": round(2.0 * 961 * 4 * W * rows / (ms * 1e-3) / 1e12, 2)}
+            g2.close()
+        del os.environ["RF_CONV_PATH"]
+        out["conv_kernels"] = paths
     if rank == 0 and world == 1:
         try:
             out["copy_gbps"] = round(ctx.copy_bandwidth(256 << 20, 20), 1)
