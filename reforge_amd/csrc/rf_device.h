@@ -47,12 +47,21 @@ RF_DEV float unorm8_to_f32(unsigned c)
     const float e = fmaf(-q, 255.0f, x);
     return fmaf(e, r, q);
 }
-RF_DEV unsigned f32_to_unorm8(float v)
+// imageStore's float -> UNORM8 as a float: clamp to [0,1] (NaN -> 0), x255, round to nearest even.
+// v_med3_f32 returns min3 when an operand is NaN, i.e. 0; the +0 addend of the fma turns a
+// clamped -0 into +0, which is what the integer code decodes to.
+RF_DEV float unorm8_code(float v)
 {
-    // clamp (NaN -> 0), x255, round to nearest even
-    v = (v > 0.0f) ? v : 0.0f;
-    v = (v > 1.0f) ? 1.0f : v;
-    return (unsigned)rintf(v * 255.0f);
+    return rintf(fmaf(__builtin_amdgcn_fmed3f(v, 0.0f, 1.0f), 255.0f, 0.0f));
+}
+RF_DEV unsigned f32_to_unorm8(float v) { return (unsigned)unorm8_code(v); }
+// code (an integer-valued float in [0,255]) -> c / 255 correctly rounded, as unorm8_to_f32
+RF_DEV float unorm8_code_to_f32(float x)
+{
+    const float r = 1.0f / 255.0f;
+    const float q = x * r;
+    const float e = fmaf(-q, 255.0f, x);
+    return fmaf(e, r, q);
 }
 
 struct PxF32 {
@@ -98,12 +107,20 @@ struct PxU8 {
     RF_DEV static f4 take(Raw r) { return decode(r); }   // the conversion already leaves the ring slot dead
     RF_DEV static unsigned pack(f4 v)
     {
-        return f32_to_unorm8(v.x) | (f32_to_unorm8(v.y) << 8) | (f32_to_unorm8(v.z) << 16) |
-               (f32_to_unorm8(v.w) << 24);
+        // v_cvt_pk_u8_f32 converts an (already integer-valued) float and inserts it as one byte
+        unsigned o = __builtin_amdgcn_cvt_pk_u8_f32(unorm8_code(v.x), 0u, 0u);
+        o = __builtin_amdgcn_cvt_pk_u8_f32(unorm8_code(v.y), 1u, o);
+        o = __builtin_amdgcn_cvt_pk_u8_f32(unorm8_code(v.z), 2u, o);
+        return __builtin_amdgcn_cvt_pk_u8_f32(unorm8_code(v.w), 3u, o);
     }
     RF_DEV static void store(char* row, unsigned xoff, f4 v) { *reinterpret_cast<unsigned*>(row + xoff) = pack(v); }
-    // what a store followed by a load of the next node does to a value
-    RF_DEV static f4 requant(f4 v) { return decode(pack(v)); }
+    // what a store followed by a load of the next node does to a value: decode(pack(v)) without
+    // the trip through the integer byte (the code is the same number either way)
+    RF_DEV static f4 requant(f4 v)
+    {
+        return make_float4(unorm8_code_to_f32(unorm8_code(v.x)), unorm8_code_to_f32(unorm8_code(v.y)),
+                           unorm8_code_to_f32(unorm8_code(v.z)), unorm8_code_to_f32(unorm8_code(v.w)));
+    }
 };
 
 // dense KxK convolution launch (rf_conv.hip), called from launch_ops

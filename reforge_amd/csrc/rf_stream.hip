@@ -556,19 +556,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void stream_kernel(const Strea
 // ---------------------------------------------------------------------------------
 // Host side: op list -> stage list -> kernel instantiation
 // ---------------------------------------------------------------------------------
-static int choose_rows_per_chunk(int rows, int n_strips, int halo_rows, const StreamTuning& tune)
+static int choose_rows_per_chunk(int rows, int n_strips, int halo_rows, int bpp, const StreamTuning& tune)
 {
     if (tune.rows_per_chunk > 0) return tune.rows_per_chunk;
     // aim for ~12 waves per CU over 256 CUs, but keep the re-read of the vertical halo
-    // (2*halo_rows per chunk) under ~10 % of a chunk
-    const int target_waves = 256 * 12;
+    // (2*halo_rows per chunk) under ~10 % of a chunk.  An rgba8 wave-row moves only 256 B and its
+    // kernels are bound by instruction issue, not by HBM: they want twice the waves in flight and
+    // tolerate twice the halo share (3840x2160 rgba8, fused 3-stage chain: 24-row chunks 57.6 us,
+    // 48-row 63.5 us; passthrough 8..16-row chunks 22 us, 36-row 28 us).
+    const bool narrow = bpp == 4;
+    const int target_waves = 256 * (narrow ? 24 : 12);
     int chunks = (target_waves + n_strips - 1) / n_strips;
     if (chunks < 1) chunks = 1;
     int rpc = (rows + chunks - 1) / chunks;
     // measured on MI355X (3840x2160, fused 3-stage chain, 6 halo rows per chunk): 48-row chunks
     // 49 us, 32-row 51 us, 64..90-row 54-56 us, 135-row 62 us -- more, shorter chunks win until
     // the re-read of the vertical halo (2*halo_rows per chunk) passes ~12 % of a chunk
-    int min_rpc = halo_rows > 0 ? 16 * halo_rows : 8;
+    int min_rpc = halo_rows > 0 ? (narrow ? 8 : 16) * halo_rows : 8;
     if (rpc < min_rpc) rpc = min_rpc;
     // large frames: many short chunks beat a few long ones (16384^2 5-stage chain: 64..128-row
     // chunks 76k Mpx/s, 1490-row chunks 67k) -- waves queue behind each other and even out
@@ -599,7 +603,7 @@ static hipError_t launch_stream(Image src, Image dst, const Geom& g, const Strea
     A.n_strips = (g.W + VALID - 1) / VALID;
     const int rows = g.y1 - g.y0;
     if (rows <= 0 || g.W <= 0) return hipSuccess;
-    A.rows_per_chunk = choose_rows_per_chunk(rows, A.n_strips, halo_rows, tune);
+    A.rows_per_chunk = choose_rows_per_chunk(rows, A.n_strips, halo_rows, Px::BPP, tune);
     A.params = params;
     A.n_work = ((A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock) * ((rows + A.rows_per_chunk - 1) / A.rows_per_chunk);
     A.alternate = tune.no_alternate ? 0 : 1;
