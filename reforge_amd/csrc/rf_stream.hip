@@ -1,29 +1,30 @@
 // rf_stream.hip -- the streaming stage-pipeline kernel for gfx950 (CDNA4, wave64): every stencil / point node of the reforge
-// render-graph path.  They replace shaders/*.comp + the per-node vkCmdDispatch of
-// src/vulkan/command.rs:166-242.
+// render-graph path, alone or fused into chains.  It replaces shaders/*.comp + the per-node
+// vkCmdDispatch of src/vulkan/command.rs:166-242.
 //
-// Design (DESIGN.md "Kernels"): the stencil/point nodes are HBM-bound (32 B/px for an
+// Design: the stencil/point nodes are HBM-bound (32 B/px for an
 // rgba32f node), so the kernel is built to move every input row across the fabric
 // once and keep everything else on chip:
 //
 //   * WAVE-AUTONOMOUS STREAMING PIPELINE.  Each 64-lane wave owns a column strip
-//     64 pixels wide (one 16-byte texel per lane: one 1 KiB fully coalesced
-//     global_load_dwordx4 per row) and walks DOWN a chunk of rows.  A node is a short
-//     list of row stages (horizontal taps, vertical taps, point op, 3x3 cross); a
-//     fused chain of nodes is simply a longer list.  Vertical taps keep a rolling
-//     window of rows in VGPRs; horizontal taps exchange the current row between
-//     lanes through a wave-private 1 KiB LDS row (halo = the wave's own edge lanes),
-//     so there is no workgroup barrier anywhere in the kernel -- LDS operations of
-//     one wave execute in order.
-//   * Input rows are prefetched PF rows ahead into a register ring (static indices
-//     via an unrolled loop) so each wave keeps PF KiB in flight.
+//     64 pixels wide (one 16-byte texel per lane: one 1 KiB fully coalesced row segment)
+//     and walks down (or up) a chunk of rows.  A node is a short list of row stages
+//     (horizontal taps, vertical taps, point op, 3x3 cross); a fused chain of nodes is simply
+//     a longer list.  Vertical taps keep a rolling window of rows in VGPRs; horizontal taps
+//     exchange the current row between lanes through a wave-private 1 KiB LDS row (halo = the
+//     wave's own edge lanes), so there is no workgroup barrier anywhere in the kernel -- LDS
+//     operations of one wave execute in order.
+//   * Input rows arrive by LDS-DMA (global_load_lds_dwordx4, no VGPR destination) into a
+//     wave-private ring of PF row slots, PF rows ahead, and are waited for with a COUNTED
+//     s_waitcnt vmcnt (struct Source).  tests/test_isa_invariants.py checks the generated code
+//     for the one-DMA-one-store-per-row contract that count rests on.
 //   * Clamp-to-edge is applied where a stage READS (row index and lane index are
 //     clamped to the image), which is what makes chained stages bit-identical to
 //     running the nodes one full-frame pass at a time.
 //
-// Numerics: every multiply-add is an explicit fmaf in the oracle's tap order; this
-// file is compiled with -ffp-contract=off, so results are bit-identical to
-// oracle/rf_oracle.c for finite inputs.
+// Numerics: every multiply-add is an explicit fmaf in the oracle's tap order (packed two at a
+// time, each half still a single-rounding fma); this file is compiled with -ffp-contract=off,
+// so results are bit-identical to oracle/rf_oracle.c for finite inputs.
 #include "rf_device.h"
 
 namespace rf {
