@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--hipgraph", action="store_true")
     ap.add_argument("--frames-per-step", type=int, default=8,
                     help="frames in the batch one step processes (each frame = one full pass of the graph)")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="frame slots the batch alternates over (reforge's --num-frames; each slot has its own stream and images)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 plumbing check on a one-GPU box: all ranks on device 0, gloo barrier; numbers are meaningless")
@@ -176,21 +178,23 @@ def main():
         flags |= rf.RF_GRAPH_HIPGRAPH
     if world > 1 and args.halo == "overfetch":
         flags |= rf.RF_GRAPH_NO_HALO_XCHG
-    g = rf.Graph(ctx, rf.Config(text), W, H, rf.RF_FORMAT_RGBA32F, num_frames=1, flags=flags)
+    nslots = max(1, args.frames_in_flight)
+    g = rf.Graph(ctx, rf.Config(text), W, H, rf.RF_FORMAT_RGBA32F, num_frames=nslots, flags=flags)
     g.fill_synthetic(seed)                      # inputs resident in HBM before anything is timed
     launches = g.plan.launch_info()
 
-    for _ in range(args.warmup * args.frames_per_step):
-        g.execute(0)
-    g.wait(0)
+    for i in range(args.warmup * args.frames_per_step):
+        g.execute(i % nslots)
+    for sl in range(nslots):
+        g.wait(sl)
 
     # ---- the timed region: exactly K steps ------------------------------------------------
     barrier_sync()
     t0 = time.perf_counter()
     fps = args.frames_per_step
     for _ in range(args.steps):
-        for _ in range(fps):                           # one step = one batch of `fps` frames
-            g.execute(0)
+        for i in range(fps):                           # one step = one batch of `fps` frames
+            g.execute(i % nslots)
     ctx.synchronize()
     barrier_sync()
     elapsed = time.perf_counter() - t0
@@ -256,7 +260,7 @@ def main():
             "frame": "%dx%d" % (W, H), "rows_per_gpu": rows, "format": "rgba32f",
             "frames_per_step": fps, "ms_per_frame": round(ms_per_step / fps, 5),
             "nodes": n_nodes, "launches_per_frame": len(launches), "launches": [l["label"] for l in launches],
-            "fusion": not args.no_fusion, "hipgraph": bool(args.hipgraph),
+            "fusion": not args.no_fusion, "hipgraph": bool(args.hipgraph), "frames_in_flight": nslots,
             "parallelism": "1 GPU" if world == 1 else "row strips x%d, halo=%s" % (world, args.halo),
         },
         "roofline": roofline,

@@ -629,7 +629,10 @@ template <int R> static typename StVTap<R>::Params vtap_params(const Op& op)
 static StGrade::Params grade_params(const Op& op) { return {op.slope, op.offset, op.saturation}; }
 static StCross3::Params cross_params(const Op& op) { return {op.wc, op.ws}; }
 
-constexpr int PF_DEFAULT = 4;
+#ifndef RF_PF_DEFAULT
+#define RF_PF_DEFAULT 4
+#endif
+constexpr int PF_DEFAULT = RF_PF_DEFAULT;   // rows in flight per wave (8 was measured slower, 3/5/6 see DESIGN.md)
 
 template <class Px> static hipError_t run_passthrough(Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
 {
