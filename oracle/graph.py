@@ -288,12 +288,22 @@ def _remap(name, mapping):
     return name
 
 
-def reusable_image_remapping(layers, infos):
-    """pipeline_graph.rs:358-427."""
+def reusable_image_remapping(layers, infos, literal=False):
+    """pipeline_graph.rs:358-427, with one deliberate difference: "is this allocation still
+    used through a remap" follows the alias chain to its end.  The reference tests ONE level
+    (images_have_remap, :364-369: `image_reuse.get(image_name) == name`), so an image read
+    through a two-level alias -- a point op written in place (X:image) on an image that was
+    itself a recycled allocation -- counts as free while a later node still reads it; the next
+    output then lands on the image its own node reads and a stencil runs in place (undefined
+    output in the reference).  Following the chain only ever keeps an image allocated longer:
+    every plan the reference gets right is unchanged.  literal=True gives the reference's own
+    result (tests/test_config_plan.py shows a graph where the two differ)."""
     free_images, images, reuse = [], [], {}
 
     def has_remap(name, imgs):
-        return any(reuse.get(img) == name for img, _ in imgs)
+        if literal:
+            return any(reuse.get(img) == name for img, _ in imgs)
+        return any(img in reuse and _remap(img, reuse) == name for img, _ in imgs)
 
     def node_uses(info, name):
         return (any(n == name for n, _ in info.input_images) or

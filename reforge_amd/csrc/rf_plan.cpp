@@ -245,11 +245,21 @@ static std::map<std::string, std::string> reusable_image_remapping(
     std::set<std::string> images;
     std::map<std::string, std::string> reuse;
 
+    // "Found a remap of the allocation in use" (:364-369).  The reference looks ONE level up
+    // (image_reuse.get(image_name) == name); this follows the alias chain to the allocation.
+    // With one level, an image read through a two-level alias (a point op written in place on
+    // an image that is itself a recycled allocation) counts as free while a later node still
+    // reads it, and that node's output lands on the image it reads: a stencil in place,
+    // undefined output in the reference.  Following the chain only keeps an image allocated
+    // longer; every plan the reference gets right is unchanged (tests/test_config_plan.py).
+    auto root_of = [&](const std::string& n) {
+        const std::string* cur = &n;
+        for (auto it = reuse.find(*cur); it != reuse.end(); it = reuse.find(*cur)) cur = &it->second;
+        return *cur;
+    };
     auto has_remap = [&](const std::string& name, const std::vector<std::pair<std::string, int>>& imgs) {
-        for (const auto& im : imgs) {
-            auto it = reuse.find(im.first);
-            if (it != reuse.end() && it->second == name) return true;
-        }
+        for (const auto& im : imgs)
+            if (reuse.count(im.first) && root_of(im.first) == name) return true;
         return false;
     };
     auto node_uses = [&](const PipelineInfo& node, const std::string& name) {
