@@ -109,6 +109,9 @@ CASES = [
     (util.DIAMOND, 2, True, True),
     (util.CHAIN3, 3, True, True),
 ]
+# graphs nobody wrote by hand (tests/util.py::random_graph), exchange and over-fetch schedules
+for _seed, _world, _xchg, _fused in ((3001, 2, True, True), (3002, 3, True, False), (3003, 2, False, True), (3004, 2, True, True)):
+    CASES.append((util.random_graph(np.random.RandomState(_seed)), _world, _xchg, _fused))
 
 
 @pytest.mark.parametrize("text,world,exchange,fused", CASES)

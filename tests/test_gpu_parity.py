@@ -392,57 +392,47 @@ def test_exchange_mode_needs_a_communicator():
 
 
 # ---- random graphs --------------------------------------------------------------------------
-def _random_graph(rng):
-    """A random pipeline config: a chain of 1..6 nodes (optionally one fork/join through a
-    `combination`), node types and parameters drawn at random, some point ops written in place
-    (`name:image`).  Names are unique, two characters or more (config_grammar.lalrpop:81)."""
-    kinds = ["passthrough", "gaussian5", "gaussian9", "gaussian", "colour_grade", "grade_inplace", "sharpen", "conv2d"]
-    decl, names = [], []
-
-    def node(i):
-        kind = kinds[rng.randint(len(kinds))]
-        name = "n%02d" % i
-        if kind == "passthrough":
-            decl.append("%s: passthrough {}" % name)
-        elif kind in ("gaussian5", "gaussian9"):
-            decl.append("%s: %s { sigma: %.2f }" % (name, kind, rng.uniform(0.4, 3.0)))
-        elif kind == "gaussian":
-            decl.append("%s: gaussian { sigma: %.2f, radius: %d }" % (name, rng.uniform(0.5, 4.0), rng.randint(0, 8)))
-        elif kind in ("colour_grade", "grade_inplace"):
-            decl.append("%s: colour_grade { slope: %.2f, offset: %.3f, saturation: %.2f }" % (name, rng.uniform(0.5, 1.5), rng.uniform(-0.1, 0.1), rng.uniform(0.0, 2.0)))
-        elif kind == "sharpen":
-            decl.append("%s: sharpen { amount: %.2f }" % (name, rng.uniform(0.0, 1.5)))
-        else:
-            decl.append("%s: conv2d { ksize: %d, sigma: %.2f }" % (name, (3, 5, 9)[rng.randint(3)], rng.uniform(0.6, 2.0)))
-        return name + (":image" if kind == "grade_inplace" else "")
-
-    n = rng.randint(1, 7)
-    chain = [node(i) for i in range(n)]
-    lines = []
-    if n >= 3 and rng.rand() < 0.35:
-        # fork after the first node, two branches, joined by a combination
-        cut = rng.randint(1, n - 1)
-        left, right = chain[1:cut + 1], chain[cut + 1:]
-        head = chain[0].split(":")[0]            # the forked image must be materialised: no in-place head
-        lines.append("input -> %s" % " -> ".join([head] + left + ["mx:input_image0"]))
-        lines.append("%s -> %s" % (head, " -> ".join(right + ["mx:input_image1"])))
-        lines.append("mx -> output")
-        decl.append("mx: combination { mix: %.2f }" % rng.uniform(0.0, 1.0))
-    else:
-        lines.append("input -> %s -> output" % " -> ".join(chain))
-    return "\n".join(lines + decl)
-
-
 @pytest.mark.parametrize("seed", range(24))
 def test_random_graphs(ctx, seed):
     """Planner (layering, aliasing, in-place point ops, fusion with greedy splitting, fork/join on
     side streams) and kernels together, on graphs nobody wrote by hand: fused, unfused and
     hipGraph execution all equal the oracle, both formats."""
     rng = np.random.RandomState(1000 + seed)
-    text = _random_graph(rng)
+    text = util.random_graph(rng)
     W, H = int(rng.randint(1, 200)), int(rng.randint(1, 120))
     for fmt in (util.F32, util.U8):
         x = util.synthetic(W, H, fmt, seed=seed)
         want = util.run_oracle(text, x)
         for flags in (0, NF, rf.RF_GRAPH_HIPGRAPH):
             util.assert_same(util.run_hip(ctx, text, x, flags=flags), want, "seed %d flags %d %dx%d\n%s" % (seed, flags, W, H, text))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_graphs_as_row_strips(seed, monkeypatch):
+    """Random graphs again, cut into 2..4 row strips in over-fetch mode (every rank's context on
+    GPU 0, no communicator) and, on one rank, through the three-part interior/boundary launch of
+    exchange mode (RF_FORCE_SPLIT): the cumulative-halo schedule of arbitrary graphs."""
+    rng = np.random.RandomState(2000 + seed)
+    text = util.random_graph(rng)
+    W, H, world = int(rng.randint(8, 160)), int(rng.randint(70, 140)), int(rng.randint(2, 5))
+    flags = (0, NF)[seed & 1]
+    ghost = rf.Plan(rf.Config(text), flags).halo_schedule(False)[3]
+    if ghost > H // world:
+        pytest.skip("strips shorter than the cumulative halo")
+    for fmt in (util.F32, util.U8):
+        want = util.run_oracle(text, pixel.fill_synthetic(W, H, fmt, 0x5EED0000 + seed))
+        strips = []
+        for rank in range(world):
+            c = rf.Context(0, rank, world, None)
+            g = rf.Graph(c, rf.Config(text), W, H, fmt, flags=flags | rf.RF_GRAPH_NO_HALO_XCHG)
+            g.fill_synthetic(0x5EED0000 + seed)
+            g.execute(); g.wait()
+            strips.append(g.download_raw())
+            g.close()
+            c.close()
+        util.assert_same(np.concatenate(strips, axis=0), want, "strips seed=%d world=%d flags=%d\n%s" % (seed, world, flags, text))
+    monkeypatch.setenv("RF_FORCE_SPLIT", "1")
+    c = rf.Context(0)
+    x = util.synthetic(W, H, util.F32, seed=seed)
+    util.assert_same(util.run_hip(c, text, x, flags=flags), util.run_oracle(text, x), "forced split seed=%d\n%s" % (seed, text))
+    c.close()

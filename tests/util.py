@@ -93,3 +93,44 @@ def assert_same(got, want, what=""):
 
 def synthetic(W, H, fmt, seed=0x5EED0002):
     return pixel.fill_synthetic(W, H, fmt, seed)
+
+
+def random_graph(rng):
+    """A random pipeline config: a chain of 1..6 nodes (optionally one fork/join through a
+    `combination`), node types and parameters drawn at random, some point ops written in place
+    (`name:image`).  Names are unique, two characters or more (config_grammar.lalrpop:81)."""
+    kinds = ["passthrough", "gaussian5", "gaussian9", "gaussian", "colour_grade", "grade_inplace", "sharpen", "conv2d"]
+    decl, names = [], []
+
+    def node(i):
+        kind = kinds[rng.randint(len(kinds))]
+        name = "n%02d" % i
+        if kind == "passthrough":
+            decl.append("%s: passthrough {}" % name)
+        elif kind in ("gaussian5", "gaussian9"):
+            decl.append("%s: %s { sigma: %.2f }" % (name, kind, rng.uniform(0.4, 3.0)))
+        elif kind == "gaussian":
+            decl.append("%s: gaussian { sigma: %.2f, radius: %d }" % (name, rng.uniform(0.5, 4.0), rng.randint(0, 8)))
+        elif kind in ("colour_grade", "grade_inplace"):
+            decl.append("%s: colour_grade { slope: %.2f, offset: %.3f, saturation: %.2f }" % (name, rng.uniform(0.5, 1.5), rng.uniform(-0.1, 0.1), rng.uniform(0.0, 2.0)))
+        elif kind == "sharpen":
+            decl.append("%s: sharpen { amount: %.2f }" % (name, rng.uniform(0.0, 1.5)))
+        else:
+            decl.append("%s: conv2d { ksize: %d, sigma: %.2f }" % (name, (3, 5, 9)[rng.randint(3)], rng.uniform(0.6, 2.0)))
+        return name + (":image" if kind == "grade_inplace" else "")
+
+    n = rng.randint(1, 7)
+    chain = [node(i) for i in range(n)]
+    lines = []
+    if n >= 3 and rng.rand() < 0.35:
+        # fork after the first node, two branches, joined by a combination
+        cut = rng.randint(1, n - 1)
+        left, right = chain[1:cut + 1], chain[cut + 1:]
+        head = chain[0].split(":")[0]            # the forked image must be materialised: no in-place head
+        lines.append("input -> %s" % " -> ".join([head] + left + ["mx:input_image0"]))
+        lines.append("%s -> %s" % (head, " -> ".join(right + ["mx:input_image1"])))
+        lines.append("mx -> output")
+        decl.append("mx: combination { mix: %.2f }" % rng.uniform(0.0, 1.0))
+    else:
+        lines.append("input -> %s -> output" % " -> ".join(chain))
+    return "\n".join(lines + decl)
