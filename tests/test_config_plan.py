@@ -257,3 +257,63 @@ def test_alias_chain_is_followed_when_freeing_images():
         i2 = og.synthesize(og.parse_config(text))
         l2 = og.order_by_execution(i2)
         assert og.reusable_image_remapping(l2, i2) == og.reusable_image_remapping(l2, i2, literal=True)
+
+
+def test_parser_differential_fuzz():
+    """Token soup through both parsers (the C++ one behind the ABI and the Python restatement of
+    config_grammar.lalrpop): they accept and reject the same texts and build the same graph --
+    and the C++ one survives everything."""
+    import numpy as np
+    vocab = ["input", "output", "aa", "bb", "cc", "blur", "a", "x1", "gaussian5", "sharpen", "colour_grade", "->", "->", "->", ":",
+             "{", "}", "{}", ",", "sigma", "amount", "1.5", "2", "-0.5", "-3", "true", "false", "1e3", "// note\n", "/* c */", "\n",
+             "\n", " ", "  ", "\t", "image", "input_image", "_x", "a-b", "-", ">", "*/", "/*", "é", "0", ".5", "5."]
+    rng = np.random.RandomState(77)
+    idents = ["aa", "bb", "cc", "blur", "x1", "_x", "a-b", "gaussian5", "sharpen", "grade", "input_image", "image", "n0"]
+    values = ["1.5", "2", "-0.5", "true", "false", "0", "10.25", "-3", "1e3", ".5"]
+
+    def pick(xs):
+        return xs[rng.randint(len(xs))]
+
+    def well_formed():
+        exprs = []
+        for _ in range(rng.randint(1, 4)):
+            kind = rng.randint(4)
+            if kind == 0:
+                mid = [pick(idents) + (":" + pick(idents) if rng.rand() < 0.25 else "") for _ in range(rng.randint(1, 4))]
+                exprs.append(pick(["input", pick(idents)]) + " -> " + " -> ".join(mid) + pick([" -> output", " -> output", ""]))
+            elif kind == 1:
+                kv = ["%s: %s" % (pick(idents), pick(values)) for _ in range(rng.randint(0, 3))]
+                exprs.append("%s: %s %s" % (pick(idents), pick(idents), "{ " + ", ".join(kv) + " }" if kv else "{}"))
+            elif kind == 2:
+                exprs.append(pick(["// a note", "/* block */", "/* two\nlines */"]))
+            else:
+                exprs.append("input -> aa -> bb -> output")
+        return pick(["\n", "\n\n", " \n"]).join(exprs)
+
+    accepted = 0
+    for i in range(1500):
+        if i % 4 == 3:
+            n = rng.randint(1, 14)
+            text = "".join(pick(vocab) + ("" if rng.rand() < 0.3 else " ") for _ in range(n))
+        else:
+            text = well_formed()
+            for _ in range(rng.randint(0, 3) if rng.rand() < 0.5 else 0):     # a few token-level mutations
+                at = rng.randint(len(text) + 1)
+                text = text[:at] + pick(vocab) + text[at + rng.randint(0, 3):]
+        try:
+            ora = og.parse_config(text, True)
+        except og.ConfigError:
+            ora = None
+        try:
+            prod = rf.Config(text, True).nodes()
+        except rf.RfError as e:
+            assert e.status == 2, text
+            prod = None
+        assert (ora is None) == (prod is None), repr(text)
+        if ora is not None:
+            accepted += 1
+            assert set(prod) == set(ora.graph_pipelines), repr(text)
+            for name, node in prod.items():
+                assert node["inputs"] == ora.graph_pipelines[name]["inputs"] and node["outputs"] == ora.graph_pipelines[name]["outputs"], repr(text)
+                assert node["type"] == ora.type_of(name) and node["params"] == ora.params_of(name), repr(text)
+    assert accepted > 50
