@@ -317,3 +317,24 @@ def test_parser_differential_fuzz():
                 assert node["inputs"] == ora.graph_pipelines[name]["inputs"] and node["outputs"] == ora.graph_pipelines[name]["outputs"], repr(text)
                 assert node["type"] == ora.type_of(name) and node["params"] == ora.params_of(name), repr(text)
     assert accepted > 50
+
+
+def test_planner_matches_restatement_on_random_graphs():
+    """300 generated graphs (chains, forks, in-place point ops): the C++ planner and the Python
+    restatement agree on layers, aliases, allocated images and every resolved name; no plan lets
+    a stencil write the image it reads; fused plans cover every node exactly once."""
+    import numpy as np
+    for seed in range(300):
+        text = util.random_graph(np.random.RandomState(5000 + seed))
+        p, layers, reuse = plans(text)
+        assert p.layers() == layers and p.aliases() == reuse, text
+        assert p.images() == og.GraphOracle(text, 4, 4, util.F32).allocated_images(), text
+        for info in p.launch_info():
+            if len(info["inputs"]) == 1 and info["radius"] > 0:
+                assert p.resolve(info["inputs"][0]) != p.resolve(info["output"]), text
+        fused = rf.Plan(rf.Config(text), 0)
+        members = [m for info in fused.launch_info() for m in info["members"]]
+        assert sorted(members) == sorted(rf.Config(text).nodes()), text
+        for info in fused.launch_info():
+            if info["radius"] > 0 and len(info["inputs"]) == 1:
+                assert fused.resolve(info["inputs"][0]) != fused.resolve(info["output"]), text
