@@ -557,31 +557,43 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void stream_kernel(const Strea
 // ---------------------------------------------------------------------------------
 // Host side: op list -> stage list -> kernel instantiation
 // ---------------------------------------------------------------------------------
-static int choose_rows_per_chunk(int rows, int n_strips, int halo_rows, int bpp, const StreamTuning& tune)
+static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo_rows, int bpp, const StreamTuning& tune)
 {
     if (tune.rows_per_chunk > 0) return tune.rows_per_chunk;
-    // aim for ~12 waves per CU over 256 CUs, but keep the re-read of the vertical halo
-    // (2*halo_rows per chunk) under ~10 % of a chunk.  An rgba8 wave-row moves only 256 B and its
-    // kernels are bound by instruction issue, not by HBM: they want twice the waves in flight and
-    // tolerate twice the halo share (3840x2160 rgba8, fused 3-stage chain: 24-row chunks 57.6 us,
-    // 48-row 63.5 us; passthrough 8..16-row chunks 22 us, 36-row 28 us).
-    const bool narrow = bpp == 4;
-    const int target_waves = 256 * (narrow ? 24 : 12);
-    int chunks = (target_waves + n_strips - 1) / n_strips;
-    if (chunks < 1) chunks = 1;
-    int rpc = (rows + chunks - 1) / chunks;
-    // measured on MI355X (3840x2160, fused 3-stage chain, 6 halo rows per chunk): 48-row chunks
-    // 49 us, 32-row 51 us, 64..90-row 54-56 us, 135-row 62 us -- more, shorter chunks win until
-    // the re-read of the vertical halo (2*halo_rows per chunk) passes ~12 % of a chunk
-    int min_rpc = halo_rows > 0 ? (narrow ? 8 : 16) * halo_rows : 8;
-    if (rpc < min_rpc) rpc = min_rpc;
-    // large frames: many short chunks beat a few long ones (16384^2 5-stage chain: 64..128-row
-    // chunks 76k Mpx/s, 1490-row chunks 67k) -- waves queue behind each other and even out
-    const int cap = min_rpc > 128 ? min_rpc : 128;
-    if (rpc > cap) rpc = cap;
+    // A wave walks its chunk row by row (0.2-0.5 us per row), so a small frame is bound by the
+    // LENGTH of the walks, not by HBM: take the shortest chunks whose workgroups are all resident
+    // at once (`slots` = CUs x workgroups per CU of this kernel: one round, no tail).  A large
+    // frame does not fit one round at any sensible height; there the chunk height is capped,
+    // because more and shorter walks stream better, down to where the halo rows a chunk
+    // recomputes (2*halo_rows) start to cost more than they hide.  Fitted to scripts/rpc_sweep.py
+    // on MI355X, 720p..8K, both formats (best chunk heights: passthrough/sharpen 8-12 at every
+    // size for rgba32f; 3-stage chain 12/16/24/24/24; gaussian9 12/24/24/32/32; 5-stage chain
+    // 12/24/32/64/96 -- e.g. the 5-stage chain at 1080p 34 us with 24-row chunks, 66 us with 112):
+    const int h = halo_rows;
+    const bool narrow = bpp == 4;                    // rgba8: bound by VALU issue, halo recompute costs more
+    const long fit = ((long)rows * strip_groups + slots - 1) / slots;
+    const int lo = h > 4 ? 2 * h : 8;
+    const int hi = narrow ? (12 * h > 16 ? 12 * h : 16) : (h <= 4 ? (8 * h > 8 ? 8 * h : 8) : 16 * h);   // 5-stage chain (h = 7) at 16384^2: 128-row 2.03 ms, 96-row 2.08, 84-row 2.12
+    // a frame that fits ONE round at up to twice the cap keeps the single round (4K 3-stage chain:
+    // 36-row chunks = 1020 workgroups on 1024 slots, 194.6k Mpx/s; 24-row 191k; 44-row 180k)
+    int rpc = (int)(fit < lo ? lo : (fit > 2 * hi ? hi : fit));
+    rpc = (rpc + 3) & ~3;
     if (rpc > rows) rpc = rows;
     if (rpc < 1) rpc = 1;
     return rpc;
+}
+
+// workgroups of this kernel the whole chip holds at once
+template <class Px, int PF, class... S> static int resident_workgroups()
+{
+    static int slots = 0;
+    if (slots == 0) {
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_kernel<Px, PF, S...>, 64 * kWavesPerBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = per_cu * (cus > 0 ? cus : 256);
+    }
+    return slots;
 }
 
 template <class Px, int PF, class... S>
@@ -604,7 +616,8 @@ static hipError_t launch_stream(Image src, Image dst, const Geom& g, const Strea
     A.n_strips = (g.W + VALID - 1) / VALID;
     const int rows = g.y1 - g.y0;
     if (rows <= 0 || g.W <= 0) return hipSuccess;
-    A.rows_per_chunk = choose_rows_per_chunk(rows, A.n_strips, halo_rows, Px::BPP, tune);
+    A.rows_per_chunk = choose_rows_per_chunk(rows, (A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock, resident_workgroups<Px, PF, S...>(),
+                                             halo_rows, Px::BPP, tune);
     A.params = params;
     A.n_work = ((A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock) * ((rows + A.rows_per_chunk - 1) / A.rows_per_chunk);
     A.alternate = tune.no_alternate ? 0 : 1;
