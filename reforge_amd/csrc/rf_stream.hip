@@ -159,7 +159,9 @@ template <int R> struct StHTap {
     struct Params { float w[R + 1]; };
     template <class Px> using State = NoState;
     // as the FIRST stage of an rgba32f pipeline the taps come straight from the DMA ring
-    template <class Px> using Feed = typename std::conditional<Px::QUANT, OwnFeed<Px>, TapFeed<R>>::type;
+    // (up to radius 7: beyond that 2R+1 prefetched taps crowd the vertical window out of the register
+    // file -- radius 10 at 4K: 209 us with the prefetch, 119 us through the LDS exchange)
+    template <class Px> using Feed = typename std::conditional<(Px::QUANT || R > 7), OwnFeed<Px>, TapFeed<R>>::type;
     RF_DEV static f4 from_taps(const Params& p, const TapFeed<R>& f)
     {
         f4 acc = f4_zero();
