@@ -193,8 +193,10 @@ template <int R> struct StVTap {
     template <class Px> using Feed = OwnFeed<Px>;
     template <class Px, bool REV> RF_DEV static void advance(const Params& p, State<Px>& s, const Lane&, f4*, f4 v, bool real, bool first, bool emit, f4& out)
     {
-        const int pushes = first ? 2 * R + 1 : 1;
-        for (int q = 0; q < pushes; ++q) {
+        if (first) {                     // the first row primes the whole window (it is always a real row)
+#pragma unroll
+            for (int i = 0; i <= 2 * R; ++i) s.win[i] = v;
+        } else {
 #pragma unroll
             for (int i = 0; i < 2 * R; ++i) s.win[i] = s.win[i + 1];
             if (real) s.win[2 * R] = v;
