@@ -575,7 +575,11 @@ static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo
     // 12/24/32/64/96 -- e.g. the 5-stage chain at 1080p 34 us with 24-row chunks, 66 us with 112):
     const int h = halo_rows;
     const bool narrow = bpp == 4;                    // rgba8: bound by VALU issue, halo recompute costs more
-    const long fit = ((long)rows * strip_groups + slots - 1) / slots;
+    // shortest chunks with every workgroup resident: at most slots / strip_groups chunks (a
+    // 31-tap gaussian at 4K, one workgroup per CU: 9 chunks x 29 groups = 261 workgroups on 256
+    // slots ran two rounds, 457 us; 8 chunks = 232 workgroups, 271 us)
+    const int max_chunks = slots / strip_groups > 1 ? slots / strip_groups : 1;
+    const long fit = (rows + max_chunks - 1) / max_chunks;
     const int lo = h > 4 ? 2 * h : 8;
     const int hi = narrow ? (12 * h > 16 ? 12 * h : 16) : (h <= 4 ? (8 * h > 8 ? 8 * h : 8) : 16 * h);   // 5-stage chain (h = 7) at 16384^2: 128-row 2.03 ms, 96-row 2.08, 84-row 2.12
     // a frame that fits ONE round at up to twice the cap keeps the single round (4K 3-stage chain:
