@@ -586,6 +586,18 @@ static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo
     // 36-row chunks = 1020 workgroups on 1024 slots, 194.6k Mpx/s; 24-row 191k; 44-row 180k)
     int rpc = (int)(fit < lo ? lo : (fit > 2 * hi ? hi : fit));
     rpc = (rpc + 3) & ~3;
+    // a few rounds: use the rounds in full -- as many chunks as that number of rounds holds
+    {
+        const int chunks0 = (rows + rpc - 1) / rpc;
+        const long rounds = ((long)chunks0 * strip_groups + slots - 1) / slots;
+        if (rounds >= 2 && rounds <= 4) {
+            const long chunks = rounds * slots / strip_groups;
+            if (chunks > chunks0) {
+                int r2 = (int)((rows + chunks - 1) / chunks);
+                if (r2 >= lo) rpc = r2;
+            }
+        }
+    }
     if (rpc > rows) rpc = rows;
     if (rpc < 1) rpc = 1;
     return rpc;
