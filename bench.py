@@ -234,6 +234,9 @@ def main():
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": load_traffic(args.workload + ("_unfused" if args.no_fusion else ""))}
+    each = sorted(g.time_each_frame(max(20, min(args.steps * fps, 200))))     # median and min per frame
+    frame_events = {"median_ms": round(each[len(each) // 2], 5), "min_ms": round(each[0], 5), "frames": len(each),
+                    "note": "hipEvent pair per frame on the frame's stream (adds a marker packet per frame)"}
     roofline["kernel"] = dom_label
     roofline["launch_ms"] = round(dom_ms, 5)
     roofline["algorithmic_bytes_per_px"] = 32 if roofline["bound"] == "hbm" else None
@@ -267,6 +270,7 @@ def main():
         "chain_hbm_frac": round(chain_frac, 4),
         "chain_algorithmic_bytes_per_px": n_nodes * 2 * BPP,
         "launch_ms": {k: round(v, 5) for k, v in per_launch},
+        "frame_ms_events": frame_events,
     }
     if args.workload == "conv31_8k" and world == 1:
         # both large-K kernels, timed the same way (the default is the VALU one; RF_CONV_PATH=2 selects MFMA)

@@ -256,6 +256,10 @@ rf_status rf_graph_time_launch(rf_graph* g, int launch, int iters, float* avg_ms
  * the stream that launch runs on: avg_ms[k] = average duration of launch k (execution
  * order); n = capacity of avg_ms (>= rf_plan_num_launches) */
 rf_status rf_graph_time_launches(rf_graph* g, int iters, float* avg_ms, int n);
+/* `iters` whole frames on slot 0, a hipEvent pair around EACH frame: ms_each[i] = GPU
+ * milliseconds of frame i (SURVEY.md 8d asks for median and min next to the mean; the
+ * marker packets cost ~2 us per frame, so the mean of these is above rf_graph_time_frames) */
+rf_status rf_graph_time_each_frame(rf_graph* g, int iters, float* ms_each);
 /* one-rank RCCL round trip (communicator of world 1, grouped send+recv to self of
  * `bytes` bytes on `device`): librccl loads and is called with the right ABI */
 rf_status rf_comm_selftest(int device, size_t bytes);

@@ -110,6 +110,7 @@ SIGNATURES = {
     "rf_graph_node_times": (_i, [_vp, _i, C.POINTER(_cp), _pf, _pi]),
     "rf_graph_times_string": (_i, [_vp, _i, _cp, _sz]),
     "rf_graph_time_frames": (_i, [_vp, _i, _pf]),
+    "rf_graph_time_each_frame": (_i, [_vp, _i, _pf]),
     "rf_graph_time_launch": (_i, [_vp, _i, _i, _pf]),
     "rf_graph_time_launches": (_i, [_vp, _i, _pf, _i]),
     "rf_comm_selftest": (_i, [_i, _sz]),

@@ -899,6 +899,31 @@ extern "C" rf_status rf_graph_time_frames(rf_graph* g, int iters, float* total_m
     return st;
 }
 
+extern "C" rf_status rf_graph_time_each_frame(rf_graph* g, int iters, float* ms_each)
+{
+    FrameSlot* f;
+    rf_status st = slot_of(g, 0, &f, "rf_graph_time_each_frame");
+    if (st != RF_OK) return st;
+    if (iters < 1 || !ms_each) return fail(RF_ERR_INVALID, "rf_graph_time_each_frame: bad argument");
+    std::vector<hipEvent_t> ev(2 * (size_t)iters, nullptr);
+    auto body = [&]() -> rf_status {
+        for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+        for (int i = 0; i < iters; ++i) {
+            HIP_TRY(hipEventRecord(ev[2 * (size_t)i], f->stream));
+            rf_status s2 = submit_frame(g, *f);
+            if (s2 != RF_OK) return s2;
+            HIP_TRY(hipEventRecord(ev[2 * (size_t)i + 1], f->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(f->stream));
+        for (int i = 0; i < iters; ++i) HIP_TRY(hipEventElapsedTime(&ms_each[i], ev[2 * (size_t)i], ev[2 * (size_t)i + 1]));
+        return RF_OK;
+    };
+    st = body();
+    for (auto e : ev)
+        if (e) (void)hipEventDestroy(e);
+    return st;
+}
+
 extern "C" rf_status rf_graph_time_launch(rf_graph* g, int launch, int iters, float* avg_ms)
 {
     FrameSlot* f;

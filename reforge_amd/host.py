@@ -320,6 +320,12 @@ class Graph:
         _check(lib().rf_graph_time_frames(self._h, iters, C.byref(ms)), "rf_graph_time_frames")
         return ms.value
 
+    def time_each_frame(self, iters):
+        """GPU milliseconds of each of `iters` frames (hipEvent pair per frame)."""
+        ms = (C.c_float * iters)()
+        _check(lib().rf_graph_time_each_frame(self._h, iters, ms), "rf_graph_time_each_frame")
+        return list(ms)
+
     def time_launch(self, launch, iters):
         ms = C.c_float()
         _check(lib().rf_graph_time_launch(self._h, launch, iters, C.byref(ms)), "rf_graph_time_launch")
