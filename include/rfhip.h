@@ -141,6 +141,10 @@ const char* rf_plan_launch_input(const rf_plan* plan, int i, int k);
 const char* rf_plan_launch_output(const rf_plan* plan, int i);
 /* rows a launch reads above/below the rows it writes (sum of its stencil radii) */
 int         rf_plan_launch_radius(const rf_plan* plan, int i);
+/* 1 if the launch's layer runs in plan order on one stream: one of its launches writes an image
+ * another launch of the layer reads or writes (an in-place point op beside a second consumer).
+ * The reference runs such a layer concurrently (command.rs:194-240), a data race. */
+int         rf_plan_launch_serial(const rf_plan* plan, int i);
 /* [host] ghost-row schedule of a row-strip partition (new: SURVEY.md 8e).
  *   exchange != 0: before launch i its input's need_src[i] = radius edge rows are
  *                  exchanged with the neighbour ranks; need_dst[i] = 0.

@@ -77,6 +77,7 @@ SIGNATURES = {
     "rf_plan_launch_input": (_cp, [_vp, _i, _i]),
     "rf_plan_launch_output": (_cp, [_vp, _i]),
     "rf_plan_launch_radius": (_i, [_vp, _i]),
+    "rf_plan_launch_serial": (_i, [_vp, _i]),
     "rf_plan_halo_schedule": (_i, [_vp, _i, _pi, _pi, _i, _pi, _pi]),
     "rf_registry_num_types": (_i, []),
     "rf_registry_type_name": (_cp, [_i]),

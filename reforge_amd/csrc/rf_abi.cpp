@@ -259,6 +259,11 @@ extern "C" int rf_plan_launch_radius(const rf_plan* p, int i)
     const LaunchDesc* l = launch_at(p, i);
     return l ? l->radius : -1;
 }
+extern "C" int rf_plan_launch_serial(const rf_plan* p, int i)
+{
+    const LaunchDesc* l = launch_at(p, i);
+    return l ? (l->serial ? 1 : 0) : -1;
+}
 extern "C" rf_status rf_plan_halo_schedule(const rf_plan* p, int exchange, int* need_src, int* need_dst, int n,
                                            int* need_input, int* ghost)
 {

@@ -210,9 +210,12 @@ rf_status issue_frame(rf_graph* g, FrameSlot& f, bool timers)
         size_t end = li;
         while (end < g->launches.size() && g->launches[end].layer == g->launches[li].layer) ++end;
         const size_t m = end - li;
-        if (m == 1) {
-            rf_status st = run_launch(g, f, li, f.stream, timers);
-            if (st != RF_OK) return st;
+        if (m == 1 || g->launches[li].serial) {
+            // one launch, or a layer with an intra-layer hazard (LaunchDesc::serial): plan order, one stream
+            for (size_t j = 0; j < m; ++j) {
+                rf_status st = run_launch(g, f, li + j, f.stream, timers);
+                if (st != RF_OK) return st;
+            }
         } else {
             HIP_TRY(hipEventRecord(f.fork, f.stream));
             for (size_t j = 0; j < m; ++j) {

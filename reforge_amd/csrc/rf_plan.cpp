@@ -501,6 +501,22 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
             out.push_back(L);
         }
     }
+    // Intra-layer hazards.  The reference runs the nodes of a layer concurrently behind one
+    // barrier (command.rs:226-240) and aliases a point op written in place (X:image) onto its
+    // input even when another node of the same layer reads that image: a data race there.  Here
+    // such a layer runs in plan order -- name order, as the oracle executes it -- so the result
+    // is defined: the launches that sort before the in-place writer see the original image.
+    for (size_t a = 0; a < out.size(); ++a) {
+        for (size_t b = 0; b < out.size(); ++b) {
+            if (a == b || out[a].layer != out[b].layer) continue;
+            bool touches = out[a].dst == out[b].dst;
+            for (const auto& sname : out[b].src) touches = touches || sname == out[a].dst;
+            if (touches) out[a].serial = out[b].serial = true;
+        }
+    }
+    for (size_t a = 0; a < out.size(); ++a)      // the whole layer, not only the pair
+        for (size_t b = 0; b < out.size(); ++b)
+            if (out[a].layer == out[b].layer && out[b].serial) out[a].serial = true;
     return true;
 }
 

@@ -88,6 +88,8 @@ struct LaunchDesc {
     int radius = 0;                 // vertical halo read beyond the rows written
     int need_src = 0;               // ghost rows of src the launch reads (multi-rank)
     int need_dst = 0;               // ghost rows of dst the launch must also produce (over-fetch mode)
+    bool serial = false;            // its layer holds a launch that writes an image another launch of the layer touches: the
+                                    // layer runs in plan (name) order on one stream instead of concurrently
 };
 
 // planned units -> launches; validates what the kernels can execute (one input image,

@@ -149,7 +149,8 @@ class Plan:
                  "members": [_s(L.rf_plan_launch_member(h, i, k)) for k in range(L.rf_plan_launch_num_members(h, i))],
                  "inputs": [_s(L.rf_plan_launch_input(h, i, k)) for k in range(L.rf_plan_launch_num_inputs(h, i))],
                  "output": _s(L.rf_plan_launch_output(h, i)),
-                 "radius": L.rf_plan_launch_radius(h, i)} for i in range(L.rf_plan_num_launches(h))]
+                 "radius": L.rf_plan_launch_radius(h, i),
+                 "serial": bool(L.rf_plan_launch_serial(h, i))} for i in range(L.rf_plan_num_launches(h))]
 
     def halo_schedule(self, exchange=True):
         """(need_src[], need_dst[], need_input, ghost) of a row-strip partition."""

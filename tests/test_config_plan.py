@@ -338,3 +338,28 @@ def test_planner_matches_restatement_on_random_graphs():
         for info in fused.launch_info():
             if info["radius"] > 0 and len(info["inputs"]) == 1:
                 assert fused.resolve(info["inputs"][0]) != fused.resolve(info["output"]), text
+
+
+IN_PLACE_BESIDE_A_READER = """
+input -> n00 -> n01 -> mx:input_image0
+n00 -> n02:image -> mx:input_image1
+mx -> output
+n00: gaussian5 { sigma: 1.54 }
+n01: gaussian { sigma: 0.94, radius: 6 }
+n02: colour_grade { slope: 0.54, offset: 0.066, saturation: 0.68 }
+mx: combination { mix: 0.19 }
+"""
+
+
+def test_layer_with_an_in_place_writer_beside_a_reader_runs_in_order():
+    """n01 and n02 share a layer and both read n00's image; n02 is written in place (n02:image) and
+    is aliased onto that image (pipeline_graph.rs:400-411).  The reference dispatches the two
+    behind one barrier (command.rs:194-240): a race.  The plan marks the layer serial -- plan
+    order is name order, which is how the oracle executes it -- and leaves other layers alone
+    (found by tests/test_gpu_fullsize.py::test_random_graphs_1080p_whole_frame)."""
+    for flags in (0, NF):
+        info = {l["label"]: l for l in rf.Plan(rf.Config(IN_PLACE_BESIDE_A_READER), flags).launch_info()}
+        assert info["n02"]["output"] == info["n01"]["inputs"][0] == "n00:output_image"
+        assert info["n01"]["serial"] and info["n02"]["serial"]
+        assert not info["n00"]["serial"] and not info["mx"]["serial"]
+    assert not any(l["serial"] for l in rf.Plan(rf.Config(util.DIAMOND), 0).launch_info())     # an ordinary fork/join stays concurrent

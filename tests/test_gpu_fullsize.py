@@ -111,3 +111,19 @@ def test_config5_conv31_8k_band(ctx):
     c = g.download_raw()
     g.close()
     assert (c == c[0, 0, 0]).all() and abs(float(c[0, 0, 0]) - 0.5) < 1e-5
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_graphs_1080p_whole_frame(ctx, seed):
+    """Generated graphs at 1920x1080, the whole frame against the oracle, both formats: enough
+    strips and chunks for every seam, both walk directions and multi-round launches."""
+    text = util.random_graph(np.random.RandomState(7000 + seed))
+    pixel.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        for fmt in (util.F32, util.U8):
+            x = pixel.fill_synthetic(1920, 1080, fmt, 0x5EED0000 + seed)
+            want = util.run_oracle(text, x)
+            util.assert_same(util.run_hip(ctx, text, x), want, "1080p seed %d fused\n%s" % (seed, text))
+            util.assert_same(util.run_hip(ctx, text, x, flags=NF), want, "1080p seed %d unfused\n%s" % (seed, text))
+    finally:
+        pixel.set_threads(1)
