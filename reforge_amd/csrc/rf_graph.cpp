@@ -197,6 +197,7 @@ rf_status run_launch(rf_graph* g, FrameSlot& f, size_t li, hipStream_t stream, b
         if (st != RF_OK) return st;
     }
     if (timers) HIP_TRY(hipEventRecord(f.t1[li], stream));
+    if (g->sync_launches) HIP_TRY(hipStreamSynchronize(stream));   // RF_SYNC_LAUNCHES=1: debugging aid
     return RF_OK;
 }
 
@@ -446,6 +447,7 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
 
     if (const char* e = std::getenv("RF_ROWS_PER_CHUNK")) g->tune.rows_per_chunk = std::atoi(e);
     if (const char* e = std::getenv("RF_CONV_PATH")) g->tune.conv_path = std::atoi(e);
+    if (const char* e = std::getenv("RF_SYNC_LAUNCHES")) g->sync_launches = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_FORCE_SPLIT")) g->force_split = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_NO_ALTERNATE")) g->tune.no_alternate = std::atoi(e);
 

@@ -340,8 +340,16 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
             chain.push_back(n);
             seen.insert(n);
         }
+        // A point op written in place (same binding for input and output, :400-411) MODIFIES its
+        // input image.  Inside a chain nobody else reads that image (one consumer by construction),
+        // but at the HEAD of a chain the image may have other consumers, which must see the modified
+        // texels exactly as they do without fusion: such a head stays a launch of its own.
+        auto modifies_shared_input = [&](const std::string& n) {
+            const PipelineInfo& p = infos.at(n);
+            return p.input_images[0].second == p.output_images[0].second && consumers[p.input_images[0].first].size() > 1;
+        };
         // greedy: longest supported prefix first
-        size_t i = 0;
+        size_t i = modifies_shared_input(chain[0]) ? 1 : 0;
         while (i < chain.size()) {
             size_t best = 1;
             for (size_t len = std::min(chain.size() - i, (size_t)kMaxFusedOps); len >= 2; --len) {

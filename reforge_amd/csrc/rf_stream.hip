@@ -92,16 +92,25 @@ template <class Px, int PF> struct Source {
 
     // DMA source row r into slot r % PF.  Program order inside iteration `it` is
     //   [first stage consumes row it] -> issue(it+PF) -> wait_row(it+1) -> ... -> store
+    // The slot being refilled is the one row `it` was read from (ds_read, one iteration ago).
+    // The DMA's data arrives through the memory path, not through the LDS instruction queue, and
+    // the compiler is free to sink the first USE of that ds_read -- and with it the only
+    // s_waitcnt lgkmcnt that proves the read has executed -- below this asm.  An L2 hit (the
+    // neighbour chunk has just fetched the same halo rows) then overtakes a ds_read still queued
+    // behind other waves' LDS traffic and the stage computes on the NEXT row's texels: wrong
+    // first rows of a walk, seen only on busy chips (tests/test_gpu_fullsize.py::
+    // test_random_graphs_1080p_whole_frame).  Hence the lgkmcnt(0) in front of the DMA: by then
+    // the taps of the row have normally been consumed and the wait is free.
     RF_DEV void issue(int r) const
     {
         const char* g = src + (ptrdiff_t)(a0 + r) * pitch;
         const unsigned dst = lds_base + (unsigned)(r % SLOTS) * (unsigned)SLOT_BYTES;
         unsigned keep;
         if constexpr (Px::BPP == 16)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
         else
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
     }
     RF_DEV void prologue() const

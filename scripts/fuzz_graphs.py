@@ -1,0 +1,36 @@
+"""Exploration (GPU box): many generated graphs at a mid-size frame against the oracle.
+usage: fuzz_graphs.py <first seed> <count> [W H]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import reforge_amd as rf
+from oracle import pixel
+from tests import util
+
+first, count = int(sys.argv[1]), int(sys.argv[2])
+W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1920, 1080)
+ctx = rf.Context(0)
+pixel.set_threads(min(16, os.cpu_count() or 1))
+bad = 0
+t0 = time.time()
+for seed in range(first, first + count):
+    rng = np.random.RandomState(seed)
+    text = util.random_graph(rng)
+    w = W if seed % 3 else int(rng.randint(1, W))
+    h = H if seed % 5 else int(rng.randint(1, H))
+    for fmt in (util.F32, util.U8):
+        x = pixel.fill_synthetic(w, h, fmt, seed)
+        try:
+            want = util.run_oracle(text, x)
+        except Exception as e:
+            print("seed", seed, "oracle failed:", e, "\n" + text, flush=True)
+            bad += 1
+            break
+        for flags in (0, rf.RF_GRAPH_NO_FUSION, rf.RF_GRAPH_HIPGRAPH):
+            try:
+                got = util.run_hip(ctx, text, x, flags=flags)
+                util.assert_same(got, want, "")
+            except Exception as e:
+                bad += 1
+                print("seed", seed, "fmt", fmt, "flags", flags, "%dx%d" % (w, h), str(e)[:300], "\n" + text, flush=True)
+print("done", count, "graphs,", bad, "failures, %.0f s" % (time.time() - t0), flush=True)

@@ -363,3 +363,26 @@ def test_layer_with_an_in_place_writer_beside_a_reader_runs_in_order():
         assert info["n01"]["serial"] and info["n02"]["serial"]
         assert not info["n00"]["serial"] and not info["mx"]["serial"]
     assert not any(l["serial"] for l in rf.Plan(rf.Config(util.DIAMOND), 0).launch_info())     # an ordinary fork/join stays concurrent
+
+
+def test_in_place_head_with_other_consumers_is_not_fused():
+    """`n00 -> n01:image -> n02 ...` beside `n00 -> n04`: n01 modifies n00's image in place and n04
+    reads that image.  Fusing n01 into the chain behind it would leave n00's image untouched and n04
+    would read the ungraded texels (found by scripts/fuzz_graphs.py): the in-place head keeps its
+    own launch, the rest of the chain still fuses."""
+    text = """input -> n00 -> n01:image -> n02 -> n03 -> mx:input_image0
+n00 -> n04 -> mx:input_image1
+mx -> output
+n00: gaussian { sigma: 0.80, radius: 1 }
+n01: colour_grade { slope: 1.39, offset: 0.098, saturation: 0.19 }
+n02: gaussian9 { sigma: 2.0 }
+n03: gaussian5 { sigma: 1.65 }
+n04: passthrough {}
+mx: combination { mix: 0.30 }"""
+    info = {l["label"]: l for l in rf.Plan(rf.Config(text), 0).launch_info()}
+    assert set(info) == {"n00", "n01", "n04", "n02+n03", "mx"}
+    assert info["n01"]["output"] == info["n01"]["inputs"][0] == info["n04"]["inputs"][0] == "n00:output_image"
+    assert info["n01"]["serial"] and info["n04"]["serial"]
+    # with a single consumer the in-place node fuses like any other
+    solo = "input -> n00 -> n01:image -> n02 -> output\nn00: sharpen {}\nn01: colour_grade {}\nn02: gaussian5 {}"
+    assert rf.Plan(rf.Config(solo), 0).launches() == ["n00+n01", "n02"] or rf.Plan(rf.Config(solo), 0).launches() == ["n00", "n01+n02"]
