@@ -83,6 +83,12 @@ def test_stream_kernels_keep_the_counted_wait_contract(stream_asm):
         assert "scratch_" not in text, name                     # no spills
         assert re.search(r"global_load_lds_dword(x4)?\b", text), name
         assert not re.search(r"\bglobal_load_dword", text.replace("global_load_lds_dword", "")), name   # the DMA is the only load
+        # every DMA refill is issued behind an lgkmcnt(0): the ds_read that consumed the slot's previous
+        # row has executed (an L2-hit refill could otherwise overtake it; Source::issue)
+        instrs = [x.strip() for x in body if x.strip() and not x.strip().startswith((";", "."))]
+        for i, ins in enumerate(instrs):
+            if ins.startswith("global_load_lds"):
+                assert any(p.startswith("s_waitcnt") and "lgkmcnt(0)" in p for p in instrs[max(0, i - 5):i]), name
         pf = prefetch_depth(name)
         for loop in steady_loops(body, pf):
             ops = [x.split()[0] for x in loop]
