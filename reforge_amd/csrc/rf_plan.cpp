@@ -346,7 +346,10 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
         // texels exactly as they do without fusion: such a head stays a launch of its own.
         auto modifies_shared_input = [&](const std::string& n) {
             const PipelineInfo& p = infos.at(n);
-            return p.input_images[0].second == p.output_images[0].second && consumers[p.input_images[0].first].size() > 1;
+            // (rf:file-input persists from frame to frame: the next frame is a consumer too -- the
+            // reference grades its input again every frame in that case, and so does this path)
+            return p.input_images[0].second == p.output_images[0].second &&
+                   (consumers[p.input_images[0].first].size() > 1 || p.input_images[0].first == kFileInput);
         };
         // greedy: longest supported prefix first
         size_t i = modifies_shared_input(chain[0]) ? 1 : 0;

@@ -386,3 +386,13 @@ mx: combination { mix: 0.30 }"""
     # with a single consumer the in-place node fuses like any other
     solo = "input -> n00 -> n01:image -> n02 -> output\nn00: sharpen {}\nn01: colour_grade {}\nn02: gaussian5 {}"
     assert rf.Plan(rf.Config(solo), 0).launches() == ["n00+n01", "n02"] or rf.Plan(rf.Config(solo), 0).launches() == ["n00", "n01+n02"]
+
+
+def test_in_place_on_the_file_input_is_not_fused():
+    """`input -> aa:image -> bb`: aa grades rf:file-input in place (pipeline_graph.rs:400-411 aliases
+    onto the input image although it is never recycled).  The input persists from frame to frame, so
+    the next frame sees graded texels -- in the reference and here; fusing aa away would change that."""
+    text = "input -> aa:image -> bb -> output\naa: colour_grade { slope: 0.9 }\nbb: gaussian5 { sigma: 1.0 }"
+    p = rf.Plan(rf.Config(text), 0)
+    assert p.launches() == ["aa", "bb"] and p.resolve("aa:image") == "rf:file-input"
+    assert rf.Plan(rf.Config(text.replace("aa:image", "aa")), 0).launches() == ["aa+bb"]

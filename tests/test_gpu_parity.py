@@ -436,3 +436,28 @@ def test_random_graphs_as_row_strips(seed, monkeypatch):
     x = util.synthetic(W, H, util.F32, seed=seed)
     util.assert_same(util.run_hip(c, text, x, flags=flags), util.run_oracle(text, x), "forced split seed=%d\n%s" % (seed, text))
     c.close()
+
+
+def test_second_frame_of_an_in_place_graph(ctx):
+    """A point op written in place on rf:file-input grades the input again on every frame (the
+    reference uploads once per slot, main.rs:164-170, and aliases the node onto the input image):
+    frame 2 equals the oracle executed twice, fused or not, on both slots in flight."""
+    text = "input -> aa:image -> bb -> cc -> output\naa: colour_grade { slope: 0.8, offset: 0.05, saturation: 1.3 }\nbb: gaussian5 { sigma: 1.2 }\ncc: sharpen { amount: 0.4 }"
+    from oracle import graph as ograph
+    for fmt in (util.F32, util.U8):
+        x = util.synthetic(300, 170, fmt, seed=9)
+        o = ograph.GraphOracle(text, 300, 170, fmt)
+        o.upload_raw(x); o.execute()
+        first = o.download_raw().copy()
+        o.execute()
+        second = o.download_raw()
+        assert first.tobytes() != second.tobytes()
+        for flags in (0, NF):
+            g = rf.Graph(ctx, rf.Config(text), 300, 170, fmt, num_frames=2, flags=flags)
+            g.upload_raw(x)
+            g.execute(0); g.execute(1); g.wait(0); g.wait(1)
+            util.assert_same(g.download_raw(0), first, "frame 1 slot 0")
+            g.execute(0); g.execute(1); g.wait(0); g.wait(1)
+            util.assert_same(g.download_raw(0), second, "frame 2 slot 0")
+            util.assert_same(g.download_raw(1), second, "frame 2 slot 1")
+            g.close()
