@@ -346,6 +346,7 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
         // texels exactly as they do without fusion: such a head stays a launch of its own.
         auto modifies_shared_input = [&](const std::string& n) {
             const PipelineInfo& p = infos.at(n);
+            if (!is_simple(p)) return false;             // no input image, or several: never a chain member anyway
             // (rf:file-input persists from frame to frame: the next frame is a consumer too -- the
             // reference grades its input again every frame in that case, and so does this path)
             return p.input_images[0].second == p.output_images[0].second &&

@@ -396,3 +396,12 @@ def test_in_place_on_the_file_input_is_not_fused():
     p = rf.Plan(rf.Config(text), 0)
     assert p.launches() == ["aa", "bb"] and p.resolve("aa:image") == "rf:file-input"
     assert rf.Plan(rf.Config(text.replace("aa:image", "aa")), 0).launches() == ["aa+bb"]
+
+
+def test_graph_without_an_input_image_plans_without_crashing():
+    """`sharpen -> output` with no `input` (allowed when no input file is given, config.rs:201): the node
+    has no input image.  The planner (fusion pass included) must survive it."""
+    for flags in (0, NF):
+        p = rf.Plan(rf.Config("sharpen -> output", expects_input=False), flags)
+        assert p.layers() == [["sharpen"]]
+        assert p.launch_info() == []          # nothing launchable; rf_graph_create reports why (test_graph_errors)
