@@ -209,7 +209,8 @@ const rf_plan* rf_graph_plan(const rf_graph* g);
 rf_status rf_graph_strip(const rf_graph* g, int* y0, int* y1);
 
 /* initialize_ubos / update_ubos (render.rs:167-223): writes one uniform member of
- * node `node`.  Unknown name -> RF_WARN_UNKNOWN_PARAM (nothing written). */
+ * node `node`.  Unknown name -> RF_WARN_UNKNOWN_PARAM (nothing written).  A conv2d node's
+ * `sigma` regenerates its default weights (replacing any set with rf_graph_set_weights). */
 rf_status rf_graph_set_param(rf_graph* g, const char* node, const char* name,
                              rf_param_type type, const void* value);
 /* conv2d weights, row-major [K][K] f32 with K = the node's resolved ksize

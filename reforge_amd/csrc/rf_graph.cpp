@@ -593,6 +593,19 @@ extern "C" rf_status rf_graph_set_param(rf_graph* g, const char* node, const cha
         return fail(RF_ERR_UNSUPPORTED, std::string("parameter '") + name + "' changes the stencil radius: destroy and re-create the graph");
     }
     invalidate_captures(g);
+    if (np.type->kind == OP_CONV2D && std::string(name) == "sigma") {
+        // the node's weights are DERIVED from sigma until rf_graph_set_weights replaces them: an edit
+        // of sigma regenerates them, as creating the graph with that sigma would
+        auto wit = g->dev_weights.find(node);
+        if (wit != g->dev_weights.end()) {
+            const int K = np.conv_ksize();
+            std::vector<float> w((size_t)K * K);
+            default_conv_weights(K, nv.f, w.data());
+            HIP_TRY(hipSetDevice(g->ctx->device));
+            for (auto& f : g->frames) HIP_TRY(hipStreamSynchronize(f.stream));
+            HIP_TRY(hipMemcpy(wit->second, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
     rebuild_ops(g);
     return RF_OK;
 }

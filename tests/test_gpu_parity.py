@@ -461,3 +461,22 @@ def test_second_frame_of_an_in_place_graph(ctx):
             util.assert_same(g.download_raw(0), second, "frame 2 slot 0")
             util.assert_same(g.download_raw(1), second, "frame 2 slot 1")
             g.close()
+
+
+def test_conv_sigma_edit_regenerates_the_weights(ctx):
+    """rf_graph_set_param on a conv2d node's sigma: the default weights are derived from sigma, so the
+    next frame equals a graph created with the new value (found by scripts/fuzz_params.py)."""
+    t0 = "input -> cc -> gg -> output\ncc: conv2d { ksize: 5, sigma: 1.70 }\ngg: colour_grade { slope: 1.10, offset: 0.00, saturation: 1.00 }"
+    t1 = t0.replace("sigma: 1.70", "sigma: 0.60").replace("slope: 1.10", "slope: 0.70")
+    for fmt in (util.F32, util.U8):
+        x = util.synthetic(97, 61, fmt, seed=4)
+        for flags in (0, NF, rf.RF_GRAPH_HIPGRAPH):
+            g = rf.Graph(ctx, rf.Config(t0), 97, 61, fmt, flags=flags)
+            g.upload_raw(x)
+            g.execute(); g.wait()
+            util.assert_same(g.download_raw(), util.run_oracle(t0, x), "before")
+            g.set_param("cc", "sigma", float(np.float32(0.60)))
+            g.set_param("gg", "slope", float(np.float32(0.70)))
+            g.execute(); g.wait()
+            util.assert_same(g.download_raw(), util.run_oracle(t1, x), "after the edits, flags %d" % flags)
+            g.close()
