@@ -2,6 +2,7 @@
 #include "rf_plan.h"
 
 #include <algorithm>
+#include <functional>
 #include <cerrno>
 #include <cmath>
 #include <cstdlib>
@@ -331,6 +332,39 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
         std::string nx = next_of(kv.first);
         if (!nx.empty()) prev_of[nx] = kv.first;
     }
+    // A point op written in place (same binding for input and output, :400-411) MODIFIES the image
+    // it reads -- and, through a run of in-place nodes, the allocation at the root of that run.  A
+    // fused launch writes only its last member's output, so an in-place member may be fused only if
+    // nobody outside the group can see its write: every node that reads a resource living on that
+    // root allocation is in the group, and the root is not rf:file-input (which persists from frame
+    // to frame -- the reference grades its input again every frame in that case, and so does this
+    // path).  Otherwise the node keeps a launch of its own.
+    auto in_place = [&](const PipelineInfo& p) { return is_simple(p) && p.input_images[0].second == p.output_images[0].second; };
+    std::map<std::string, std::string> root_memo;
+    std::function<std::string(const std::string&)> root_of = [&](const std::string& res) -> std::string {
+        auto it = root_memo.find(res);
+        if (it != root_memo.end()) return it->second;
+        root_memo[res] = res;                                      // cycle guard
+        std::string r = res;
+        auto pr = producers.find(res);
+        if (pr != producers.end() && pr->second.size() == 1 && in_place(infos.at(pr->second[0])))
+            r = root_of(infos.at(pr->second[0]).input_images[0].first);
+        return root_memo[res] = r;
+    };
+    std::map<std::string, std::set<std::string>> readers_of_root;
+    for (const auto& kv : infos)
+        for (const auto& in : kv.second.input_images) readers_of_root[root_of(in.first)].insert(kv.first);
+    auto side_effects_stay_inside = [&](const std::vector<std::string>& group) {
+        for (const auto& m : group) {
+            const PipelineInfo& p = infos.at(m);
+            if (!in_place(p)) continue;
+            const std::string root = root_of(p.input_images[0].first);
+            if (root == kFileInput) return false;
+            for (const auto& reader : readers_of_root[root])
+                if (std::find(group.begin(), group.end(), reader) == group.end()) return false;
+        }
+        return true;
+    };
     std::vector<std::vector<std::string>> groups;
     for (const auto& kv : infos) {
         if (prev_of.count(kv.first)) continue;   // not a chain head
@@ -340,26 +374,17 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
             chain.push_back(n);
             seen.insert(n);
         }
-        // A point op written in place (same binding for input and output, :400-411) MODIFIES its
-        // input image.  Inside a chain nobody else reads that image (one consumer by construction),
-        // but at the HEAD of a chain the image may have other consumers, which must see the modified
-        // texels exactly as they do without fusion: such a head stays a launch of its own.
-        auto modifies_shared_input = [&](const std::string& n) {
-            const PipelineInfo& p = infos.at(n);
-            if (!is_simple(p)) return false;             // no input image, or several: never a chain member anyway
-            // (rf:file-input persists from frame to frame: the next frame is a consumer too -- the
-            // reference grades its input again every frame in that case, and so does this path)
-            return p.input_images[0].second == p.output_images[0].second &&
-                   (consumers[p.input_images[0].first].size() > 1 || p.input_images[0].first == kFileInput);
-        };
         // greedy: longest supported prefix first
-        size_t i = modifies_shared_input(chain[0]) ? 1 : 0;
+        size_t i = 0;
         while (i < chain.size()) {
             size_t best = 1;
             for (size_t len = std::min(chain.size() - i, (size_t)kMaxFusedOps); len >= 2; --len) {
                 std::vector<Op> ops;
                 for (size_t k = 0; k < len; ++k) ops.push_back(plan.nodes.at(chain[i + k]).to_op(nullptr));
-                if (stream_supported(ops.data(), (int)len)) { best = len; break; }
+                if (!stream_supported(ops.data(), (int)len)) continue;
+                if (!side_effects_stay_inside(std::vector<std::string>(chain.begin() + i, chain.begin() + i + len))) continue;
+                best = len;
+                break;
             }
             if (best >= 2) groups.emplace_back(chain.begin() + i, chain.begin() + i + best);
             i += best;

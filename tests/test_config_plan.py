@@ -405,3 +405,28 @@ def test_graph_without_an_input_image_plans_without_crashing():
         p = rf.Plan(rf.Config("sharpen -> output", expects_input=False), flags)
         assert p.layers() == [["sharpen"]]
         assert p.launch_info() == []          # nothing launchable; rf_graph_create reports why (test_graph_errors)
+
+
+def test_runs_of_in_place_nodes_fuse_only_when_nobody_else_sees_the_image():
+    """The write of an in-place node lands on the allocation at the ROOT of its run of in-place nodes
+    (aa:image -> bb:image both grade the image aa read).  Fusing is allowed only if every reader of
+    that allocation is inside the group and it is not rf:file-input (scripts/fuzz_graphs.py,
+    scripts/fuzz_strips.py found both shapes)."""
+    # second in-place node of a run on the file input: still modifies the input every frame
+    t = "input -> aa:image -> bb:image -> cc -> output\naa: colour_grade {}\nbb: colour_grade {}\ncc: sharpen {}"
+    p = rf.Plan(rf.Config(t), 0)
+    assert p.launches() == ["aa", "bb", "cc"] and p.resolve("bb:image") == "rf:file-input"
+    # a run on an image that a second branch also reads (through its own in-place node)
+    t = """input -> n00 -> n01:image -> n02:image -> n03 -> mx:input_image0
+n00 -> n04:image -> mx:input_image1
+mx -> output
+n00: gaussian5 {}
+n01: colour_grade {}
+n02: colour_grade {}
+n03: gaussian5 {}
+n04: colour_grade {}
+mx: combination { mix: 0.5 }"""
+    assert sorted(rf.Plan(rf.Config(t), 0).launches()) == ["mx", "n00", "n01", "n02", "n03", "n04"]
+    # the same run with no other reader fuses as before
+    t = "input -> n00 -> n01:image -> n02:image -> output\nn00: gaussian5 {}\nn01: colour_grade {}\nn02: colour_grade {}"
+    assert len(rf.Plan(rf.Config(t), 0).launches()) == 2
