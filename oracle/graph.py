@@ -252,7 +252,12 @@ def synthesize(cfg):
             for resource, descriptor in cfg.graph_pipelines[name][key]:
                 if descriptor not in t["images"]:
                     raise ConfigError("Shader has no binding named: %s" % descriptor)   # :179
-                dst.append((resource, t["images"][descriptor]))
+                # a node named in several graph expressions repeats the same (resource, binding)
+                # (config.rs:149-190 pushes per occurrence); the planner works on sets -- with the
+                # duplicate, the aliasing pass first remaps the output and then also allocates it,
+                # and that alias-and-allocation later lands a stencil's output on its own input
+                if (resource, t["images"][descriptor]) not in dst:
+                    dst.append((resource, t["images"][descriptor]))
         given = cfg.params_of(name)
         info.params = {k: _parse_param(given.get(k), ty) for k, ty in t["params"].items()}
         infos[name] = info

@@ -428,7 +428,14 @@ bool build_plan(const Config& cfg, uint32_t flags, Plan& plan, std::string& err)
                     err = "Shader " + tname + " has no binding named: " + d.descriptor_name;
                     return false;
                 }
-                dst.push_back({d.resource_name, b});
+                // A node named in several graph expressions ("aa -> bb" and "aa -> cc") gets the same
+                // (resource, binding) pushed once per occurrence (config.rs:149-190).  The planner
+                // treats the lists as SETS: with a duplicate, reusable_image_remapping (:398-424)
+                // first remaps the output onto a free image and then, free list now empty, also
+                // records it as an allocation of its own -- an image that is both an alias and a
+                // recyclable allocation, which later hands a stencil its own input as output.
+                const std::pair<std::string, int> e{d.resource_name, b};
+                if (std::find(dst.begin(), dst.end(), e) == dst.end()) dst.push_back(e);
             }
         }
         plan.infos[name] = info;

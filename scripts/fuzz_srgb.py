@@ -15,7 +15,7 @@ bad = 0
 t0 = time.time()
 for seed in range(first, first + count):
     rng = np.random.RandomState(seed)
-    text = util.random_graph(rng)
+    text = (util.random_dag if os.environ.get("FUZZ_GEN") == "dag" else util.random_graph)(rng)
     W, H = int(rng.randint(1, 900)), int(rng.randint(1, 500))
     fmt = (util.F32, util.U8)[seed & 1]
     flags = (0, rf.RF_GRAPH_NO_FUSION)[(seed >> 1) & 1]

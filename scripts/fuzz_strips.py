@@ -16,7 +16,7 @@ bad = 0
 t0 = time.time()
 for seed in range(first, first + count):
     rng = np.random.RandomState(seed)
-    text = util.random_graph(rng)
+    text = (util.random_dag if os.environ.get("FUZZ_GEN") == "dag" else util.random_graph)(rng)
     W, H = int(rng.randint(200, 1920)), int(rng.randint(400, 1080))
     world = int(rng.randint(2, 5))
     flags = (0, rf.RF_GRAPH_NO_FUSION)[seed & 1]

@@ -430,3 +430,45 @@ mx: combination { mix: 0.5 }"""
     # the same run with no other reader fuses as before
     t = "input -> n00 -> n01:image -> n02:image -> output\nn00: gaussian5 {}\nn01: colour_grade {}\nn02: colour_grade {}"
     assert len(rf.Plan(rf.Config(t), 0).launches()) == 2
+
+
+def test_a_node_named_in_two_expressions_lists_its_output_once():
+    """`n01 -> n02` ... `n02 -> n03`, `n02 -> n07`: config.rs:149-190 pushes n02's output once per
+    occurrence.  With the duplicate, the aliasing pass (pipeline_graph.rs:398-424) remaps the output
+    onto a free image and then, free list empty, ALSO records it as an allocation: an image that is
+    alias and recyclable allocation at once, which later lands a stencil's output on its own input
+    (scripts/fuzz_graphs.py with FUZZ_GEN=dag found it).  The planner works on sets."""
+    import numpy as np
+    text = util.random_dag(np.random.RandomState(500059))
+    cfg = og.parse_config(text)
+    assert cfg.graph_pipelines["n02"]["outputs"] == [("n02:output_image", "output_image")] * 2       # the config keeps both
+    infos = og.synthesize(cfg)
+    assert infos["n02"].output_images == [("n02:output_image", 1)]                                   # the planner does not
+    for flags in (0, NF):
+        p = rf.Plan(rf.Config(text), flags)
+        info = p.launch_info()
+        assert info, "the plan must be launchable"
+        for l in info:
+            if l["radius"] > 0 and len(l["inputs"]) == 1:
+                assert l["inputs"][0] != l["output"]
+        roots = set(p.images())
+        assert all(p.resolve(a) in roots for a in p.aliases())          # every alias ends on an allocation
+
+
+def test_planner_matches_restatement_on_random_dags():
+    """400 graphs from the wide generator (several forks and joins, nodes read by many, in-place runs,
+    type aliases): same layers, aliases and images as the restatement; every plan launchable; no
+    stencil writes the image it reads."""
+    import numpy as np
+    for seed in range(400):
+        text = util.random_dag(np.random.RandomState(9000 + seed))
+        p, layers, reuse = plans(text)
+        assert p.layers() == layers and p.aliases() == reuse, text
+        for flags in (0, NF):
+            q = rf.Plan(rf.Config(text), flags)
+            info = q.launch_info()
+            assert info, text
+            assert sorted(m for l in info for m in l["members"]) == sorted(rf.Config(text).nodes()), text
+            for l in info:
+                if l["radius"] > 0 and len(l["inputs"]) == 1:
+                    assert l["inputs"][0] != l["output"], text

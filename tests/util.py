@@ -134,3 +134,63 @@ def random_graph(rng):
     else:
         lines.append("input -> %s -> output" % " -> ".join(chain))
     return "\n".join(lines + decl)
+
+
+def random_dag(rng):
+    """A wider generator than random_graph: up to 9 nodes, any earlier node's output (or the input)
+    may feed a new node, `combination` joins appear anywhere, type aliases, large radii and kernels,
+    in-place point ops anywhere.  The last node drives the output; dangling nodes are pruned by
+    making every node reachable from it (a node nobody reads feeds a final join)."""
+    point = ["colour_grade", "grade", "colour-grade"]
+    decl, edges = [], []            # edges: list of chains as token lists
+    outputs = ["input"]             # names whose output image can be read
+    n = rng.randint(1, 10)
+    readers = {}
+    for i in range(n):
+        name = "n%02d" % i
+        roll = rng.rand()
+        src = outputs[rng.randint(len(outputs))] if rng.rand() < 0.35 else outputs[-1]
+        if roll < 0.15 and len(outputs) >= 3:
+            a, b = [outputs[k] for k in rng.choice(len(outputs), 2, replace=False)]
+            if a != "input" or b != "input":
+                decl.append("%s: combination { mix: %.2f }" % (name, rng.uniform(0, 1)))
+                edges.append([a, name + ":input_image0"])
+                edges.append([b, name + ":input_image1"])
+                readers[a] = readers.get(a, 0) + 1
+                readers[b] = readers.get(b, 0) + 1
+                outputs.append(name)
+                continue
+        kind = ["passthrough", "gaussian5", "gaussian9", "gaussian", "point", "point_inplace", "sharpen", "conv2d"][rng.randint(8)]
+        tok = name
+        if kind == "passthrough":
+            decl.append("%s: passthrough {}" % name)
+        elif kind in ("gaussian5", "gaussian9"):
+            decl.append("%s: %s { sigma: %.2f }" % (name, kind, rng.uniform(0.4, 3.0)))
+        elif kind == "gaussian":
+            r = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 8, 11, 15], p=[.1, .15, .15, .15, .15, .1, .08, .05, .04, .03]))
+            decl.append("%s: gaussian { sigma: %.2f, radius: %d }" % (name, rng.uniform(0.5, 5.0), r))
+        elif kind in ("point", "point_inplace"):
+            decl.append("%s: %s { slope: %.2f, offset: %.3f, saturation: %.2f }" % (name, point[rng.randint(3)], rng.uniform(0.5, 1.5), rng.uniform(-0.1, 0.1), rng.uniform(0.0, 2.0)))
+            if kind == "point_inplace":
+                tok = name + ":image"
+        elif kind == "sharpen":
+            decl.append("%s: sharpen { amount: %.2f }" % (name, rng.uniform(0.0, 1.5)))
+        else:
+            k = int(rng.choice([3, 5, 7, 9, 13, 31], p=[.3, .25, .2, .15, .07, .03]))
+            decl.append("%s: conv2d { ksize: %d, sigma: %.2f }" % (name, k, rng.uniform(0.6, 4.0)))
+        edges.append([src, tok])
+        readers[src] = readers.get(src, 0) + 1
+        outputs.append(name)
+    # every node must reach the output: join the dangling ones into the last node's result
+    last = outputs[-1]
+    dangling = [o for o in outputs[1:-1] if readers.get(o, 0) == 0]
+    j = 0
+    for d in dangling:
+        name = "j%02d" % j
+        j += 1
+        decl.append("%s: combination { mix: %.2f }" % (name, rng.uniform(0, 1)))
+        edges.append([last, name + ":input_image0"])
+        edges.append([d, name + ":input_image1"])
+        last = name
+    edges.append([last, "output"])
+    return "\n".join([" -> ".join(e) for e in edges] + decl)
