@@ -10,7 +10,7 @@ from tests import util
 first, count = int(sys.argv[1]), int(sys.argv[2])
 pixel.set_threads(min(16, os.cpu_count() or 1))
 ctx = rf.Context(0)
-EDITS = {"colour_grade": ["slope", "offset", "saturation"], "sharpen": ["amount"], "gaussian5": ["sigma"], "gaussian9": ["sigma"],
+EDITS = {"colour_grade": ["slope", "offset", "saturation"], "grade": ["slope", "offset", "saturation"], "colour-grade": ["slope", "offset", "saturation"], "sharpen": ["amount"], "gaussian5": ["sigma"], "gaussian9": ["sigma"],
          "gaussian": ["sigma"], "conv2d": ["sigma"], "combination": ["mix"]}
 bad = 0
 t0 = time.time()
@@ -29,11 +29,11 @@ for seed in range(first, first + count):
         lines = text.split("\n")
         cur = text
         for _ in range(3):
-            idx = [i for i, l in enumerate(lines) if re.match(r"^\w+: (\w+) \{ ", l)]
+            idx = [i for i, l in enumerate(lines) if re.match(r"^\w+: ([\w-]+) \{ ", l)]
             if not idx:
                 break
             i = idx[rng.randint(len(idx))]
-            m = re.match(r"^(\w+): (\w+) \{ (.*) \}$", lines[i])
+            m = re.match(r"^(\w+): ([\w-]+) \{ (.*) \}$", lines[i])
             node, typ, body = m.group(1), m.group(2), m.group(3)
             name = EDITS[typ][rng.randint(len(EDITS[typ]))]
             val = round(float(rng.uniform(0.1, 2.0)), 2)
