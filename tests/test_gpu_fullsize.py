@@ -129,3 +129,15 @@ def test_random_graphs_1080p_whole_frame(ctx, seed):
             util.assert_same(util.run_hip(ctx, text, x, flags=NF), want, "1080p seed %d unfused\n%s" % (seed, text))
     finally:
         pixel.set_threads(1)
+
+
+def test_config4_chain5_whole_16k_frame_one_gpu(ctx):
+    """BASELINE config 4's whole 16384 x 16384 rgba32f frame on ONE GPU (what bench.py --workload
+    chain5_16k times at N=1): 4 GiB per image, byte offsets beyond 2^31 and 2^32.  Fused (one
+    launch) == one launch per node over the whole frame, and bands at the top, across the 2 GiB
+    and 4 GiB-offset rows and at the bottom equal the oracle."""
+    W, H, seed = 16384, 16384, 0x5EED0004
+    fused = gpu_frame(ctx, util.CHAIN5, W, H, util.F32, seed)
+    band_check(fused, util.CHAIN5, W, H, util.F32, seed, 7, [(0, 8), (8188, 8196), (16376, 16384)])
+    unfused = gpu_frame(ctx, util.CHAIN5, W, H, util.F32, seed, flags=NF)
+    assert np.array_equal(fused.view(np.uint32), unfused.view(np.uint32))
