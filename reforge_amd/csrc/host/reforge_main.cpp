@@ -59,7 +59,7 @@ void usage()
         "      --shader-format <rgba8|rgba32f>  Shader image format [default: rgba32f]\n"
         "      --config <config>              Path to the pipeline configuration file\n"
         "      --shader-path <shader-path>    Kept for compatibility; filter types are compiled in [default: shaders]\n"
-        "      --num-frames <NUM_FRAMES>      Frames in flight when displaying (headless forces 1) [default: 2]\n"
+        "      --num-frames <NUM_FRAMES>      Frames in flight in the --watch loop (one headless frame forces 1) [default: 2]\n"
         "      --synthetic <SEED>             Generate the input on the GPU instead of reading a file\n"
         "      --frames <N>                   Execute the graph N times and report the mean frame time\n"
         "      --no-fusion                    One kernel launch per node, as the reference dispatches\n"
@@ -203,7 +203,9 @@ int main(int argc, char** argv)
         warnln("No output file given: window/swapchain presentation is out of scope on an MI355X box; pass -o <file>");
         return 1;
     }
-    const int num_frames = 1;   // main.rs:77-78: headless uses one frame in flight
+    // main.rs:77-78: headless uses one frame in flight; the --watch loop stands in for the windowed
+    // loop and cycles --num-frames slots like it (main.rs:69-70, render.rs:328-337)
+    const int num_frames = args.watch ? (args.num_frames < 1 ? 1 : args.num_frames) : 1;
     if (!args.config.empty() && !args.shader_file_path.empty()) {   // main.rs:80-83
         warnln("Cannot specify both a config and shader file");
         return 1;
@@ -309,7 +311,7 @@ int main(int argc, char** argv)
         last_mtime = m;
         rf_config* c2 = create_config();
         if (!c2) return false;
-        (void)rf_graph_wait(graph, 0);
+        for (int k = 0; k < num_frames; ++k) (void)rf_graph_wait(graph, k);   // device_wait_idle, render.rs:126
         rf_graph* g2 = nullptr;
         if (rf_graph_create(ctx, c2, &opt, &g2) != RF_OK) {
             warnln(rf_last_error());
@@ -330,14 +332,17 @@ int main(int argc, char** argv)
     const double t_start = now_ms();
     double timer = t_start, avg_ms = 0.0, sum_ms = 0.0;
     char times[4096] = "";
+    int slot = 0;
     for (int i = 0; i < frames; ++i) {
+        slot = i % num_frames;
+        RF_CHECK(rf_graph_wait(graph, slot));   // wait_for_frame_fence: the previous use of this slot (render.rs:328-337)
         if (args.frame_interval_ms > 0) {   // pace the loop like a display would, so the config can be edited while it runs
-            RF_CHECK(rf_graph_wait(graph, 0));
             std::this_thread::sleep_for(std::chrono::milliseconds(args.frame_interval_ms));
         }
         if (args.watch && trigger_reloads()) {
             std::fputs("\r\x1b[2K", stderr);   // main.rs:141
             RF_CHECK(load_input());
+            slot = 0;                           // recreate_graph resets frame_index (render.rs:134)
         }
         if (args.watch || frames == 1) {
             rf_status ts = rf_graph_set_time(graph, (float)((now_ms() - t_start) / 1e3));   // update_ubos, render.rs:212-223
@@ -347,22 +352,19 @@ int main(int argc, char** argv)
             const double elapsed = now_ms() - timer;
             timer = now_ms();
             avg_ms = avg_ms - avg_ms / 60.0 + elapsed / 60.0;   // utils::moving_avg, utils.rs:76-82
-            if (opt.flags & RF_GRAPH_TIMERS) {
-                RF_CHECK(rf_graph_wait(graph, 0));
-                if (i > 0) RF_CHECK(rf_graph_times_string(graph, 0, times, sizeof(times)));
-            }
+            if ((opt.flags & RF_GRAPH_TIMERS) && i >= num_frames) RF_CHECK(rf_graph_times_string(graph, slot, times, sizeof(times)));   // this slot's previous frame
             std::fprintf(stderr, "\rFrame: %5.2fms, Frame-Avg: %5.2fms, GPU: {%s}", elapsed, avg_ms, times);
         }
-        RF_CHECK(rf_graph_execute(graph, 0));
+        RF_CHECK(rf_graph_execute(graph, slot));
     }
-    RF_CHECK(rf_graph_wait(graph, 0));
+    for (int k = 0; k < num_frames; ++k) RF_CHECK(rf_graph_wait(graph, k));
     sum_ms = now_ms() - t_start;
     const double frame_ms = sum_ms / (double)frames;
-    if (opt.flags & RF_GRAPH_TIMERS) RF_CHECK(rf_graph_times_string(graph, 0, times, sizeof(times)));
+    if (opt.flags & RF_GRAPH_TIMERS) RF_CHECK(rf_graph_times_string(graph, slot, times, sizeof(times)));
     std::fprintf(stderr, "\rFrame: %5.2fms, Frame-Avg: %5.2fms, GPU: {%s}\n", frame_ms, args.watch ? avg_ms : frame_ms, times);   // main.rs:157
 
     staging.resize((size_t)width * height * 4);
-    RF_CHECK(rf_graph_download_srgb8(graph, 0, staging.data(), (size_t)width * 4));
+    RF_CHECK(rf_graph_download_srgb8(graph, slot, staging.data(), (size_t)width * 4));
     if (!write_image(args.output_file, width, height, staging.data())) { warnln("Encoding error: cannot write " + args.output_file); return 1; }
 
     rf_graph_destroy(graph);
