@@ -196,7 +196,7 @@ def test_non_finite_texels_propagate_like_the_oracle(ctx):
     x[5, 7] = [np.inf, -np.inf, np.nan, 1.0]
     x[20, 60] = [-0.0, 1e-42, -1e-42, 3e38]
     x[39, 89] = [np.nan, 0.5, np.inf, -np.inf]
-    for name in ("gaussian5", "gaussian9", "sharpen", "grade", "chain3", "passthrough"):
+    for name in ("gaussian5", "gaussian9", "sharpen", "grade", "chain3", "chain5", "passthrough", "conv3", "conv9", "gaussian_r7"):
         want = util.run_oracle(NODES[name], x)
         for flags in (0, NF):
             got = util.run_hip(ctx, NODES[name], x, flags=flags)
