@@ -100,6 +100,7 @@ struct rf_graph {
     rf::StreamTuning tune;
     bool force_split = false;          // RF_FORCE_SPLIT=1: interior/boundary split without an exchange (tests)
     bool sync_launches = false;        // RF_SYNC_LAUNCHES=1: host-synchronise after every launch (debugging aid)
+    bool concurrent_layers = false;    // RF_CONCURRENT_LAYERS=1: the launches of a hazard-free layer run on side streams (slower, measured)
     uint8_t* d_staging = nullptr;      // RGBA8 staging rows (render.rs:552-564)
     size_t staging_bytes = 0;
     std::vector<std::string> time_names;   // scratch for rf_graph_node_times

@@ -392,14 +392,17 @@ def test_exchange_mode_needs_a_communicator():
 
 
 # ---- random graphs --------------------------------------------------------------------------
-@pytest.mark.parametrize("seed", range(24))
-def test_random_graphs(ctx, seed):
-    """Planner (layering, aliasing, in-place point ops, fusion with greedy splitting, fork/join on
-    side streams) and kernels together, on graphs nobody wrote by hand: fused, unfused and
-    hipGraph execution all equal the oracle, both formats."""
+@pytest.mark.parametrize("seed", range(40))
+def test_random_graphs(ctx, seed, monkeypatch):
+    """Planner (layering, aliasing, in-place point ops, fusion with greedy splitting) and kernels
+    together, on graphs nobody wrote by hand: fused, unfused and hipGraph execution all equal the
+    oracle, both formats -- with the layers in plan order (default) and, every other seed, with
+    hazard-free layers forked onto side streams (RF_CONCURRENT_LAYERS=1)."""
     rng = np.random.RandomState(1000 + seed)
-    text = util.random_graph(rng)
+    text = (util.random_graph if seed < 24 else util.random_dag)(rng)
     W, H = int(rng.randint(1, 200)), int(rng.randint(1, 120))
+    if seed & 1:
+        monkeypatch.setenv("RF_CONCURRENT_LAYERS", "1")
     for fmt in (util.F32, util.U8):
         x = util.synthetic(W, H, fmt, seed=seed)
         want = util.run_oracle(text, x)
