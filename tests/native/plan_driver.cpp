@@ -1,3 +1,6 @@
+// Test driver (tests/test_sanitizers.py): feeds texts separated by 0x01 through the host-only half
+// of the C ABI -- config parser, planner, launch/halo accessors -- in a build of rf_config.cpp,
+// rf_plan.cpp and rf_abi.cpp with AddressSanitizer + UndefinedBehaviorSanitizer + LeakSanitizer.
 #include <cstdio>
 #include <fstream>
 #include <sstream>
