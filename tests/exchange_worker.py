@@ -1,0 +1,44 @@
+"""One rank of tests/test_gpu_exchange.py: the product in EXCHANGE mode (per-launch neighbour exchange,
+interior/boundary split) with the test double of librccl on the loader path.  Run as a script:
+  exchange_worker.py <rank> <world> <W> <H> <fmt> <flags> <seed> <config file> <out dir> <frames>"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import reforge_amd as rf  # noqa: E402
+
+
+def main():
+    rank, world, W, H, fmt, flags, seed = (int(a) for a in sys.argv[1:8])
+    text = open(sys.argv[8]).read()
+    out_dir, frames = sys.argv[9], int(sys.argv[10])
+    id_path = os.path.join(out_dir, "unique_id.bin")
+    if rank == 0:
+        uid = rf.Context.unique_id()
+        with open(id_path + ".tmp", "wb") as fh:
+            fh.write(uid)
+        os.rename(id_path + ".tmp", id_path)
+    else:
+        for _ in range(3000):
+            if os.path.exists(id_path):
+                break
+            time.sleep(0.01)
+        uid = open(id_path, "rb").read()
+    ctx = rf.Context(0, rank, world, uid)
+    g = rf.Graph(ctx, rf.Config(text), W, H, fmt, flags=flags)       # exchange mode: RF_GRAPH_NO_HALO_XCHG is NOT set
+    g.fill_synthetic(seed)
+    for _ in range(frames):
+        g.execute()
+    g.wait()
+    np.save(os.path.join(out_dir, "strip%d.npy" % rank), g.download_raw())
+    g.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""GPU: the EXCHANGE half of the multi-rank executor (rf_graph.cpp: exchange_rows on the comm stream,
+three-part interior/boundary launches, event edges) run for real by 2..4 processes sharing GPU 0.
+RCCL refuses two ranks on one device, so the processes load tests/native/fake_rccl.cpp -- the RCCL entry
+points librfhip dlopens, with the real signatures, over shared memory -- in its place.  Everything
+else is the product.  (The real library's ABI is covered by rf_comm_selftest; the schedule by
+tests/test_dist_gloo.py; real multi-GPU runs are the driver's.)"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import reforge_amd as rf
+from oracle import pixel
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def fake_rccl_dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("fake_rccl")
+    so = str(d / "librccl.so.1")
+    subprocess.check_call([HIPCC, "-O2", "-std=c++17", "-shared", "-fPIC", "-x", "c++", os.path.join(ROOT, "tests", "native", "fake_rccl.cpp"),
+                           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-o", so],
+                          stderr=subprocess.DEVNULL)
+    return str(d)
+
+
+def run_ranks(fake_dir, tmp_path, text, world, W, H, fmt, flags, seed, frames=1):
+    cfg = tmp_path / "graph.cfg"
+    cfg.write_text(text)
+    env = dict(os.environ, LD_LIBRARY_PATH=fake_dir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "exchange_worker.py"), str(r), str(world), str(W), str(H), str(fmt),
+                               str(flags), str(seed), str(cfg), str(tmp_path), str(frames)], env=env, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    errs = []
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung in the exchange")
+        errs.append((p.returncode, err[-1500:]))
+    assert all(rc == 0 for rc, _ in errs), errs
+    return np.concatenate([np.load(tmp_path / ("strip%d.npy" % r)) for r in range(world)], axis=0)
+
+
+CASES = [(util.CHAIN3, 2, 0), (util.CHAIN5, 3, 0), (util.CHAIN5, 2, rf.RF_GRAPH_NO_FUSION), (util.DIAMOND, 2, 0), (util.CHAIN5_SPLIT, 4, 0)]
+
+
+@pytest.mark.parametrize("text,world,flags", CASES)
+def test_exchange_mode_reproduces_the_full_frame(fake_rccl_dir, tmp_path, text, world, flags):
+    W, H, seed = 333, 257, 0x5EED0004
+    for fmt in (util.F32, util.U8):
+        sub = tmp_path / ("fmt%d" % fmt)
+        sub.mkdir()
+        got = run_ranks(fake_rccl_dir, sub, text, world, W, H, fmt, flags, seed)
+        want = util.run_oracle(text, pixel.fill_synthetic(W, H, fmt, seed))
+        util.assert_same(got, want, "exchange mode, world=%d flags=%d fmt=%d" % (world, flags, fmt))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_exchange_mode_random_graphs(fake_rccl_dir, tmp_path, seed):
+    rng = np.random.RandomState(8000 + seed)
+    text = (util.random_dag if seed & 1 else util.random_graph)(rng)
+    world = int(rng.randint(2, 4))
+    W, H = int(rng.randint(40, 500)), int(rng.randint(150, 400))
+    flags = (0, rf.RF_GRAPH_NO_FUSION)[(seed >> 1) & 1]
+    fmt = (util.F32, util.U8)[seed % 2]
+    if rf.Plan(rf.Config(text), flags).halo_schedule(True)[3] > H // world:
+        pytest.skip("strips shorter than the widest halo")
+    got = run_ranks(fake_rccl_dir, tmp_path, text, world, W, H, fmt, flags, seed)
+    want = util.run_oracle(text, pixel.fill_synthetic(W, H, fmt, seed))
+    util.assert_same(got, want, "exchange mode, world=%d flags=%d\n%s" % (world, flags, text))
+
+
+def test_exchange_mode_several_frames(fake_rccl_dir, tmp_path):
+    """Three frames back to back: the ghost rows of frame n+1 must not be exchanged before frame n's
+    boundary launches have read them (src_ready / halo_ready edges)."""
+    W, H, seed = 500, 301, 11
+    got = run_ranks(fake_rccl_dir, tmp_path, util.CHAIN5, 3, W, H, util.F32, 0, seed, frames=3)
+    util.assert_same(got, util.run_oracle(util.CHAIN5, pixel.fill_synthetic(W, H, util.F32, seed)), "three frames")
