@@ -85,3 +85,11 @@ def test_exchange_mode_several_frames(fake_rccl_dir, tmp_path):
     W, H, seed = 500, 301, 11
     got = run_ranks(fake_rccl_dir, tmp_path, util.CHAIN5, 3, W, H, util.F32, 0, seed, frames=3)
     util.assert_same(got, util.run_oracle(util.CHAIN5, pixel.fill_synthetic(W, H, util.F32, seed)), "three frames")
+
+
+def test_exchange_mode_thin_strips(fake_rccl_dir, tmp_path):
+    """Strips of 15 rows under a 7-row halo: too thin for an interior (rows <= 4 r), so the exchange
+    runs on the launch's own stream in front of one whole-strip launch."""
+    W, H, seed = 211, 60, 5
+    got = run_ranks(fake_rccl_dir, tmp_path, util.CHAIN5, 4, W, H, util.U8, 0, seed)
+    util.assert_same(got, util.run_oracle(util.CHAIN5, pixel.fill_synthetic(W, H, util.U8, seed)), "thin strips")
