@@ -1,6 +1,6 @@
 """One rank of tests/test_gpu_exchange.py: the product in EXCHANGE mode (per-launch neighbour exchange,
 interior/boundary split) with the test double of librccl on the loader path.  Run as a script:
-  exchange_worker.py <rank> <world> <W> <H> <fmt> <flags> <seed> <config file> <out dir> <frames>"""
+  exchange_worker.py <rank> <world> <W> <H> <fmt> <flags> <seed> <config file> <out dir> <frames> [fill|upload|srgb]"""
 import os
 import sys
 import time
@@ -30,12 +30,21 @@ def main():
             time.sleep(0.01)
         uid = open(id_path, "rb").read()
     ctx = rf.Context(0, rank, world, uid)
-    g = rf.Graph(ctx, rf.Config(text), W, H, fmt, flags=flags)       # exchange mode: RF_GRAPH_NO_HALO_XCHG is NOT set
-    g.fill_synthetic(seed)
+    source = sys.argv[11] if len(sys.argv) > 11 else "fill"
+    g = rf.Graph(ctx, rf.Config(text), W, H, fmt, flags=flags)       # exchange mode unless the caller set RF_GRAPH_NO_HALO_XCHG
+    y0, y1 = g.strip
+    if source == "fill":
+        g.fill_synthetic(seed)
+    else:
+        from oracle import pixel                                     # the test's input generator (not the product's)
+        if source == "upload":
+            g.upload_raw(pixel.fill_synthetic(W, H, fmt, seed)[y0:y1])          # a rank uploads ITS rows of the frame
+        else:
+            g.upload_srgb8(pixel.fill_synthetic(W, H, rf.RF_FORMAT_RGBA8, seed)[y0:y1])
     for _ in range(frames):
         g.execute()
     g.wait()
-    np.save(os.path.join(out_dir, "strip%d.npy" % rank), g.download_raw())
+    np.save(os.path.join(out_dir, "strip%d.npy" % rank), g.download_srgb8() if source == "srgb" else g.download_raw())
     g.close()
     ctx.close()
 

@@ -30,12 +30,12 @@ def fake_rccl_dir(tmp_path_factory):
     return str(d)
 
 
-def run_ranks(fake_dir, tmp_path, text, world, W, H, fmt, flags, seed, frames=1):
+def run_ranks(fake_dir, tmp_path, text, world, W, H, fmt, flags, seed, frames=1, source="fill"):
     cfg = tmp_path / "graph.cfg"
     cfg.write_text(text)
     env = dict(os.environ, LD_LIBRARY_PATH=fake_dir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "exchange_worker.py"), str(r), str(world), str(W), str(H), str(fmt),
-                               str(flags), str(seed), str(cfg), str(tmp_path), str(frames)], env=env, stderr=subprocess.PIPE, text=True)
+                               str(flags), str(seed), str(cfg), str(tmp_path), str(frames), source], env=env, stderr=subprocess.PIPE, text=True)
              for r in range(world)]
     errs = []
     for p in procs:
@@ -93,3 +93,31 @@ def test_exchange_mode_thin_strips(fake_rccl_dir, tmp_path):
     W, H, seed = 211, 60, 5
     got = run_ranks(fake_rccl_dir, tmp_path, util.CHAIN5, 4, W, H, util.U8, 0, seed)
     util.assert_same(got, util.run_oracle(util.CHAIN5, pixel.fill_synthetic(W, H, util.U8, seed)), "thin strips")
+
+
+@pytest.mark.parametrize("flags", [0, rf.RF_GRAPH_NO_HALO_XCHG])
+def test_uploaded_strips(fake_rccl_dir, tmp_path, flags):
+    """Each rank uploads ITS rows of a host frame.  Exchange mode trades ghost rows per launch as
+    before; over-fetch mode needs the neighbours' rows of the INPUT once, at upload (the cumulative
+    halo), and nothing afterwards."""
+    W, H, seed = 280, 190, 21
+    for fmt in (util.F32, util.U8):
+        sub = tmp_path / ("fmt%d" % fmt)
+        sub.mkdir()
+        got = run_ranks(fake_rccl_dir, sub, util.CHAIN5, 3, W, H, fmt, flags, seed, source="upload")
+        util.assert_same(got, util.run_oracle(util.CHAIN5, pixel.fill_synthetic(W, H, fmt, seed)), "uploaded strips flags=%d" % flags)
+
+
+def test_srgb_strips(fake_rccl_dir, tmp_path):
+    """The sRGB boundary on strips: every rank uploads and downloads its rows of an RGBA8 frame."""
+    from oracle import graph as og
+    W, H, seed = 200, 160, 31
+    rgba = pixel.fill_synthetic(W, H, util.U8, seed)
+    for fmt in (util.F32, util.U8):
+        sub = tmp_path / ("fmt%d" % fmt)
+        sub.mkdir()
+        got = run_ranks(fake_rccl_dir, sub, util.CHAIN3, 2, W, H, fmt, 0, seed, source="srgb")
+        ref = og.GraphOracle(util.CHAIN3, W, H, fmt)
+        ref.upload_srgb8(rgba)
+        ref.execute()
+        assert got.tobytes() == ref.download_srgb8().tobytes()
