@@ -83,6 +83,14 @@ __global__ __launch_bounds__(256) void conv2d_tile_kernel(const char* src, size_
 // ---------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kMaxDevices = 64;
+static int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    return dev;
+}
+
 constexpr int kConvStripW = 64;     // output columns per workgroup
 constexpr int kConvWRow = 64;       // dwords per padded weight row: 15 zeros, K taps, zeros
 constexpr int kCm2StepRows = 16;                 // output rows per step: 4 M-tiles of 4 rows per wave
@@ -234,7 +242,8 @@ static hipError_t launch_conv_mfma(int steps, dim3 grid, size_t lds, hipStream_t
     } else {
         if (steps != STEPS)
             return launch_conv_mfma<Px, STEPS + 1>(steps, grid, lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0, y1, rpc, K, weights);
-        static bool attr_set = false;
+        static bool attr_done[kMaxDevices] = {};   // the attribute is per device
+        bool& attr_set = attr_done[current_device()];
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<Px, STEPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024);
@@ -362,7 +371,8 @@ static hipError_t launch_conv_valu(int k, dim3 grid, size_t lds, hipStream_t str
         return hipErrorInvalidValue;
     } else {
         if (k != K) return launch_conv_valu<Px, K + 2>(k, grid, lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0, y1, rpc, ring, weights);
-        static bool attr_set = false;
+        static bool attr_done[kMaxDevices] = {};   // the attribute is per device
+        bool& attr_set = attr_done[current_device()];
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_valu_kernel<Px, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;

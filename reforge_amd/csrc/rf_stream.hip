@@ -615,11 +615,14 @@ static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo
 // workgroups of this kernel the whole chip holds at once
 template <class Px, int PF, class... S> static int resident_workgroups()
 {
-    static int slots = 0;
+    static int slots_of[64] = {};                    // per device: a process may hold contexts on several GPUs
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int& slots = slots_of[dev];
     if (slots == 0) {
-        int per_cu = 0, dev = 0, cus = 256;
+        int per_cu = 0, cus = 256;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_kernel<Px, PF, S...>, 64 * kWavesPerBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         slots = per_cu * (cus > 0 ? cus : 256);
     }
     return slots;
