@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RF_ABI_VERSION 1
+#define RF_ABI_VERSION 2
 
 typedef enum rf_status {
     RF_OK              = 0,
@@ -65,12 +65,29 @@ typedef struct rf_config rf_config;  /* config::Config    src/config/config.rs:3
 typedef struct rf_plan   rf_plan;    /* layers + aliasing src/vulkan/pipeline_graph.rs:358-497 */
 typedef struct rf_graph  rf_graph;   /* PipelineGraph + its frames  pipeline_graph.rs:43-57    */
 
+/* rf_graph_options.exec_flags: executor variants kept for measurement and for the tests.
+ * Each also has an environment override read at rf_graph_create (RF_SYNC_LAUNCHES=1, ...):
+ * the environment wins when set. */
+#define RF_EXEC_SYNC_LAUNCHES     0x1u  /* host-synchronise after every launch (debugging aid)       */
+#define RF_EXEC_CONCURRENT_LAYERS 0x2u  /* launches of a hazard-free layer on side streams, as the
+                                           reference lets a layer overlap (command.rs:194-240)      */
+#define RF_EXEC_FORCE_SPLIT       0x4u  /* interior/boundary three-part stencil launch without an
+                                           exchange (how the multi-rank split is tested on one GPU) */
+#define RF_EXEC_NO_ALTERNATE      0x8u  /* every chunk walks top-down                                */
+#define RF_EXEC_NO_JIT            0x10u /* never compile a fused chain at graph creation: only the
+                                           ahead-of-time catalogue fuses                            */
+
 typedef struct rf_graph_options {
     int       width;        /* RenderInfo.width   src/render.rs:40 */
     int       height;       /* RenderInfo.height  (the FULL frame height on every rank) */
     rf_format format;       /* RenderInfo.format  */
     int       num_frames;   /* frames in flight   src/main.rs:69-70; >= 1 */
     uint32_t  flags;        /* RF_GRAPH_* */
+    /* tuning, 0 = the library's own choice (RF_ABI_VERSION >= 2; no reference counterpart) */
+    int       rows_per_chunk; /* rows a wave walks per chunk (env RF_ROWS_PER_CHUNK)              */
+    int       conv_path;      /* conv2d kernel: 0 auto, 1 LDS tile, 2 MFMA band, 3 VALU, 4 hybrid
+                                 (env RF_CONV_PATH)                                               */
+    uint32_t  exec_flags;     /* RF_EXEC_* */
 } rf_graph_options;
 
 /* ------------------------------------------------------------------------- */
@@ -182,6 +199,9 @@ rf_status rf_ctx_create(int device, rf_ctx** out);
 /* [host] fills a 128-byte RCCL unique id on the calling rank (rank 0) for
  * rf_ctx_create_dist; the caller broadcasts the bytes to the other ranks */
 rf_status rf_comm_unique_id(void* id128);
+/* [host] path of the RCCL library the halo exchange calls into (loaded on first use; "" if it
+ * cannot be loaded).  dlopen by SONAME: a copy the process has already mapped wins. */
+const char* rf_comm_library(void);
 /* one process per GPU: rank `rank` of `world` ranks on one node, neighbour halo
  * exchange over RCCL.  `id128` = the bytes produced by rf_comm_unique_id on rank 0 */
 rf_status rf_ctx_create_dist(int device, int rank, int world, const void* id128, rf_ctx** out);

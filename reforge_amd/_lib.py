@@ -29,10 +29,19 @@ RF_GRAPH_NO_FUSION = 0x2
 RF_GRAPH_HIPGRAPH = 0x4
 RF_GRAPH_NO_HALO_XCHG = 0x8
 
+RF_EXEC_SYNC_LAUNCHES = 0x1
+RF_EXEC_CONCURRENT_LAYERS = 0x2
+RF_EXEC_FORCE_SPLIT = 0x4
+RF_EXEC_NO_ALTERNATE = 0x8
+RF_EXEC_NO_JIT = 0x10
+
+RF_CONV_AUTO, RF_CONV_TILE, RF_CONV_MFMA, RF_CONV_VALU, RF_CONV_HYBRID = 0, 1, 2, 3, 4
+
 
 class GraphOptions(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("format", C.c_int),
-                ("num_frames", C.c_int), ("flags", C.c_uint32)]
+                ("num_frames", C.c_int), ("flags", C.c_uint32),
+                ("rows_per_chunk", C.c_int), ("conv_path", C.c_int), ("exec_flags", C.c_uint32)]
 
 
 _vp, _cp, _i, _sz, _u32, _f = C.c_void_p, C.c_char_p, C.c_int, C.c_size_t, C.c_uint32, C.c_float
@@ -86,6 +95,7 @@ SIGNATURES = {
     "rf_strip_rows": (_i, [_i, _i, _i, _pi, _pi]),
     "rf_ctx_create": (_i, [_i, _pvp]),
     "rf_comm_unique_id": (_i, [_vp]),
+    "rf_comm_library": (_cp, []),
     "rf_ctx_create_dist": (_i, [_i, _i, _i, _vp, _pvp]),
     "rf_ctx_destroy": (None, [_vp]),
     "rf_ctx_synchronize": (_i, [_vp]),

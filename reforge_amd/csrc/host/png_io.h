@@ -195,6 +195,8 @@ inline bool read_png(const std::string& path, int& w, int& h, std::vector<uint8_
         if (pos + 12 + len > file.size()) { err = "truncated chunk"; return false; }
         const uint8_t* type = &file[pos + 4];
         const uint8_t* data = &file[pos + 8];
+        // chunk CRC-32 over type + data: a corrupt file fails here instead of decoding silently
+        if ((crc32_update(0xFFFFFFFFu, type, 4 + (size_t)len) ^ 0xFFFFFFFFu) != be32(data + len)) { err = "chunk CRC mismatch"; return false; }
         if (std::memcmp(type, "IHDR", 4) == 0 && len >= 13) {
             w = (int)be32(data);
             h = (int)be32(data + 4);
@@ -209,6 +211,9 @@ inline bool read_png(const std::string& path, int& w, int& h, std::vector<uint8_
         pos += 12 + len;
     }
     if (w < 1 || h < 1) { err = "missing IHDR"; return false; }
+    // a crafted IHDR must not drive the allocations below: 2^28 pixels (1 GiB of RGBA8) is far
+    // beyond any frame this host uploads
+    if ((uint64_t)w * (uint64_t)h > (1ull << 28)) { err = "image dimensions too large"; return false; }
     int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (depth != 8 || ch == 0 || interlace != 0) { err = "only 8-bit grey/RGB/RGBA non-interlaced PNGs are decoded"; return false; }
     std::vector<uint8_t> raw;

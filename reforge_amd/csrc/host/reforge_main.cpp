@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <exception>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -195,7 +196,23 @@ double now_ms()
 
 }  // namespace
 
+static int run(int argc, char** argv);
+
+// Nothing may escape main as an exception: a malformed input file or an allocation failure ends the
+// run with a warning and exit code 1, like the reference's Option::None + warnln! paths.
 int main(int argc, char** argv)
+{
+    try {
+        return run(argc, argv);
+    } catch (const std::exception& e) {
+        warnln(std::string("fatal: ") + e.what());
+    } catch (...) {
+        warnln("fatal: unknown exception");
+    }
+    return 1;
+}
+
+static int run(int argc, char** argv)
 {
     Args args;
     if (!parse_args(argc, argv, args)) { usage(); return 2; }

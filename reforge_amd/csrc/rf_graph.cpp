@@ -2,9 +2,12 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
+#include "rf_rccl_abi.h"
 #include "rf_runtime.h"
 
 using namespace rf;
@@ -15,22 +18,18 @@ using namespace rf;
 // ---------------------------------------------------------------------------------
 namespace {
 
-struct NcclId { char internal[128]; };
-typedef int (*InitRankFn)(void**, int, NcclId, int);
-
 struct RcclLib {
     void* handle = nullptr;
-    int (*GetUniqueId)(NcclId*) = nullptr;
-    InitRankFn CommInitRank = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
+    std::string path;                       // the file the symbols came from (dladdr)
+    NcclGetUniqueIdFn GetUniqueId = nullptr;
+    NcclCommInitRankFn CommInitRank = nullptr;
+    NcclCommDestroyFn CommDestroy = nullptr;
+    NcclSendFn Send = nullptr;
+    NcclRecvFn Recv = nullptr;
+    NcclGroupFn GroupStart = nullptr;
+    NcclGroupFn GroupEnd = nullptr;
+    NcclGetErrorStringFn GetErrorString = nullptr;
 };
-
-constexpr int kNcclChar = 0;   // ncclInt8 / ncclChar
 
 RcclLib* rccl_lib(std::string& err)
 {
@@ -51,20 +50,25 @@ RcclLib* rccl_lib(std::string& err)
         if (!p) ok = false;
         return p;
     };
-    lib.GetUniqueId = (int (*)(NcclId*))sym("ncclGetUniqueId");
-    lib.CommInitRank = (InitRankFn)sym("ncclCommInitRank");
-    lib.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
-    lib.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
-    lib.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
-    lib.GroupStart = (int (*)())sym("ncclGroupStart");
-    lib.GroupEnd = (int (*)())sym("ncclGroupEnd");
-    lib.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    lib.GetUniqueId = (NcclGetUniqueIdFn)sym("ncclGetUniqueId");
+    lib.CommInitRank = (NcclCommInitRankFn)sym("ncclCommInitRank");
+    lib.CommDestroy = (NcclCommDestroyFn)sym("ncclCommDestroy");
+    lib.Send = (NcclSendFn)sym("ncclSend");
+    lib.Recv = (NcclRecvFn)sym("ncclRecv");
+    lib.GroupStart = (NcclGroupFn)sym("ncclGroupStart");
+    lib.GroupEnd = (NcclGroupFn)sym("ncclGroupEnd");
+    lib.GetErrorString = (NcclGetErrorStringFn)sym("ncclGetErrorString");
     if (!ok) {
         err = "librccl.so lacks a required symbol";
         dlclose(lib.handle);
         lib.handle = nullptr;
         return nullptr;
     }
+    // dlopen by SONAME returns a copy that is ALREADY mapped (PyTorch ships its own librccl.so with
+    // SONAME librccl.so.1: under bench.py both communicators then live in that one library instance,
+    // which is what RCCL expects); record the file for rf_comm_library()
+    Dl_info info;
+    if (dladdr((void*)lib.Send, &info) && info.dli_fname) lib.path = info.dli_fname;
     return &lib;
 }
 
@@ -124,15 +128,43 @@ rf_status exchange_rows(rf_graph* g, const DeviceImage& img, int r, hipStream_t 
     const int Hs = strip_rows_of(g);
     const size_t bytes = (size_t)r * img.pitch;
     NCCL_TRY(lib, lib->GroupStart());
+    // every exit below closes the group: a return from inside an open ncclGroupStart would leave
+    // the communicator collecting the NEXT caller's operations into this half-built group
+    int rc = 0;
+    const char* what = "";
+    auto step = [&](int r_, const char* w) {
+        if (rc == 0 && r_ != 0) { rc = r_; what = w; }
+    };
     if (ctx->rank > 0) {
-        NCCL_TRY(lib, lib->Send(img.base, bytes, kNcclChar, ctx->rank - 1, ctx->comm, stream));
-        NCCL_TRY(lib, lib->Recv(img.base - (ptrdiff_t)bytes, bytes, kNcclChar, ctx->rank - 1, ctx->comm, stream));
+        step(lib->Send(img.base, bytes, kNcclChar, ctx->rank - 1, ctx->comm, stream), "ncclSend(up)");
+        if (rc == 0) step(lib->Recv(img.base - (ptrdiff_t)bytes, bytes, kNcclChar, ctx->rank - 1, ctx->comm, stream), "ncclRecv(up)");
     }
-    if (ctx->rank < ctx->world - 1) {
-        NCCL_TRY(lib, lib->Send(img.base + (size_t)(Hs - r) * img.pitch, bytes, kNcclChar, ctx->rank + 1, ctx->comm, stream));
-        NCCL_TRY(lib, lib->Recv(img.base + (size_t)Hs * img.pitch, bytes, kNcclChar, ctx->rank + 1, ctx->comm, stream));
+    if (rc == 0 && ctx->rank < ctx->world - 1) {
+        step(lib->Send(img.base + (size_t)(Hs - r) * img.pitch, bytes, kNcclChar, ctx->rank + 1, ctx->comm, stream), "ncclSend(down)");
+        if (rc == 0) step(lib->Recv(img.base + (size_t)Hs * img.pitch, bytes, kNcclChar, ctx->rank + 1, ctx->comm, stream), "ncclRecv(down)");
     }
-    NCCL_TRY(lib, lib->GroupEnd());
+    const int rc_end = lib->GroupEnd();
+    if (rc != 0) return fail(RF_ERR_DEVICE, std::string(what) + ": " + lib->GetErrorString(rc));
+    if (rc_end != 0) return fail(RF_ERR_DEVICE, std::string("ncclGroupEnd: ") + lib->GetErrorString(rc_end));
+    // The first exchange of a context is where a mis-paired send/recv (ranks that disagree about the
+    // plan) would hang forever.  Wait for it with a deadline instead: poll the stream, give up after
+    // RF_XCHG_TIMEOUT_S seconds (default 60) with RF_ERR_DEVICE, never block without bound.
+    if (!ctx->exchanged_once) {
+        double limit_s = 60.0;
+        if (const char* e = std::getenv("RF_XCHG_TIMEOUT_S")) limit_s = std::atof(e) > 0 ? std::atof(e) : limit_s;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return fail(RF_ERR_DEVICE, std::string("halo exchange: ") + hipGetErrorString(q));
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
+                return fail(RF_ERR_DEVICE, "halo exchange: the first neighbour send/recv of rank " + std::to_string(ctx->rank) + " of " +
+                                               std::to_string(ctx->world) + " did not complete in " + std::to_string((int)limit_s) +
+                                               " s (ranks disagree about the graph, or a rank is missing)");
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        ctx->exchanged_once = true;
+    }
     return RF_OK;
 }
 
@@ -311,6 +343,13 @@ extern "C" rf_status rf_comm_unique_id(void* id128)
     return RF_OK;
 }
 
+extern "C" const char* rf_comm_library(void)
+{
+    std::string err;
+    RcclLib* lib = rccl_lib(err);
+    return lib ? lib->path.c_str() : "";
+}
+
 extern "C" rf_status rf_ctx_create_dist(int device, int rank, int world, const void* id128, rf_ctx** out)
 {
     if (world < 1 || rank < 0 || rank >= world) return fail(RF_ERR_INVALID, "rf_ctx_create_dist: bad rank/world");
@@ -449,12 +488,23 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
         return fail(RF_ERR_UNSUPPORTED, "strip height " + std::to_string(opt.height / ctx->world) +
                                             " is smaller than the halo " + std::to_string(g->ghost));
 
+    // tuning and executor variants: rf_graph_options first, the environment overrides when set
+    g->tune.rows_per_chunk = opt.rows_per_chunk;
+    g->tune.conv_path = opt.conv_path;
+    g->tune.no_alternate = (opt.exec_flags & RF_EXEC_NO_ALTERNATE) ? 1 : 0;
+    g->sync_launches = (opt.exec_flags & RF_EXEC_SYNC_LAUNCHES) != 0;
+    g->concurrent_layers = (opt.exec_flags & RF_EXEC_CONCURRENT_LAYERS) != 0;
+    g->force_split = (opt.exec_flags & RF_EXEC_FORCE_SPLIT) != 0;
     if (const char* e = std::getenv("RF_ROWS_PER_CHUNK")) g->tune.rows_per_chunk = std::atoi(e);
     if (const char* e = std::getenv("RF_CONV_PATH")) g->tune.conv_path = std::atoi(e);
     if (const char* e = std::getenv("RF_SYNC_LAUNCHES")) g->sync_launches = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_CONCURRENT_LAYERS")) g->concurrent_layers = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_FORCE_SPLIT")) g->force_split = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_NO_ALTERNATE")) g->tune.no_alternate = std::atoi(e);
+    // Exchange mode shares ONE comm stream and one src_ready/halo_ready event pair per slot: two
+    // stencils of a layer reading the same source would each re-exchange its ghost rows while the
+    // other's boundary kernels may still read them.  Plan order on one stream keeps it ordered.
+    if (exchange_mode(g)) g->concurrent_layers = false;
 
     // per-frame images, streams, events (PipelineGraphFrame::new, Frame::new)
     const size_t pitch = align_up((size_t)opt.width * bytes_per_pixel(opt.format), 256);

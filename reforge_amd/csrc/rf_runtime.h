@@ -51,6 +51,7 @@ struct rf_ctx {
     float* d_tables = nullptr;             // sRGB eotf[256] ++ thr[255]
     void* comm = nullptr;                  // ncclComm_t
     const rf::RcclApi* rccl = nullptr;
+    bool exchanged_once = false;           // the first halo exchange is waited for with a deadline
 };
 
 namespace rf {

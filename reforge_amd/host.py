@@ -217,10 +217,11 @@ _DTYPES = {_lib.RF_FORMAT_RGBA8: np.uint8, _lib.RF_FORMAT_RGBA32F: np.float32}
 class Graph:
     """PipelineGraph + its per-frame resources (src/vulkan/pipeline_graph.rs:43-57)."""
 
-    def __init__(self, ctx, config, width, height, fmt=_lib.RF_FORMAT_RGBA32F, num_frames=1, flags=0):
+    def __init__(self, ctx, config, width, height, fmt=_lib.RF_FORMAT_RGBA32F, num_frames=1, flags=0,
+                 rows_per_chunk=0, conv_path=0, exec_flags=0):
         self.ctx, self.width, self.height, self.format = ctx, width, height, fmt
         self._h = C.c_void_p()
-        opt = _lib.GraphOptions(width, height, fmt, num_frames, flags)
+        opt = _lib.GraphOptions(width, height, fmt, num_frames, flags, rows_per_chunk or 0, conv_path, exec_flags)
         _check(lib().rf_graph_create(ctx.handle, config.handle, C.byref(opt), C.byref(self._h)), "rf_graph_create")
         y0, y1 = C.c_int(), C.c_int()
         _check(lib().rf_graph_strip(self._h, C.byref(y0), C.byref(y1)), "rf_graph_strip")
@@ -408,6 +409,7 @@ class Render:
             self.graph.close()
         self.graph = g
         self._first_run = [True] * self.info.num_frames
+        self._input_loaded = False
         return True
 
     def staging_buffer(self):                 # staging_buffer_ptr, render.rs:60
@@ -436,10 +438,14 @@ class Render:
         return self.graph.times_string(self.frame_index)
 
     def record_initial_image_load(self):      # render.rs:264-313
+        # rf_graph_upload_srgb8 writes the input image of EVERY frame slot, so it runs once per
+        # graph (reforge_main.cpp's load_input does the same); the reference uploads per slot
+        # because each of its slots owns a private input image (main.rs:164-170)
         self.graph.upload_srgb8(self.staging)
+        self._input_loaded = True
 
     def record(self):                         # render.rs:359-404
-        if self._first_run[self.frame_index] and self.info.has_input_image:
+        if self._first_run[self.frame_index] and self.info.has_input_image and not self._input_loaded:
             self.record_initial_image_load()
         self._first_run[self.frame_index] = False
 

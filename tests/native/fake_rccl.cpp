@@ -24,7 +24,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
+
+#include "rf_rccl_abi.h"   // the function types the product calls through (checked against the real rccl.h by rccl_abi_check.cpp)
 
 namespace {
 
@@ -49,7 +52,7 @@ struct Comm {
     std::string name;
 };
 
-struct Id { char internal[128]; };
+typedef rf::NcclId Id;   // the product's own view of ncclUniqueId
 
 struct Op {
     bool send;
@@ -170,3 +173,13 @@ const char* ncclGetErrorString(int r)
 }
 
 }  // extern "C"
+
+// the double implements exactly the types the product binds
+static_assert(std::is_same<decltype(&ncclGetUniqueId), rf::NcclGetUniqueIdFn>::value, "ncclGetUniqueId");
+static_assert(std::is_same<decltype(&ncclCommInitRank), rf::NcclCommInitRankFn>::value, "ncclCommInitRank");
+static_assert(std::is_same<decltype(&ncclCommDestroy), rf::NcclCommDestroyFn>::value, "ncclCommDestroy");
+static_assert(std::is_same<decltype(&ncclSend), rf::NcclSendFn>::value, "ncclSend");
+static_assert(std::is_same<decltype(&ncclRecv), rf::NcclRecvFn>::value, "ncclRecv");
+static_assert(std::is_same<decltype(&ncclGroupStart), rf::NcclGroupFn>::value, "ncclGroupStart");
+static_assert(std::is_same<decltype(&ncclGroupEnd), rf::NcclGroupFn>::value, "ncclGroupEnd");
+static_assert(std::is_same<decltype(&ncclGetErrorString), rf::NcclGetErrorStringFn>::value, "ncclGetErrorString");

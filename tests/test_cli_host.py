@@ -14,6 +14,17 @@ from tests import util
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "reforge_amd", "reforge")
+CLI_SRC = [os.path.join(ROOT, "reforge_amd", "csrc", "host", f) for f in ("reforge_main.cpp", "png_io.h")]
+
+
+@pytest.fixture(autouse=True, scope="module")
+def cli_is_fresh():
+    """The binary is a build artefact (git-ignored): a missing one, or one older than its sources,
+    must fail these tests instead of quietly exercising something stale."""
+    assert os.path.exists(CLI), "reforge_amd/reforge is not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
+    newest = max(os.path.getmtime(f) for f in CLI_SRC)
+    assert os.path.getmtime(CLI) >= newest, "reforge_amd/reforge is older than csrc/host/*: rebuild"
+
 
 
 def write_png(path, img, filt):

@@ -25,7 +25,7 @@ def fake_rccl_dir(tmp_path_factory):
     d = tmp_path_factory.mktemp("fake_rccl")
     so = str(d / "librccl.so.1")
     subprocess.check_call([HIPCC, "-O2", "-std=c++17", "-shared", "-fPIC", "-x", "c++", os.path.join(ROOT, "tests", "native", "fake_rccl.cpp"),
-                           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-o", so],
+                           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "reforge_amd", "csrc"), "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-o", so],
                           stderr=subprocess.DEVNULL)
     return str(d)
 

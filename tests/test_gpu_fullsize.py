@@ -23,18 +23,8 @@ GAUSS9 = "input -> gaussian9 -> output\ngaussian9: gaussian9 { sigma: 2.0 }"
 CONV31 = "input -> conv2d -> output\nconv2d: conv2d { ksize: 31, sigma: 5.0 }"
 
 
-def gpu_frame(ctx, text, W, H, fmt, seed, flags=0, rpc=None):
-    old = os.environ.get("RF_ROWS_PER_CHUNK")
-    if rpc is not None:
-        os.environ["RF_ROWS_PER_CHUNK"] = str(rpc)
-    try:
-        g = rf.Graph(ctx, rf.Config(text), W, H, fmt, flags=flags)
-    finally:
-        if rpc is not None:
-            if old is None:
-                os.environ.pop("RF_ROWS_PER_CHUNK", None)
-            else:
-                os.environ["RF_ROWS_PER_CHUNK"] = old
+def gpu_frame(ctx, text, W, H, fmt, seed, flags=0, rpc=None, conv_path=0):
+    g = rf.Graph(ctx, rf.Config(text), W, H, fmt, flags=flags, rows_per_chunk=rpc or 0, conv_path=conv_path)
     g.fill_synthetic(seed)
     g.execute()
     g.wait()
@@ -102,6 +92,10 @@ def test_config5_conv31_8k_band(ctx):
     W, H, seed = 7680, 4320, 0x5EED0005
     out = gpu_frame(ctx, CONV31, W, H, util.F32, seed)
     band_check(out, CONV31, W, H, util.F32, seed, 15, [(0, 2), (2159, 2161), (4318, 4320)])
+    # every large-K kernel at the full size: the banded MFMA contraction north_star names, the
+    # register-blocked VALU kernel and the hybrid of the two must all produce the same frame
+    for path in (rf.RF_CONV_MFMA, rf.RF_CONV_VALU, rf.RF_CONV_HYBRID):
+        assert gpu_frame(ctx, CONV31, W, H, util.F32, seed, conv_path=path).tobytes() == out.tobytes(), "conv path %d at 8K" % path
     # linearity in the input survives at full size: conv(x) of a constant frame is that
     # constant times the kernel sum, identical at every pixel away from nothing (clamp-to-edge
     # keeps a constant frame constant everywhere)
@@ -114,21 +108,20 @@ def test_config5_conv31_8k_band(ctx):
 
 
 @pytest.mark.parametrize("seed", range(16))
-def test_random_graphs_1080p_whole_frame(ctx, seed, monkeypatch):
+def test_random_graphs_1080p_whole_frame(ctx, seed):
     """Generated graphs at 1920x1080, the whole frame against the oracle, both formats: enough
     strips and chunks for every seam, both walk directions and multi-round launches -- and enough
     waves in flight for timing-dependent faults to show (this test found the in-place/fork race of
     a layer, the fused in-place head and a ds_read that an LDS-DMA refill could overtake)."""
     text = (util.random_graph if seed < 8 else util.random_dag)(np.random.RandomState(7000 + seed))
-    if seed & 1:
-        monkeypatch.setenv("RF_CONCURRENT_LAYERS", "1")       # hazard-free layers forked onto side streams
+    ex = rf.RF_EXEC_CONCURRENT_LAYERS if seed & 1 else 0      # hazard-free layers forked onto side streams
     pixel.set_threads(min(16, os.cpu_count() or 1))
     try:
         for fmt in (util.F32, util.U8):
             x = pixel.fill_synthetic(1920, 1080, fmt, 0x5EED0000 + seed)
             want = util.run_oracle(text, x)
-            util.assert_same(util.run_hip(ctx, text, x), want, "1080p seed %d fused\n%s" % (seed, text))
-            util.assert_same(util.run_hip(ctx, text, x, flags=NF), want, "1080p seed %d unfused\n%s" % (seed, text))
+            util.assert_same(util.run_hip(ctx, text, x, exec_flags=ex), want, "1080p seed %d fused\n%s" % (seed, text))
+            util.assert_same(util.run_hip(ctx, text, x, flags=NF, exec_flags=ex), want, "1080p seed %d unfused\n%s" % (seed, text))
     finally:
         pixel.set_threads(1)
 

@@ -205,14 +205,13 @@ def test_non_finite_texels_propagate_like_the_oracle(ctx):
             assert ok.all(), "%s flags=%d: %d finite texels differ" % (name, flags, (~ok).sum())
 
 
-@pytest.mark.parametrize("path", ["1", "2", "3"])
-def test_conv2d_every_kernel_path(ctx, path, monkeypatch):
+@pytest.mark.parametrize("path", [1, 2, 3, 4])
+def test_conv2d_every_kernel_path(ctx, path):
     """The three conv2d kernels (1 = 16x16 LDS tile, 2 = banded MFMA, 3 = register-blocked VALU)
     are all bit-identical to the oracle: ragged widths around the 64/128-column strips, heights
     around the 16/32-row steps (several steps per chunk: the register-prefetched ring refill),
-    frame edges inside the halo.  K < 9 has no MFMA kernel: path 2 then takes the VALU kernel."""
-    monkeypatch.setenv("RF_CONV_PATH", path)
-    monkeypatch.setenv("RF_ROWS_PER_CHUNK", "64")
+    frame edges inside the halo.  K < 9 has no MFMA kernel: path 2 then takes the VALU kernel.
+    Path 4 is the MFMA + VALU hybrid (K >= 9, else VALU).  Selected through rf_graph_options."""
     for K, sigma in ((3, 0.8), (5, 1.0), (9, 1.5), (13, 2.0), (21, 3.5), (31, 5.0)):
         text = "input -> conv2d -> output\nconv2d: conv2d { ksize: %d, sigma: %.1f }" % (K, sigma)
         rng = np.random.RandomState(K)
@@ -220,8 +219,8 @@ def test_conv2d_every_kernel_path(ctx, path, monkeypatch):
         for fmt in (util.F32, util.U8):
             for W, H in ((7, 5), (65, 9), (129, 17), (200, 45), (131, 150)):
                 x = util.synthetic(W, H, fmt, seed=K * 100 + W)
-                util.assert_same(util.run_hip(ctx, text, x, weights={"conv2d": w}), util.run_oracle(text, x, {"conv2d": w}),
-                                 "conv path %s K=%d %dx%d fmt=%d" % (path, K, W, H, fmt))
+                util.assert_same(util.run_hip(ctx, text, x, weights={"conv2d": w}, conv_path=path, rows_per_chunk=64),
+                                 util.run_oracle(text, x, {"conv2d": w}), "conv path %s K=%d %dx%d fmt=%d" % (path, K, W, H, fmt))
 
 
 # ---- the sRGB boundary (render.rs:264-313, :406-433) ------------------------------------
@@ -365,17 +364,16 @@ def test_row_strips_overfetch_on_one_gpu(text, world, flags):
         util.assert_same(np.concatenate(strips, axis=0), want, "world=%d flags=%d fmt=%d" % (world, flags, fmt))
 
 
-def test_interior_boundary_split(ctx, monkeypatch):
+def test_interior_boundary_split(ctx):
     """Exchange mode overlaps the halo exchange with the interior rows by issuing a stencil
     launch in three parts (interior, top r rows, bottom r rows).  RF_FORCE_SPLIT=1 takes that
     path on one rank without the exchange: the three parts must tile the frame exactly."""
-    monkeypatch.setenv("RF_FORCE_SPLIT", "1")
     for fmt in (util.F32, util.U8):
         x = util.synthetic(211, 157, fmt, seed=5)
         for text in (util.CHAIN3, util.CHAIN5, util.DIAMOND, NODES["gaussian_r7"], NODES["conv9"]):
             want = util.run_oracle(text, x)
             for flags in (0, NF, rf.RF_GRAPH_TIMERS):
-                util.assert_same(util.run_hip(ctx, text, x, flags=flags), want, "split flags=%d" % flags)
+                util.assert_same(util.run_hip(ctx, text, x, flags=flags, exec_flags=rf.RF_EXEC_FORCE_SPLIT), want, "split flags=%d" % flags)
 
 
 def test_exchange_mode_needs_a_communicator():
@@ -393,7 +391,7 @@ def test_exchange_mode_needs_a_communicator():
 
 # ---- random graphs --------------------------------------------------------------------------
 @pytest.mark.parametrize("seed", range(40))
-def test_random_graphs(ctx, seed, monkeypatch):
+def test_random_graphs(ctx, seed):
     """Planner (layering, aliasing, in-place point ops, fusion with greedy splitting) and kernels
     together, on graphs nobody wrote by hand: fused, unfused and hipGraph execution all equal the
     oracle, both formats -- with the layers in plan order (default) and, every other seed, with
@@ -401,13 +399,12 @@ def test_random_graphs(ctx, seed, monkeypatch):
     rng = np.random.RandomState(1000 + seed)
     text = (util.random_graph if seed < 24 else util.random_dag)(rng)
     W, H = int(rng.randint(1, 200)), int(rng.randint(1, 120))
-    if seed & 1:
-        monkeypatch.setenv("RF_CONCURRENT_LAYERS", "1")
+    ex = rf.RF_EXEC_CONCURRENT_LAYERS if seed & 1 else 0
     for fmt in (util.F32, util.U8):
         x = util.synthetic(W, H, fmt, seed=seed)
         want = util.run_oracle(text, x)
         for flags in (0, NF, rf.RF_GRAPH_HIPGRAPH):
-            util.assert_same(util.run_hip(ctx, text, x, flags=flags), want, "seed %d flags %d %dx%d\n%s" % (seed, flags, W, H, text))
+            util.assert_same(util.run_hip(ctx, text, x, flags=flags, exec_flags=ex), want, "seed %d flags %d %dx%d\n%s" % (seed, flags, W, H, text))
 
 
 @pytest.mark.parametrize("seed", range(10))
@@ -434,7 +431,7 @@ def test_random_graphs_as_row_strips(seed, monkeypatch):
             g.close()
             c.close()
         util.assert_same(np.concatenate(strips, axis=0), want, "strips seed=%d world=%d flags=%d\n%s" % (seed, world, flags, text))
-    monkeypatch.setenv("RF_FORCE_SPLIT", "1")
+    monkeypatch.setenv("RF_FORCE_SPLIT", "1")          # the environment form of RF_EXEC_FORCE_SPLIT (it overrides the options)
     c = rf.Context(0)
     x = util.synthetic(W, H, util.F32, seed=seed)
     util.assert_same(util.run_hip(c, text, x, flags=flags), util.run_oracle(text, x), "forced split seed=%d\n%s" % (seed, text))
