@@ -1,28 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- the headline metric of BASELINE.json on MI355X:
   Mpixels/s of the 3-stage rgba32f chain (gaussian5 -> colour_grade -> sharpen) on a
-  3840x2160 frame, one frame per step, plus the HBM-roofline fraction of the dominant
-  kernel and the CPU oracle timed beside it.
+  3840x2160 frame, plus the HBM-roofline fraction of the dominant kernel, the CPU oracle
+  timed beside it, and -- in the same JSON line -- every other BASELINE config.
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One process per GPU.  N > 1 is WEAK scaling: rank r owns a 3840x2160 row strip of a
-3840x(2160*N) frame (reforge's frames shard as row strips).  By default the
-strips carry their own halo (over-fetch: the chain's 3 ghost rows are generated with the
-strip, so a step needs no communication); `--halo exchange` runs the per-launch RCCL
-neighbour exchange instead.
+A STEP is one pass of the hot path over one batch of `frames_per_step` synthetic frames: each
+frame is one rf_graph_execute = one full pass of the whole graph over the whole frame (nothing
+is cached between frames).  The batch size is chosen in the warm-up so that the K timed steps
+last about 0.6 s (a 4K frame takes ~45 us; a timed region of a few ms says little).  The timed
+region contains exactly K steps on inputs already resident in HBM, bracketed by a barrier +
+device synchronize on both sides; the slowest rank's time is the job's time.
 
-A step is one pass of the hot path over one batch of `--frames-per-step` (default 8)
-synthetic frames: each frame is one rf_graph_execute = one full pass of the whole graph
-over the whole frame (nothing is cached between frames); batching only keeps the timed
-region long against the closing barrier when K is small.  The timed region contains
-exactly K steps on inputs already resident in HBM, bracketed by a barrier + device
-synchronize on both sides; the slowest rank's time is the job's time.  The oracle is used
-only for the cpu_baseline leg.
+N = 1 (default): headline workload = BASELINE configs[1]; the `workloads` block then times
+configs[2..4] (gauss9_8k, chain5_16k whole frame on one GPU, conv31_8k on each of its kernels)
+plus the rgba8 chain and the fork/join diamond, each with launch_ms, roofline and `verified`:
+after the timed frames, bands of output rows are copied back and compared bit for bit with the
+oracle run on the same synthetic rows (the oracle is the checker here, never the thing timed).
+
+N > 1: one process per GPU, row strips.  The headline is WEAK scaling: rank r
+owns a 3840x2160 strip of a 3840x(2160*N) frame.  Both halo schedules are timed, K steps each:
+  over-fetch  the strips carry the chain's cumulative halo, no communication per frame;
+  exchange    the per-launch RCCL neighbour send/recv over xGMI overlapped with the interior
+              rows (the north-star path): `value` is THIS one when it ran.
+Then BASELINE configs[3], 16384^2 5-stage chain as N row strips (STRONG scaling), both schedules:
+`strong_16k`.  Compare with workloads.chain5_16k of the N = 1 run for the speed-up.
 """
 import argparse
+import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -45,29 +54,108 @@ sharp:  sharpen      { amount: 0.5 }
 wide:   gaussian9    { sigma: 2.0 }
 finish: colour_grade { slope: 0.95, offset: 0.01, saturation: 0.9 }
 """
+DIAMOND = """
+input -> blur -> mixer:input_image0
+input -> sharp -> mixer:input_image1
+mixer -> output
+blur:  gaussian5   { sigma: 1.5 }
+sharp: sharpen     { amount: 0.75 }
+mixer: combination { mix: 0.25 }
+"""
 
-# name -> (config text, W, H per GPU, nodes, seed, description, strong?)
+F32, U8 = 1, 0
+# name -> dict(text, W, H (per GPU when weak), fmt, nodes, seed, radius (total vertical halo), desc, strong)
 WORKLOADS = {
-    "chain3_4k": (CHAIN3, 3840, 2160, 3, 0x5EED0002,
-                  "BASELINE configs[1]: gaussian5 -> colour_grade -> sharpen, 3840x2160 rgba32f", False),
-    "gauss9_8k": ("input -> gaussian9 -> output\ngaussian9: gaussian9 { sigma: 2.0 }", 7680, 4320, 1, 0x5EED0003,
-                  "BASELINE configs[2]: 9x9 separable gaussian, 7680x4320 rgba32f", False),
-    "chain5_16k": (CHAIN5, 16384, 16384, 5, 0x5EED0004,
-                   "BASELINE configs[3]: 5-stage chain, 16384x16384 rgba32f, row strips (STRONG scaling)", True),
-    "conv31_8k": ("input -> conv2d -> output\nconv2d: conv2d { ksize: 31, sigma: 5.0 }", 7680, 4320, 1, 0x5EED0005,
-                  "BASELINE configs[4]: 31x31 dense convolution, 7680x4320 rgba32f", False),
+    "chain3_4k": dict(text=CHAIN3, W=3840, H=2160, fmt=F32, nodes=3, seed=0x5EED0002, radius=3, strong=False,
+                      desc="BASELINE configs[1]: gaussian5 -> colour_grade -> sharpen, 3840x2160 rgba32f"),
+    "gauss9_8k": dict(text="input -> gaussian9 -> output\ngaussian9: gaussian9 { sigma: 2.0 }", W=7680, H=4320, fmt=F32, nodes=1,
+                      seed=0x5EED0003, radius=4, strong=False, desc="BASELINE configs[2]: 9x9 separable gaussian, 7680x4320 rgba32f"),
+    "chain5_16k": dict(text=CHAIN5, W=16384, H=16384, fmt=F32, nodes=5, seed=0x5EED0004, radius=7, strong=True,
+                       desc="BASELINE configs[3]: 5-stage chain, 16384x16384 rgba32f, row strips (STRONG scaling)"),
+    "conv31_8k": dict(text="input -> conv2d -> output\nconv2d: conv2d { ksize: 31, sigma: 5.0 }", W=7680, H=4320, fmt=F32, nodes=1,
+                      seed=0x5EED0005, radius=15, strong=False, desc="BASELINE configs[4]: 31x31 dense convolution, 7680x4320 rgba32f"),
+    "chain3_4k_u8": dict(text=CHAIN3, W=3840, H=2160, fmt=U8, nodes=3, seed=0x5EED0002, radius=3, strong=False,
+                         desc="the headline chain on rgba8 (4 B/px): 3840x2160"),
+    "diamond_4k": dict(text=DIAMOND, W=3840, H=2160, fmt=F32, nodes=3, seed=0x5EED0006, radius=2, strong=False,
+                       desc="fork/join graph of pipeline_graph.rs:462-468 (blur || sharpen -> combination), 3840x2160 rgba32f"),
 }
+SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "diamond_4k"]
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec)
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 MFMA peak
-BPP = 16                       # rgba32f
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 MFMA peak (= f32 vector peak)
+MALL_BYTES = 256 << 20         # MI355X_MICROARCH.md: Infinity Cache
+CONV_PATHS = (("valu", 3), ("mfma", 2), ("hybrid", 4))
 
 
-def cpu_baseline(text, W, H, seed, budget_s=12.0):
+def bpp_of(fmt):
+    return 16 if fmt == F32 else 4
+
+
+def kernel_sources_sha16():
+    """Identity of the kernel sources the committed PMC traffic figures were measured on."""
+    h = hashlib.sha256()
+    for f in ("rf_stream.hip", "rf_conv.hip", "rf_misc.hip", "rf_device.h"):
+        with open(os.path.join(ROOT, "reforge_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(key):
+    """(HBM bytes per launch from the committed rocprofv3 PMC passes, note).  profiles/traffic.json
+    records the kernel sources it was measured on; a figure from other sources is refused (null)."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(p) as fh:
+            t = json.load(fh)
+    except (OSError, ValueError):
+        return None, "no profiles/traffic.json"
+    rec = t.get("recorded", {})
+    if key not in rec:
+        return None, "no PMC profile of this workload"
+    if t.get("kernel_sources_sha16") != kernel_sources_sha16():
+        return None, "profiles/traffic.json was measured on other kernel sources (%s, now %s): re-run scripts/profile_all.sh" % (
+            t.get("kernel_sources_sha16"), kernel_sources_sha16())
+    return rec[key], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/), FETCH doubled per the gfx950 guide"
+
+
+# ---- the oracle: CHECKER and cpu_baseline only ------------------------------------------------
+def verify_bands(g, wl, strip_y0, H_total, bands):
+    """Bands of the rank's output rows against the oracle, bit for bit.  `bands` are (y0, y1) in
+    the strip's local rows; each must lie at a true frame edge or `radius` rows inside the frame."""
+    import numpy as np
+
+    from oracle import graph as ograph
+    from oracle import pixel
+    W, fmt, r = wl["W"], wl["fmt"], wl["radius"]
+    pixel.set_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    try:
+        for b0, b1 in bands:
+            gy0, gy1 = strip_y0 + b0, strip_y0 + b1
+            lo, hi = max(0, gy0 - r), min(H_total, gy1 + r)
+            src = pixel.fill_synthetic(W, hi - lo, fmt, wl["seed"], y0=lo)
+            o = ograph.GraphOracle(wl["text"], W, hi - lo, fmt)
+            o.upload_raw(src)
+            o.execute()
+            want = o.download_raw()[gy0 - lo:gy1 - lo]
+            got = g.download_rows(b0, b1)
+            if np.ascontiguousarray(got).tobytes() != np.ascontiguousarray(want).tobytes():
+                return False
+    finally:
+        pixel.set_threads(1)
+    return True
+
+
+def default_bands(rows):
+    mid = rows // 2
+    return [(0, 4), (mid - 2, mid + 2), (rows - 4, rows)]
+
+
+def cpu_baseline(wl, budget_s=12.0):
     """The oracle (oracle/rf_oracle.c, a scalar port of one-invocation-per-pixel,
     one-pass-per-node execution) on the host cores, bounded to ~budget_s seconds per leg."""
     from oracle import graph as ograph
     from oracle import pixel
+    text, W, H, seed = wl["text"], wl["W"], wl["H"], wl["seed"]
 
     def leg(threads, rows):
         pixel.set_threads(threads)
@@ -100,15 +188,94 @@ def cpu_baseline(text, W, H, seed, budget_s=12.0):
     }
 
 
-def load_traffic(key):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json),
-    null when no profile of this workload exists."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        with open(p) as fh:
-            return json.load(fh).get(key)
-    except (OSError, ValueError):
-        return None
+# ---- measurement ------------------------------------------------------------------------------
+def launch_roofline(g, wl, launches, rows, n_ev, traffic_key=None):
+    """HIP events on the launch's own stream -> (per_launch [(label, ms)], roofline of the dominant launch)."""
+    W, bpp = wl["W"], bpp_of(wl["fmt"])
+    # One launch per frame: two events around a run of back-to-back frames on the launch's stream
+    # (an event pair around EVERY launch would put a marker packet between kernels and inflate each
+    # by ~2 us).  Several launches per frame: a pair per launch, to tell them apart.
+    if len(launches) == 1:
+        per_launch = [(launches[0]["label"], g.time_frames(n_ev) / n_ev)]
+    else:
+        per_launch = g.time_launches(min(n_ev, 100))
+    dom = max(range(len(per_launch)), key=lambda i: per_launch[i][1])
+    dom_label, dom_ms = per_launch[dom]
+    traffic, note = load_traffic(traffic_key) if traffic_key else (None, "not profiled")
+    if "conv2d" in wl["text"]:
+        flops = 2.0 * 961 * 4 * W * rows
+        achieved = flops / (dom_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "algorithmic_flop_per_px": 2 * 961 * 4}
+    else:
+        # algorithmic bytes of ONE launch: (inputs + outputs) x W x rows x bpp.  A fused launch is
+        # priced as the single read + single write it performs, NOT as the sum of the nodes it
+        # covers (that figure is chain_hbm_frac).
+        n_in = len(launches[dom]["inputs"])
+        alg_bytes = (n_in + 1) * W * rows * bpp
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_px": (n_in + 1) * bpp}
+    roof["traffic_source"] = note
+    roof["kernel"] = dom_label
+    roof["launch_ms"] = round(dom_ms, 5)
+    return per_launch, roof
+
+
+def side_workload(rf, ctx, name, verify=True):
+    """One BASELINE config beside the headline (N = 1): frames timed with HIP events on the frame's
+    stream, the dominant launch priced against its roofline, the result band-checked."""
+    wl = WORKLOADS[name]
+    out = {"workload": wl["desc"]}
+    variants = CONV_PATHS if name == "conv31_8k" else (("", 0),)
+    for vname, path in variants:
+        g = rf.Graph(ctx, rf.Config(wl["text"]), wl["W"], wl["H"], wl["fmt"], conv_path=path)
+        g.fill_synthetic(wl["seed"])
+        launches = g.plan.launch_info()
+        g.execute(); g.wait()
+        t1 = max(g.time_frames(2) / 2, 1e-3)                      # ms per frame, to size the timed run
+        n = int(max(5, min(300, 250.0 / t1)))                      # ~0.25 s of frames
+        frame_ms = g.time_frames(n) / n
+        per_launch, roof = launch_roofline(g, wl, launches, g.rows, max(5, min(n, 100)), traffic_key=name if not vname else name + "_" + vname)
+        res = {"ms_per_frame": round(frame_ms, 5), "mpx_per_s": round(wl["W"] * wl["H"] / frame_ms / 1e3, 1), "frames_timed": n,
+               "launches": [l["label"] for l in launches], "launch_ms": {k: round(v, 5) for k, v in per_launch}, "roofline": roof}
+        if roof["bound"] == "hbm":
+            # all launches of a frame against the HBM time of their algorithmic bytes
+            alg = sum((len(l["inputs"]) + 1) * wl["W"] * g.rows * bpp_of(wl["fmt"]) for l in launches)
+            res["frame_hbm_frac"] = round(alg / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            res["frame_algorithmic_bytes"] = alg
+        if verify:
+            g.execute(); g.wait()
+            t0 = time.perf_counter()
+            res["verified"] = bool(verify_bands(g, wl, 0, wl["H"], default_bands(g.rows)))
+            res["verify_s"] = round(time.perf_counter() - t0, 2)
+        g.close()
+        if vname:
+            out[vname] = res
+        else:
+            out.update(res)
+    if name == "conv31_8k":
+        best = max((v for v, _ in CONV_PATHS), key=lambda v: out[v]["roofline"]["frac"])
+        out["best"] = best
+        out["roofline"] = dict(out[best]["roofline"], kernel_path=best)
+        out["verified"] = all(out[v].get("verified", True) for v, _ in CONV_PATHS)
+    return out
+
+
+def timed_steps(g, steps, fps, nslots, barrier_sync, ctx, dist, red_dev, torch):
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for i in range(fps):                           # one step = one batch of `fps` frames
+            g.execute(i % nslots)
+    ctx.synchronize()
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed
 
 
 def main():
@@ -117,16 +284,21 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="chain3_4k", choices=sorted(WORKLOADS))
-    ap.add_argument("--halo", default="overfetch", choices=["overfetch", "exchange"])
+    ap.add_argument("--halo", default="both", choices=["both", "overfetch", "exchange"],
+                    help="N > 1: which ghost-row schedule(s) to time; `value` is the exchange (RCCL) run when it ran")
     ap.add_argument("--no-fusion", action="store_true", help="one launch per node, as the reference dispatches")
     ap.add_argument("--hipgraph", action="store_true")
-    ap.add_argument("--frames-per-step", type=int, default=8,
-                    help="frames in the batch one step processes (each frame = one full pass of the graph)")
+    ap.add_argument("--frames-per-step", type=int, default=0,
+                    help="frames in the batch one step processes (each frame = one full pass of the graph); 0 = sized in the warm-up "
+                         "so that the K timed steps last ~0.6 s")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="frame slots the batch alternates over (reforge's --num-frames; each slot has its own stream and images)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-workloads", action="store_true", help="N = 1: only the headline workload")
+    ap.add_argument("--skip-strong", action="store_true", help="N > 1: skip the 16384^2 strong-scaling run")
+    ap.add_argument("--conv-path", type=int, default=0, help="conv2d kernel for --workload conv31_8k (rf_graph_options.conv_path)")
     ap.add_argument("--rehearse", action="store_true",
-                    help="N>1 plumbing check on a one-GPU box: all ranks on device 0, gloo barrier; numbers are meaningless")
+                    help="N>1 plumbing check on a one-GPU box: all ranks on device 0, gloo barrier, over-fetch only; numbers are meaningless")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,90 +331,124 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    text, W, Hper, n_nodes, seed, desc, strong = WORKLOADS[args.workload]
+    wl = WORKLOADS[args.workload]
+    text, W, Hper, fmt, n_nodes, seed, strong = wl["text"], wl["W"], wl["H"], wl["fmt"], wl["nodes"], wl["seed"], wl["strong"]
     H = Hper if (strong or world == 1) else Hper * world
+    bpp = bpp_of(fmt)
 
-    uid = None
-    if world > 1 and args.halo == "exchange":
-        t = torch.zeros(128, dtype=torch.uint8, device=red_dev)
-        if rank == 0:
-            t = torch.frombuffer(bytearray(rf.Context.unique_id()), dtype=torch.uint8).to(red_dev)
-        dist.broadcast(t, 0)
-        uid = bytes(t.cpu().numpy().tobytes())
-    ctx = rf.Context(local_rank, rank, world, uid) if world > 1 else rf.Context(local_rank)
+    # ---- contexts: one without a communicator (over-fetch), one with RCCL (exchange) ----------
+    modes = []
+    if world == 1:
+        modes = ["single"]
+    elif args.rehearse:
+        modes = ["overfetch"]
+    else:
+        modes = {"both": ["overfetch", "exchange"], "overfetch": ["overfetch"], "exchange": ["exchange"]}[args.halo]
+    comm_info = None
+    ctx_plain = rf.Context(local_rank, rank, world, None) if world > 1 else rf.Context(local_rank)
+    ctx_rccl, rccl_error = None, None
+    if "exchange" in modes:
+        try:
+            t = torch.zeros(128, dtype=torch.uint8, device=red_dev)
+            if rank == 0:
+                t = torch.frombuffer(bytearray(rf.Context.unique_id()), dtype=torch.uint8).to(red_dev)
+            dist.broadcast(t, 0)
+            uid = bytes(t.cpu().numpy().tobytes())
+            ctx_rccl = rf.Context(local_rank, rank, world, uid)
+            comm_info = {"rccl_ranks": ctx_rccl.world, "rccl_library": rf.lib().rf_comm_library().decode()}
+        except rf.RfError as e:
+            rccl_error = str(e)
+        # every rank must agree on whether the exchange leg runs
+        ok = torch.tensor([0 if rccl_error else 1], dtype=torch.int32, device=red_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            modes.remove("exchange")
+            rccl_error = rccl_error or "another rank could not create its RCCL communicator"
+            if not modes:
+                modes = ["overfetch"]
 
-    flags = 0
+    flags0 = 0
     if args.no_fusion:
-        flags |= rf.RF_GRAPH_NO_FUSION
+        flags0 |= rf.RF_GRAPH_NO_FUSION
     if args.hipgraph:
-        flags |= rf.RF_GRAPH_HIPGRAPH
-    if world > 1 and args.halo == "overfetch":
-        flags |= rf.RF_GRAPH_NO_HALO_XCHG
+        flags0 |= rf.RF_GRAPH_HIPGRAPH
     nslots = max(1, args.frames_in_flight)
-    g = rf.Graph(ctx, rf.Config(text), W, H, rf.RF_FORMAT_RGBA32F, num_frames=nslots, flags=flags)
-    g.fill_synthetic(seed)                      # inputs resident in HBM before anything is timed
-    launches = g.plan.launch_info()
 
-    for i in range(args.warmup * args.frames_per_step):
-        g.execute(i % nslots)
-    for sl in range(nslots):
-        g.wait(sl)
+    def make_graph(mode, wl_, H_):
+        ctx = ctx_rccl if mode == "exchange" else ctx_plain
+        fl = flags0 | (rf.RF_GRAPH_NO_HALO_XCHG if mode == "overfetch" else 0)
+        g = rf.Graph(ctx, rf.Config(wl_["text"]), wl_["W"], H_, wl_["fmt"], num_frames=nslots, flags=fl, conv_path=args.conv_path)
+        g.fill_synthetic(wl_["seed"])                  # inputs resident in HBM before anything is timed
+        return ctx, g
 
-    # ---- the timed region: exactly K steps ------------------------------------------------
-    barrier_sync()
-    t0 = time.perf_counter()
+    # ---- the headline: K timed steps per halo schedule -------------------------------------------
+    legs = {}
     fps = args.frames_per_step
-    for _ in range(args.steps):
-        for i in range(fps):                           # one step = one batch of `fps` frames
+    g_keep = None
+    for mode in modes:
+        ctx, g = make_graph(mode, wl, H)
+        launches = g.plan.launch_info()
+        if fps <= 0:
+            # size the batch in the warm-up: K steps of `fps` frames should last ~0.6 s
+            for i in range(8):
+                g.execute(i % nslots)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for i in range(32):
+                g.execute(i % nslots)
+            ctx.synchronize()
+            t_frame = (time.perf_counter() - t0) / 32
+            fps = int(min(4096, max(8, math.ceil(0.6 / (args.steps * t_frame)))))
+            if dist is not None:                           # every rank the same batch
+                tf = torch.tensor([fps], dtype=torch.int64, device=red_dev)
+                dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+                fps = int(tf.item())
+        for i in range(args.warmup * fps):
             g.execute(i % nslots)
-    ctx.synchronize()
-    barrier_sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        for sl in range(nslots):
+            g.wait(sl)
+        elapsed = timed_steps(g, args.steps, fps, nslots, barrier_sync, ctx, dist, red_dev, torch)
+        legs[mode] = {"elapsed": elapsed, "launches": launches, "rows": g.rows, "strip": g.strip}
+        if mode == modes[-1]:
+            g_keep = (ctx, g, mode)
+        else:
+            g.close()
 
+    head_mode = modes[-1]                                  # exchange when it ran, else over-fetch / single
+    leg = legs[head_mode]
+    elapsed = leg["elapsed"]
+    ctx, g, _ = g_keep
+    launches, rows = leg["launches"], leg["rows"]
     ms_per_step = elapsed / args.steps * 1e3
     total_px = W * H                                   # the whole job's frame
     value = total_px * fps / (elapsed / args.steps) / 1e6
 
-    # ---- roofline of the dominant kernel: HIP events on the launch's own stream -------------
-    rows = g.rows
-    # One launch per frame: two events around a run of back-to-back frames on the launch's
-    # stream (an event pair around EVERY launch would put a marker packet between kernels and
-    # inflate each by ~2 us).  Several launches per frame: a pair per launch, to tell them apart.
     n_ev = max(20, min(args.steps * fps, 400))
-    if len(launches) == 1:
-        per_launch = [(launches[0]["label"], g.time_frames(n_ev) / n_ev)]
-    else:
-        per_launch = g.time_launches(min(n_ev, 100))
-    dom = max(range(len(per_launch)), key=lambda i: per_launch[i][1])
-    dom_label, dom_ms = per_launch[dom]
-    if args.workload == "conv31_8k":
-        flops = 2.0 * 961 * 4 * W * rows
-        achieved = flops / (dom_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": load_traffic(args.workload)}
-    else:
-        # algorithmic bytes of ONE launch: (inputs + outputs) x W x rows x 16 B.  A fused launch
-        # is priced as the single read + single write it performs (32 B/px), NOT as the sum
-        # of the nodes it covers (that figure is reported as chain_hbm_frac below).
-        n_in = len(launches[dom]["inputs"])
-        alg_bytes = (n_in + 1) * W * rows * BPP
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": load_traffic(args.workload + ("_unfused" if args.no_fusion else ""))}
+    per_launch, roofline = launch_roofline(g, wl, launches, rows, n_ev,
+                                           traffic_key=args.workload + ("_unfused" if args.no_fusion else ""))
     each = sorted(g.time_each_frame(max(20, min(args.steps * fps, 200))))     # median and min per frame
     frame_events = {"median_ms": round(each[len(each) // 2], 5), "min_ms": round(each[0], 5), "frames": len(each),
                     "note": "hipEvent pair per frame on the frame's stream (adds a marker packet per frame)"}
-    roofline["kernel"] = dom_label
-    roofline["launch_ms"] = round(dom_ms, 5)
-    roofline["algorithmic_bytes_per_px"] = 32 if roofline["bound"] == "hbm" else None
+    working_set = len(g.plan.images()) * W * rows * bpp
+    roofline["mall_resident"] = bool(working_set <= MALL_BYTES)
+    roofline["working_set_bytes"] = working_set
+
+    # the headline result is checked too: bands at the strip seams / frame edges against the oracle
+    verified = None
+    if not args.skip_cpu_baseline:
+        g.execute(0)
+        g.wait(0)
+        try:
+            verified = bool(verify_bands(g, dict(wl, H=H), leg["strip"][0], H, default_bands(rows)))
+        except Exception as e:                              # the checker must never take the measurement down
+            verified = "error: %s" % e
+        if dist is not None:
+            v = torch.tensor([1 if verified is True else 0], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN)
+            verified = bool(int(v.item()))
 
     # BASELINE.md's "% HBM roofline": the per-node algorithmic bytes of the whole chain
-    chain_bytes = n_nodes * 2 * BPP * total_px
+    chain_bytes = n_nodes * 2 * bpp * total_px
     chain_frac = chain_bytes / (elapsed / args.steps / fps) / 1e9 / (HBM_PEAK_GBS * world)
 
     out = {
@@ -256,45 +462,89 @@ def main():
         "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,                           # BASELINE.md holds no published number
-        "dtype": "f32",
+        "dtype": "f32" if fmt == F32 else "u8->f32",
         "data": "synthetic",
         "config": {
-            "workload": desc,
-            "frame": "%dx%d" % (W, H), "rows_per_gpu": rows, "format": "rgba32f",
-            "frames_per_step": fps, "ms_per_frame": round(ms_per_step / fps, 5),
+            "workload": wl["desc"],
+            "frame": "%dx%d" % (W, H), "rows_per_gpu": rows, "format": "rgba32f" if fmt == F32 else "rgba8",
+            "frames_per_step": fps, "ms_per_frame": round(ms_per_step / fps, 5), "timed_region_s": round(elapsed, 4),
             "nodes": n_nodes, "launches_per_frame": len(launches), "launches": [l["label"] for l in launches],
             "fusion": not args.no_fusion, "hipgraph": bool(args.hipgraph), "frames_in_flight": nslots,
-            "parallelism": "1 GPU" if world == 1 else "row strips x%d, halo=%s" % (world, args.halo),
+            "parallelism": "1 GPU" if world == 1 else "row strips x%d, halo=%s" % (world, head_mode),
         },
         "roofline": roofline,
+        "verified": verified,
         "chain_hbm_frac": round(chain_frac, 4),
-        "chain_algorithmic_bytes_per_px": n_nodes * 2 * BPP,
+        "chain_algorithmic_bytes_per_px": n_nodes * 2 * bpp,
         "launch_ms": {k: round(v, 5) for k, v in per_launch},
         "frame_ms_events": frame_events,
     }
-    if args.workload == "conv31_8k" and world == 1:
-        # both large-K kernels, timed the same way (the default is the VALU one; RF_CONV_PATH=2 selects MFMA)
-        paths = {}
-        for name, env in (("valu", "3"), ("mfma", "2")):
-            os.environ["RF_CONV_PATH"] = env
-            g2 = rf.Graph(ctx, rf.Config(text), W, H, rf.RF_FORMAT_RGBA32F, num_frames=1, flags=flags)
-            g2.fill_synthetic(seed)
-            g2.execute(0)
-            g2.wait(0)
-            ms = g2.time_frames(5) / 5
-            paths[name] = {"ms": round(ms, 4), "useful_tflops": round(2.0 * 961 * 4 * W * rows / (ms * 1e-3) / 1e12, 2)}
-            g2.close()
-        del os.environ["RF_CONV_PATH"]
-        out["conv_kernels"] = paths
+    if world > 1:
+        out["halo"] = {m: {"value": round(total_px * fps / (legs[m]["elapsed"] / args.steps) / 1e6, 1),
+                           "ms_per_step": round(legs[m]["elapsed"] / args.steps * 1e3, 5),
+                           "communication": "none per frame (ghost rows generated with the strip)" if m == "overfetch"
+                           else "RCCL neighbour send/recv per stencil launch, overlapped with the interior rows"} for m in legs}
+        out["halo"]["value_is"] = head_mode
+        if comm_info:
+            out.update(comm_info)
+        if rccl_error:
+            out["rccl_error"] = rccl_error
+    g.close()
+
+    # ---- N > 1: BASELINE configs[3], 16384^2 as N row strips (strong scaling) ---------------------
+    if world > 1 and not args.skip_strong and args.workload == "chain3_4k":
+        wl16 = WORKLOADS["chain5_16k"]
+        if args.rehearse:
+            wl16 = dict(wl16, W=2048, H=2048)          # plumbing only: every rank shares one GPU
+        strong_out = {"workload": wl16["desc"], "frame": "%dx%d" % (wl16["W"], wl16["H"])}
+        for mode in modes:
+            c16, g16 = make_graph(mode, wl16, wl16["H"])
+            for i in range(3):
+                g16.execute(0)
+            g16.wait(0)
+            n16 = 20
+            barrier_sync()
+            t0 = time.perf_counter()
+            for i in range(n16):
+                g16.execute(0)
+            c16.synchronize()
+            barrier_sync()
+            dt = time.perf_counter() - t0
+            tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item()) / n16
+            ok = None
+            if not args.skip_cpu_baseline:
+                ok = bool(verify_bands(g16, wl16, g16.strip[0], wl16["H"], default_bands(g16.rows)))
+                v = torch.tensor([1 if ok else 0], dtype=torch.int32, device=red_dev)
+                dist.all_reduce(v, op=dist.ReduceOp.MIN)
+                ok = bool(int(v.item()))
+            strong_out[mode] = {"ms_per_frame": round(dt * 1e3, 4), "mpx_per_s": round(wl16["W"] * wl16["H"] / dt / 1e6, 1),
+                                "frame_hbm_frac": round(2 * 16 * wl16["W"] * wl16["H"] / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
+                                "rows_per_gpu": g16.rows, "frames_timed": n16, "verified": ok}
+            g16.close()
+        strong_out["note"] = "speed-up = mpx_per_s here / workloads.chain5_16k.mpx_per_s of the N = 1 run"
+        out["strong_16k"] = strong_out
+
+    # ---- N = 1: the other BASELINE configs, the copy rate of the box, the CPU baseline -------------
     if rank == 0 and world == 1:
         try:
             out["copy_gbps"] = round(ctx.copy_bandwidth(256 << 20, 20), 1)
         except rf.RfError:
             out["copy_gbps"] = None
+        out["roofline"]["copy_gbps"] = out["copy_gbps"]
+        if not args.skip_workloads and args.workload == "chain3_4k":
+            out["workloads"] = {}
+            for name in SIDE_WORKLOADS:
+                try:
+                    out["workloads"][name] = side_workload(rf, ctx, name, verify=not args.skip_cpu_baseline)
+                except rf.RfError as e:
+                    out["workloads"][name] = {"error": str(e)}
         if not args.skip_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(text, W, H, seed)
-    g.close()
-    ctx.close()
+            out["cpu_baseline"] = cpu_baseline(wl)
+    if ctx_rccl is not None:
+        ctx_rccl.close()
+    ctx_plain.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -258,6 +258,9 @@ rf_status rf_graph_wait(rf_graph* g, int frame_slot);
 /* write_output_to_buffer (render.rs:406-433): linear -> sRGB8 of the rank's strip */
 rf_status rf_graph_download_srgb8(rf_graph* g, int frame_slot, uint8_t* rgba, size_t row_stride);
 rf_status rf_graph_download_raw(rf_graph* g, int frame_slot, void* texels, size_t row_stride);
+/* rows [y0, y1) (local to the rank's strip) of the output image, raw texels: what a caller that
+ * only needs part of a very large frame copies back (a 16384^2 rgba32f frame is 4 GiB) */
+rf_status rf_graph_download_rows(rf_graph* g, int frame_slot, int y0, int y1, void* texels, size_t row_stride);
 /* raw texels of any allocated image (debug / tests), by resource name */
 rf_status rf_graph_download_image(rf_graph* g, int frame_slot, const char* resource,
                                   void* texels, size_t row_stride);

@@ -118,6 +118,7 @@ SIGNATURES = {
     "rf_graph_download_srgb8": (_i, [_vp, _i, _vp, _sz]),
     "rf_graph_download_raw": (_i, [_vp, _i, _vp, _sz]),
     "rf_graph_download_image": (_i, [_vp, _i, _cp, _vp, _sz]),
+    "rf_graph_download_rows": (_i, [_vp, _i, _i, _i, _vp, _sz]),
     "rf_graph_node_times": (_i, [_vp, _i, C.POINTER(_cp), _pf, _pi]),
     "rf_graph_times_string": (_i, [_vp, _i, _cp, _sz]),
     "rf_graph_time_frames": (_i, [_vp, _i, _pf]),

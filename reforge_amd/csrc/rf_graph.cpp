@@ -864,6 +864,21 @@ extern "C" rf_status rf_graph_download_raw(rf_graph* g, int frame_slot, void* te
     return download_image(g, *f, g->output_image, texels, row_stride);
 }
 
+extern "C" rf_status rf_graph_download_rows(rf_graph* g, int frame_slot, int y0, int y1, void* texels, size_t row_stride)
+{
+    FrameSlot* f;
+    rf_status st = slot_of(g, frame_slot, &f, "rf_graph_download_rows");
+    if (st != RF_OK) return st;
+    const size_t row_bytes = (size_t)g->opt.width * bytes_per_pixel(g->opt.format);
+    if (!texels) return fail(RF_ERR_INVALID, "rf_graph_download_rows: null buffer");
+    if (row_stride < row_bytes) return fail(RF_ERR_INVALID, "rf_graph_download_rows: row_stride smaller than a row");
+    if (y0 < 0 || y1 > strip_rows_of(g) || y0 >= y1) return fail(RF_ERR_INVALID, "rf_graph_download_rows: rows outside the strip");
+    const DeviceImage& img = f->images.at(g->output_image);
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    HIP_TRY(hipMemcpy2D(texels, row_stride, img.base + (size_t)y0 * img.pitch, img.pitch, row_bytes, (size_t)(y1 - y0), hipMemcpyDeviceToHost));
+    return RF_OK;
+}
+
 extern "C" rf_status rf_graph_download_image(rf_graph* g, int frame_slot, const char* resource, void* texels, size_t row_stride)
 {
     FrameSlot* f;

@@ -296,6 +296,12 @@ class Graph:
         _check(lib().rf_graph_download_srgb8(self._h, slot, out.ctypes.data, out.strides[0]), "rf_graph_download_srgb8")
         return out
 
+    def download_rows(self, y0, y1, slot=0):
+        """Rows [y0, y1) of the strip's output image (raw texels)."""
+        out = np.empty((y1 - y0, self.width, 4), _DTYPES[self.format])
+        _check(lib().rf_graph_download_rows(self._h, slot, y0, y1, out.ctypes.data, out.strides[0]), "rf_graph_download_rows")
+        return out
+
     def download_image(self, resource, slot=0):
         out = np.empty((self.rows, self.width, 4), _DTYPES[self.format])
         _check(lib().rf_graph_download_image(self._h, slot, resource.encode(), out.ctypes.data, out.strides[0]),

@@ -57,16 +57,23 @@ def main():
         rows = [r for r in csv.DictReader(fh) if "copy_kernel" not in r["Name"] and "fill" not in r["Name"] and "rocclr" not in r["Name"]]
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     dom = rows[0]["Name"]
+    # traffic.json = {"kernel_sources_sha16": identity of the kernel sources measured, "recorded": {workload: bytes}};
+    # figures recorded on other sources are dropped (bench.py refuses them anyway)
+    sys.path.insert(0, ROOT)
+    import bench
+    sha = bench.kernel_sources_sha16()
     tpath = os.path.join(prof, "traffic.json")
-    traffic = {}
+    traffic = {"kernel_sources_sha16": sha, "recorded": {}}
     if os.path.exists(tpath):
         with open(tpath) as fh:
-            traffic = json.load(fh)
+            old = json.load(fh)
+        if old.get("kernel_sources_sha16") == sha:
+            traffic["recorded"] = old.get("recorded", {})
     match = [k for k in out["kernels"] if k.split("(")[0] == dom.split("(")[0]]
-    traffic[key] = out["kernels"][match[0]]["bytes"] if match else None
+    traffic["recorded"][key] = out["kernels"][match[0]]["bytes"] if match else None
     with open(tpath, "w") as fh:
         json.dump(traffic, fh, indent=1, sort_keys=True)
-    print("dominant:", dom[:100], "avg ns", rows[0]["AverageNs"], "traffic", traffic[key])
+    print("dominant:", dom[:100], "avg ns", rows[0]["AverageNs"], "traffic", traffic["recorded"][key])
 
 
 if __name__ == "__main__":
