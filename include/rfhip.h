@@ -73,7 +73,8 @@ typedef struct rf_graph  rf_graph;   /* PipelineGraph + its frames  pipeline_gra
                                            reference lets a layer overlap (command.rs:194-240)      */
 #define RF_EXEC_FORCE_SPLIT       0x4u  /* interior/boundary three-part stencil launch without an
                                            exchange (how the multi-rank split is tested on one GPU) */
-#define RF_EXEC_NO_ALTERNATE      0x8u  /* every chunk walks top-down                                */
+#define RF_EXEC_NO_ALTERNATE      0x8u  /* every chunk walks top-down (default: chosen per launch)      */
+#define RF_EXEC_ALTERNATE         0x20u /* odd chunks walk bottom-up (halo rows shared through L2)      */
 #define RF_EXEC_NO_JIT            0x10u /* never compile a fused chain at graph creation: only the
                                            ahead-of-time catalogue fuses                            */
 
@@ -88,6 +89,8 @@ typedef struct rf_graph_options {
     int       conv_path;      /* conv2d kernel: 0 auto, 1 LDS tile, 2 MFMA band, 3 VALU, 4 hybrid
                                  (env RF_CONV_PATH)                                               */
     uint32_t  exec_flags;     /* RF_EXEC_* */
+    int       texels_per_lane;/* stream kernels, rgba32f: 0 auto, 1 = 64-wide strips, 2 = 128-wide
+                                 (env RF_TEXELS_PER_LANE)                                         */
 } rf_graph_options;
 
 /* ------------------------------------------------------------------------- */

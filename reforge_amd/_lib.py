@@ -34,6 +34,7 @@ RF_EXEC_CONCURRENT_LAYERS = 0x2
 RF_EXEC_FORCE_SPLIT = 0x4
 RF_EXEC_NO_ALTERNATE = 0x8
 RF_EXEC_NO_JIT = 0x10
+RF_EXEC_ALTERNATE = 0x20
 
 RF_CONV_AUTO, RF_CONV_TILE, RF_CONV_MFMA, RF_CONV_VALU, RF_CONV_HYBRID = 0, 1, 2, 3, 4
 
@@ -41,7 +42,8 @@ RF_CONV_AUTO, RF_CONV_TILE, RF_CONV_MFMA, RF_CONV_VALU, RF_CONV_HYBRID = 0, 1, 2
 class GraphOptions(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("format", C.c_int),
                 ("num_frames", C.c_int), ("flags", C.c_uint32),
-                ("rows_per_chunk", C.c_int), ("conv_path", C.c_int), ("exec_flags", C.c_uint32)]
+                ("rows_per_chunk", C.c_int), ("conv_path", C.c_int), ("exec_flags", C.c_uint32),
+                ("texels_per_lane", C.c_int)]
 
 
 _vp, _cp, _i, _sz, _u32, _f = C.c_void_p, C.c_char_p, C.c_int, C.c_size_t, C.c_uint32, C.c_float

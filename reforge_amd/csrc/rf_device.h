@@ -24,6 +24,15 @@ RF_DEV f4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 // four fmaf as two v_pk_fma_f32 (each lane-pair fma is still one single-rounding fmaf): a VALU
 // instruction costs the same issue slot packed or not, and the kernels are issue-sensitive
 typedef float v2f __attribute__((ext_vector_type(2)));
+// the weight already as a pair {w, w}: stage parameters are stored that way, so that a weight is ONE aligned 8-byte
+// scalar load (hipcc otherwise widens neighbouring float loads into overlapping vector loads, which can pin the whole
+// parameter block to scratch: it did for the grade -> gaussian chains)
+RF_DEV f4 fma4(v2f ww, f4 v, f4 a)
+{
+    const v2f lo = __builtin_elementwise_fma(ww, v2f{v.x, v.y}, v2f{a.x, a.y});
+    const v2f hi = __builtin_elementwise_fma(ww, v2f{v.z, v.w}, v2f{a.z, a.w});
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
 RF_DEV f4 fma4(float w, f4 v, f4 a)
 {
     const v2f ww = {w, w};

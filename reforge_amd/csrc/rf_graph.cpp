@@ -491,16 +491,18 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
     // tuning and executor variants: rf_graph_options first, the environment overrides when set
     g->tune.rows_per_chunk = opt.rows_per_chunk;
     g->tune.conv_path = opt.conv_path;
-    g->tune.no_alternate = (opt.exec_flags & RF_EXEC_NO_ALTERNATE) ? 1 : 0;
+    g->tune.texels_per_lane = opt.texels_per_lane;
+    g->tune.walk = (opt.exec_flags & RF_EXEC_NO_ALTERNATE) ? 2 : (opt.exec_flags & RF_EXEC_ALTERNATE) ? 1 : 0;
     g->sync_launches = (opt.exec_flags & RF_EXEC_SYNC_LAUNCHES) != 0;
     g->concurrent_layers = (opt.exec_flags & RF_EXEC_CONCURRENT_LAYERS) != 0;
     g->force_split = (opt.exec_flags & RF_EXEC_FORCE_SPLIT) != 0;
     if (const char* e = std::getenv("RF_ROWS_PER_CHUNK")) g->tune.rows_per_chunk = std::atoi(e);
     if (const char* e = std::getenv("RF_CONV_PATH")) g->tune.conv_path = std::atoi(e);
+    if (const char* e = std::getenv("RF_TEXELS_PER_LANE")) g->tune.texels_per_lane = std::atoi(e);
     if (const char* e = std::getenv("RF_SYNC_LAUNCHES")) g->sync_launches = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_CONCURRENT_LAYERS")) g->concurrent_layers = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_FORCE_SPLIT")) g->force_split = std::atoi(e) != 0;
-    if (const char* e = std::getenv("RF_NO_ALTERNATE")) g->tune.no_alternate = std::atoi(e);
+    if (const char* e = std::getenv("RF_NO_ALTERNATE")) g->tune.walk = std::atoi(e) ? 2 : 1;
     // Exchange mode shares ONE comm stream and one src_ready/halo_ready event pair per slot: two
     // stencils of a layer reading the same source would each re-exchange its ghost rows while the
     // other's boundary kernels may still read them.  Plan order on one stream keeps it ordered.

@@ -59,7 +59,8 @@ struct Geom {
 // Tuning knobs (0 = heuristic).  Read once from the environment by rf_graph.
 struct StreamTuning {
     int rows_per_chunk = 0;   // RF_ROWS_PER_CHUNK
-    int no_alternate = 0;     // RF_NO_ALTERNATE=1: every chunk walks top-down
+    int walk = 0;             // chunk walk direction: 0 auto, 1 odd chunks bottom-up (halo rows shared through L2), 2 all top-down
+    int texels_per_lane = 0;  // RF_TEXELS_PER_LANE: 0 auto, 1 or 2 (rgba32f stream kernels)
     int conv_path = 0;        // RF_CONV_PATH: 0 = register-blocked VALU kernel, 1 = 16x16 LDS tile, 2 = MFMA (K >= 9), 3 = VALU
 };
 

@@ -30,20 +30,35 @@
 namespace rf {
 
 // ---------------------------------------------------------------------------------
-// Per-lane context of a streaming wave
+// Per-lane context of a streaming wave.  A wave's strip is 64*T texels wide: lane l owns the
+// T texels at strip positions l, l + 64, ... (texel j of the lane = position l + 64 j), so every
+// global access and every LDS row access of a wave instruction is 64 consecutive texels -- one
+// fully coalesced 1 KiB segment for rgba32f -- whatever T is.  T = 2 halves the share of halo
+// lanes (2 RH of 128 instead of 2 RH of 64) and the per-row scalar work per texel.
 // ---------------------------------------------------------------------------------
-struct Lane {
+template <int T> struct Tex { f4 v[T]; };
+
+template <int T> RF_DEV Tex<T> tex_zero()
+{
+    Tex<T> z;
+#pragma unroll
+    for (int j = 0; j < T; ++j) z.v[j] = f4_zero();
+    return z;
+}
+
+template <int T> struct Lane {
     int lane;   // 0..63
-    int x;      // frame column this lane stands for (may lie outside [0,W) in the halo)
-    int x0;     // column of lane 0
+    int x0;     // frame column of strip position 0 (may be negative: left halo)
     int W;
-    f4* lds;    // wave-private LDS rows, 64 texels each
-    // LDS slot holding column clamp(x+dx) -- clamp-to-edge at the frame border, and
+    f4* lds;    // wave-private LDS rows, 64*T texels each
+    RF_DEV int pos(int j) const { return lane + 64 * j; }          // strip position of the lane's texel j
+    RF_DEV int col(int j) const { return x0 + lane + 64 * j; }     // its frame column (may lie outside [0,W) in the halo)
+    // LDS slot holding column clamp(col(j)+dx) -- clamp-to-edge at the frame border, and
     // kept inside the wave's row for the halo lanes (whose results are discarded)
-    RF_DEV int nbr(int dx) const
+    RF_DEV int nbr(int j, int dx) const
     {
-        int c = min(max(x + dx, 0), W - 1) - x0;
-        return min(max(c, 0), 63);
+        int c = min(max(col(j) + dx, 0), W - 1) - x0;
+        return min(max(c, 0), 64 * T - 1);
     }
 };
 
@@ -64,25 +79,25 @@ RF_DEV void wave_sync()
 // (s_waitcnt vmcnt(0)) at each use, because loads and stores share vmcnt on gfx9 and its
 // wait-count pass treats mixed pending events as out of order.  The DMA is issued from an
 // asm statement (invisible to that pass) and waited for with a COUNTED vmcnt: vector
-// memory operations retire in issue order, and a wave issues exactly one DMA per input
-// row and one store per output row, in a fixed program order (see wait_row).
+// memory operations retire in issue order, and a wave issues exactly T DMAs per input
+// row and T stores per output row, in a fixed program order (see wait_row).
 // ---------------------------------------------------------------------------------
 template <int N> RF_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-struct Sink {
+template <int T> struct Sink {
     char* dst;          // address of local row 0
     ptrdiff_t pitch;    // negative when the wave walks bottom-up
-    unsigned xoff;      // lane's byte offset in a row
-    bool lane_ok;       // lane owns an output texel
+    unsigned xoff[T];   // byte offset of the lane's texel j in a row
+    bool lane_ok[T];    // the lane owns an output texel at j
     int row;            // next output row
     int first_store;    // iteration of the first store, -1 before it (wave-uniform)
 };
 
-template <class Px, int PF> struct Source {
+template <class Px, int PF, int T> struct Source {
     static_assert(PF >= 2, "the ring needs at least two slots");
     static constexpr int SLOTS = PF;
-    static constexpr int SLOT_BYTES = 64 * Px::BPP;
-    const char* src;      // address of local row 0, already offset by the lane's column
+    static constexpr int SLOT_BYTES = 64 * T * Px::BPP;
+    const char* src[T];   // address of local row 0, already offset by the column of the lane's texel j
     ptrdiff_t pitch;
     int a0, n0;           // first source row, number of source rows
     unsigned lds_base;    // LDS byte address of slot 0 (wave-uniform)
@@ -103,28 +118,33 @@ template <class Px, int PF> struct Source {
     // the taps of the row have normally been consumed and the wait is free.
     RF_DEV void issue(int r) const
     {
-        const char* g = src + (ptrdiff_t)(a0 + r) * pitch;
-        const unsigned dst = lds_base + (unsigned)(r % SLOTS) * (unsigned)SLOT_BYTES;
-        unsigned keep;
-        if constexpr (Px::BPP == 16)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
-        else
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+        const unsigned dst0 = lds_base + (unsigned)(r % SLOTS) * (unsigned)SLOT_BYTES;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const char* g = src[j] + (ptrdiff_t)(a0 + r) * pitch;
+            const unsigned dst = dst0 + (unsigned)(j * 64 * Px::BPP);
+            unsigned keep;
+            if constexpr (Px::BPP == 16)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+        }
     }
     RF_DEV void prologue() const
     {
         for (int r = 0; r < PF && r < n0; ++r) issue(r);
     }
     // Wait until row r has landed, leaving younger operations in flight.  Younger than
-    // row r's DMA at this point: the DMAs of rows r+1 .. r+PF-1 (when they exist) and, once
-    // the pipeline emits a row per iteration, the stores of the PF-1 iterations in between.
-    RF_DEV void wait_row(int r, const Sink& k) const
+    // row r's DMAs at this point: the DMAs of rows r+1 .. r+PF-1 (when they exist) and, once
+    // the pipeline emits a row per iteration, the stores of the PF-1 iterations in between
+    // (T of each per row).
+    RF_DEV void wait_row(int r, const Sink<T>& k) const
     {
         if (n0 - 1 - r >= PF - 1) {
-            if (k.first_store >= 0 && k.first_store <= r - PF) wait_vmcnt<2 * PF - 2>();
-            else wait_vmcnt<PF - 1>();
+            if (k.first_store >= 0 && k.first_store <= r - PF) wait_vmcnt<(2 * PF - 2) * T>();
+            else wait_vmcnt<(PF - 1) * T>();
         } else {
             wait_vmcnt<0>();
         }
@@ -133,28 +153,44 @@ template <class Px, int PF> struct Source {
 
 // what the first stage is handed each iteration, fetched from the ring one iteration
 // ahead so the LDS latency hides behind the previous row's arithmetic
-template <class Px> struct OwnFeed {      // the lane's own texel
-    typename Px::Raw nxt;
-    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane& L)
+template <class Px, int T> struct OwnFeed {      // the lane's own texels
+    typename Px::Raw nxt[T];
+    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane<T>& L)
     {
-        nxt = *reinterpret_cast<const typename Px::Raw*>(s.slot(r) + (size_t)L.lane * Px::BPP);
+#pragma unroll
+        for (int j = 0; j < T; ++j) nxt[j] = *reinterpret_cast<const typename Px::Raw*>(s.slot(r) + (size_t)L.pos(j) * Px::BPP);
     }
-    RF_DEV f4 own() const { return Px::decode(nxt); }
+    RF_DEV Tex<T> own() const
+    {
+        Tex<T> o;
+#pragma unroll
+        for (int j = 0; j < T; ++j) o.v[j] = Px::decode(nxt[j]);
+        return o;
+    }
 };
-template <int R> struct TapFeed {         // rgba32f: the 2R+1 horizontal taps, straight from the DMA ring
-    f4 t[2 * R + 1];
-    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane& L)
+template <int R, int T> struct TapFeed {         // rgba32f: the 2R+1 horizontal taps, straight from the DMA ring
+    f4 t[T][2 * R + 1];
+    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane<T>& L)
     {
         const f4* row = reinterpret_cast<const f4*>(s.slot(r));
 #pragma unroll
-        for (int i = -R; i <= R; ++i) t[i + R] = row[L.nbr(i)];
+        for (int j = 0; j < T; ++j) {
+#pragma unroll
+            for (int i = -R; i <= R; ++i) t[j][i + R] = row[L.nbr(j, i)];
+        }
     }
-    RF_DEV f4 own() const { return t[R]; }
+    RF_DEV Tex<T> own() const
+    {
+        Tex<T> o;
+#pragma unroll
+        for (int j = 0; j < T; ++j) o.v[j] = t[j][R];
+        return o;
+    }
 };
 
 // ---------------------------------------------------------------------------------
 // Row stages.  advance() is called once per row entering the stage:
-//   v      the row's texel for this lane (undefined when !real)
+//   v      the row's texels for this lane (undefined when !real)
 //   real   a new input row; false = the newest row repeated (clamp-to-edge below the frame)
 //   first  the stage's first row: it primes the whole window (clamp-to-edge above the frame,
 //          or rows that are shifted out again before anything is emitted)
@@ -165,58 +201,128 @@ struct NoState {};
 // horizontal taps of the separable gaussian: sum_i w[|i|] * in[x+i], ascending i
 template <int R> struct StHTap {
     static constexpr int RV = 0, RH = R, LDS_ROWS = (R > 0) ? 1 : 0;
-    struct Params { float w[R + 1]; };
-    template <class Px> using State = NoState;
+    struct Params { v2f w[R + 1]; };   // each weight twice: the operand pair of a packed fma (see fma4)
+    template <class Px, int T> using State = NoState;
     // as the FIRST stage of an rgba32f pipeline the taps come straight from the DMA ring
     // (up to radius 7: beyond that 2R+1 prefetched taps crowd the vertical window out of the register
     // file -- radius 10 at 4K: 209 us with the prefetch, 119 us through the LDS exchange)
-    template <class Px> using Feed = typename std::conditional<(Px::QUANT || R > 7), OwnFeed<Px>, TapFeed<R>>::type;
-    RF_DEV static f4 from_taps(const Params& p, const TapFeed<R>& f)
+    template <class Px, int T> using Feed = typename std::conditional<(Px::QUANT || R > 7 || T > 1), OwnFeed<Px, T>, TapFeed<R, T>>::type;
+    template <int T> RF_DEV static Tex<T> from_taps(const Params& p, const TapFeed<R, T>& f)
     {
-        f4 acc = f4_zero();
+        Tex<T> o;
 #pragma unroll
-        for (int i = -R; i <= R; ++i) acc = fma4(p.w[i < 0 ? -i : i], f.t[i + R], acc);
-        return acc;
+        for (int j = 0; j < T; ++j) {
+            f4 acc = f4_zero();
+#pragma unroll
+            for (int i = -R; i <= R; ++i) acc = fma4(p.w[i < 0 ? -i : i], f.t[j][i + R], acc);
+            o.v[j] = acc;
+        }
+        return o;
     }
-    template <class Px, bool REV> RF_DEV static void advance(const Params& p, NoState&, const Lane& L, f4* lds, f4 v, bool, bool, bool, f4& out)
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, NoState&, const Lane<T>& L, f4* lds, const Tex<T>& v, bool, bool, bool, Tex<T>& out)
     {
         if constexpr (R > 0) {
-            lds[L.lane] = v;
+#pragma unroll
+            for (int j = 0; j < T; ++j) lds[L.pos(j)] = v.v[j];
             wave_sync();
         }
-        f4 acc = f4_zero();
 #pragma unroll
-        for (int i = -R; i <= R; ++i) {
-            f4 t = (i == 0) ? v : lds[L.nbr(i)];
-            acc = fma4(p.w[i < 0 ? -i : i], t, acc);
+        for (int j = 0; j < T; ++j) {
+            f4 acc = f4_zero();
+#pragma unroll
+            for (int i = -R; i <= R; ++i) {
+                f4 t = (i == 0) ? v.v[j] : lds[L.nbr(j, i)];
+                acc = fma4(p.w[i < 0 ? -i : i], t, acc);
+            }
+            out.v[j] = acc;
         }
-        out = acc;
     }
 };
 
-// vertical taps: sum_j w[|j|] * tmp[y+j], ascending j; the window lives in VGPRs
+// vertical taps: sum_j w[|j|] * tmp[y+j], ascending j.
+//
+// Walking top-down the rows arrive in ascending order, which IS the tap order of every output row:
+// the stage then keeps one running sum per pending output row instead of a window of input rows
+// (SCATTER form).  Row r contributes  acc[y] = fma(w|r-y|, tmp[r], acc[y])  to the 2R+1 outputs it
+// reaches; the oldest of them, y = r - R, takes its last tap and is emitted.  Each output still
+// sums its taps in ascending j from 0 -- bit-identical to the window form -- but the slide of the
+// pending rows is done by the fma itself (destination = the slot one up from its addend), where a
+// window of rows has to be shifted with moves: 2 x 2R v_mov_b64 per row and texel.
+// Walking bottom-up (REV) the rows arrive in DESCENDING order, so the sums cannot be formed on
+// arrival; those walks keep the window of rows (GATHER form).
 template <int R> struct StVTap {
     static constexpr int RV = R, RH = 0, LDS_ROWS = 0;
-    struct Params { float w[R + 1]; };
-    template <class Px> struct State { f4 win[2 * R + 1]; };
-    template <class Px> using Feed = OwnFeed<Px>;
-    template <class Px, bool REV> RF_DEV static void advance(const Params& p, State<Px>& s, const Lane&, f4*, f4 v, bool real, bool first, bool emit, f4& out)
+    struct Params { v2f w[R + 1]; };
+    // scatter: acc[k] = running sum of output row (newest - R + 1 + k), k = 0 .. 2R-1; last = newest real row (bottom-edge flush)
+    // gather:  win[i] = input row (newest - 2R + i)
+    template <class Px, int T> struct State { Tex<T> win[2 * R + 1]; };
+    template <class Px, int T> using Feed = OwnFeed<Px, T>;
+
+    // running sums 0 .. 2R-2 slide down by one while taking their tap (compile-time recursion: every weight
+    // index is a constant for the front end already, so the parameter block stays in scalar registers)
+    template <int K, int T> RF_DEV static void slide(const Params& p, Tex<T>* acc, const f4& v, int t)
     {
-        if (first) {                     // the first row primes the whole window (it is always a real row)
-#pragma unroll
-            for (int i = 0; i <= 2 * R; ++i) s.win[i] = v;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2 * R; ++i) s.win[i] = s.win[i + 1];
-            if (real) s.win[2 * R] = v;
+        if constexpr (K + 1 < 2 * R) {
+            constexpr int j = R - 1 - K;                                       // row newest-R+1+K takes tap j
+            acc[K].v[t] = fma4(p.w[j < 0 ? -j : j], v, acc[K + 1].v[t]);
+            slide<K + 1, T>(p, acc, v, t);
         }
-        if (emit) {
-            f4 acc = f4_zero();
+    }
+    template <int T> RF_DEV static void scatter_row(const Params& p, Tex<T>* acc, const Tex<T>& v, Tex<T>& out)
+    {
 #pragma unroll
-            // taps are accumulated in ascending FRAME row order; walking bottom-up the window
-            // holds the rows the other way round
-            for (int j = -R; j <= R; ++j) acc = fma4(p.w[j < 0 ? -j : j], s.win[REV ? R - j : j + R], acc);
-            out = acc;
+        for (int t = 0; t < T; ++t) {
+            out.v[t] = fma4(p.w[R], v.v[t], acc[0].v[t]);                       // j = +R: the last tap of row newest-R
+            slide<0, T>(p, acc, v.v[t], t);
+            acc[2 * R - 1].v[t] = fma4(p.w[R], v.v[t], f4_zero());              // j = -R: the first tap of row newest+R
+        }
+    }
+    // KEEP: the row may be the stage's last real one (tail and generic loop phases): remember it for the flush
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, State<Px, T>& s, const Lane<T>&, f4*, const Tex<T>& v, bool real, bool first, bool emit, Tex<T>& out)
+    {
+        if constexpr (R == 0) {
+            out = tex_zero<T>();
+#pragma unroll
+            for (int t = 0; t < T; ++t) out.v[t] = fma4(p.w[0], v.v[t], f4_zero());
+        } else if constexpr (!REV) {
+            // s.win[0 .. 2R-1] are the running sums, s.win[2R] the newest real row
+            if (first) {
+                // clamp-to-edge above the stage's first row: as if 2R more copies of it had arrived before
+#pragma unroll
+                for (int k = 0; k < 2 * R; ++k) s.win[k] = tex_zero<T>();
+                Tex<T> dummy;
+#pragma unroll
+                for (int n = 0; n < 2 * R; ++n) scatter_row<T>(p, s.win, v, dummy);
+            }
+            Tex<T> in;                        // by value: a reference picked between two objects would pin both to memory
+#pragma unroll
+            for (int t = 0; t < T; ++t) in.v[t] = real ? v.v[t] : s.win[2 * R].v[t];
+            Tex<T> o;
+            scatter_row<T>(p, s.win, in, o);
+            if (emit) out = o;
+            if constexpr (KEEP) {
+                if (real) s.win[2 * R] = v;
+            }
+        } else {
+            if (first) {                     // the first row primes the whole window (it is always a real row)
+#pragma unroll
+                for (int i = 0; i <= 2 * R; ++i) s.win[i] = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2 * R; ++i) s.win[i] = s.win[i + 1];
+                if (real) s.win[2 * R] = v;
+            }
+            if (emit) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    f4 acc = f4_zero();
+#pragma unroll
+                    // taps are accumulated in ascending FRAME row order; walking bottom-up the window
+                    // holds the rows the other way round
+                    for (int j = -R; j <= R; ++j) acc = fma4(p.w[j < 0 ? -j : j], s.win[R - j].v[t], acc);
+                    out.v[t] = acc;
+                }
+            }
         }
     }
 };
@@ -225,17 +331,22 @@ template <int R> struct StVTap {
 struct StGrade {
     static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
     struct Params { float slope, offset, saturation; };
-    template <class Px> using State = NoState;
-    template <class Px> using Feed = OwnFeed<Px>;
+    template <class Px, int T> using State = NoState;
+    template <class Px, int T> using Feed = OwnFeed<Px, T>;
     RF_DEV static float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
-    template <class Px, bool REV> RF_DEV static void advance(const Params& p, NoState&, const Lane&, f4*, f4 c, bool, bool, bool, f4& out)
+    RF_DEV static f4 grade(const Params& p, f4 c)
     {
         float tr = fmaf(c.x, p.slope, p.offset);
         float tg = fmaf(c.y, p.slope, p.offset);
         float tb = fmaf(c.z, p.slope, p.offset);
         float luma = fmaf(0.0722f, tb, fmaf(0.7152f, tg, 0.2126f * tr));
-        out = make_float4(clamp01(fmaf(p.saturation, tr - luma, luma)), clamp01(fmaf(p.saturation, tg - luma, luma)),
-                          clamp01(fmaf(p.saturation, tb - luma, luma)), c.w);
+        return make_float4(clamp01(fmaf(p.saturation, tr - luma, luma)), clamp01(fmaf(p.saturation, tg - luma, luma)),
+                           clamp01(fmaf(p.saturation, tb - luma, luma)), c.w);
+    }
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, NoState&, const Lane<T>&, f4*, const Tex<T>& c, bool, bool, bool, Tex<T>& out)
+    {
+#pragma unroll
+        for (int j = 0; j < T; ++j) out.v[j] = grade(p, c.v[j]);
     }
 };
 
@@ -246,16 +357,20 @@ struct StGrade {
 struct StCross3 {
     static constexpr int RV = 1, RH = 1, LDS_ROWS = 1;
     struct Params { float wc, ws; };
-    template <class Px> struct State { f4 n, c, cw, ce; };   // rows y-1, y and y's left/right neighbours
-    template <class Px> using Feed = OwnFeed<Px>;
-    RF_DEV static void exchange(const Lane& L, f4* lds, f4 v, f4& w, f4& e)
+    template <class Px, int T> struct State { Tex<T> n, c, cw, ce; };   // rows y-1, y and y's left/right neighbours
+    template <class Px, int T> using Feed = OwnFeed<Px, T>;
+    template <int T> RF_DEV static void exchange(const Lane<T>& L, f4* lds, const Tex<T>& v, Tex<T>& w, Tex<T>& e)
     {
-        lds[L.lane] = v;
+#pragma unroll
+        for (int j = 0; j < T; ++j) lds[L.pos(j)] = v.v[j];
         wave_sync();
-        w = lds[L.nbr(-1)];
-        e = lds[L.nbr(+1)];
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            w.v[j] = lds[L.nbr(j, -1)];
+            e.v[j] = lds[L.nbr(j, +1)];
+        }
     }
-    template <class Px, bool REV> RF_DEV static void advance(const Params& p, State<Px>& s, const Lane& L, f4* lds, f4 v, bool real, bool first, bool emit, f4& out)
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, State<Px, T>& s, const Lane<T>& L, f4* lds, const Tex<T>& v, bool real, bool first, bool emit, Tex<T>& out)
     {
         if (first) {                     // window = [v, v, (next row)]
             s.n = v;
@@ -263,16 +378,19 @@ struct StCross3 {
             exchange(L, lds, v, s.cw, s.ce);
             return;
         }
-        const f4 below = real ? v : s.c;
+        const Tex<T> below = real ? v : s.c;
         if (emit) {
-            f4 acc = f4_zero();
-            // frame order N, W, C, E, S: walking bottom-up the older row is the one BELOW
-            acc = fma4(p.ws, REV ? below : s.n, acc);
-            acc = fma4(p.ws, s.cw, acc);
-            acc = fma4(p.wc, s.c, acc);
-            acc = fma4(p.ws, s.ce, acc);
-            acc = fma4(p.ws, REV ? s.n : below, acc);
-            out = acc;
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                f4 acc = f4_zero();
+                // frame order N, W, C, E, S: walking bottom-up the older row is the one BELOW
+                acc = fma4(p.ws, REV ? below.v[j] : s.n.v[j], acc);
+                acc = fma4(p.ws, s.cw.v[j], acc);
+                acc = fma4(p.wc, s.c.v[j], acc);
+                acc = fma4(p.ws, s.ce.v[j], acc);
+                acc = fma4(p.ws, REV ? s.n.v[j] : below.v[j], acc);
+                out.v[j] = acc;
+            }
         }
         s.n = s.c;
         if (real) {
@@ -287,11 +405,12 @@ struct StCross3 {
 struct StNodeEnd {
     static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
     struct Params {};
-    template <class Px> using State = NoState;
-    template <class Px> using Feed = OwnFeed<Px>;
-    template <class Px, bool REV> RF_DEV static void advance(const Params&, NoState&, const Lane&, f4*, f4 v, bool, bool, bool, f4& out)
+    template <class Px, int T> using State = NoState;
+    template <class Px, int T> using Feed = OwnFeed<Px, T>;
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params&, NoState&, const Lane<T>&, f4*, const Tex<T>& v, bool, bool, bool, Tex<T>& out)
     {
-        out = Px::requant(v);
+#pragma unroll
+        for (int j = 0; j < T; ++j) out.v[j] = Px::requant(v.v[j]);
     }
 };
 
@@ -315,32 +434,41 @@ template <class S, class...> struct FirstOf { typedef S type; };
 
 // REV: the wave walks its chunk bottom-up (rows are addressed with a negated pitch, so the
 // schedule below is unchanged); stages whose tap order depends on the row direction read it.
-template <class Px, bool REV, int LdsIdx, class... S> struct Chain;
+template <class Px, bool REV, int T, int LdsIdx, class... S> struct Chain;
 
 // end of the chain: the store
-template <class Px, bool REV, int LdsIdx> struct Chain<Px, REV, LdsIdx> {
+template <class Px, bool REV, int T, int LdsIdx> struct Chain<Px, REV, T, LdsIdx> {
     RF_DEV void plan_backward(int oa, int ob, int, int, int& in_a, int& in_b) { in_a = oa; in_b = ob; }
     RF_DEV int plan_forward(int tprev) { return tprev; }
-    template <bool STEADY> RF_DEV void step(bool has, f4 v, int it, const Lane&, Sink& k, const ParamPack<>&)
+    template <int MODE> RF_DEV void step(bool has, const Tex<T>& v, int it, const Lane<T>&, Sink<T>& k, const ParamPack<>&)
     {
+        constexpr bool STEADY = MODE != 0;
         if (STEADY || has) {
-            // exactly ONE vector-memory instruction per emitted row: Source::wait_row counts on it
-            if (k.lane_ok) Px::store(k.dst + (ptrdiff_t)k.row * k.pitch, k.xoff, v);
+            // the row's values are computed HERE, under the full exec mask: left to itself hipcc sinks the
+            // last stage's arithmetic into the exec-masked store block and schedules it there as one
+            // serial chain per half texel with an s_nop between dependent packed fmas
+#pragma unroll
+            for (int j = 0; j < T; ++j) asm volatile("" ::"v"(v.v[j].x), "v"(v.v[j].y), "v"(v.v[j].z), "v"(v.v[j].w));
+            // exactly T vector-memory instructions per emitted row: Source::wait_row counts on it
+            // (every one of them has at least one active lane: see the strip placement in stream_kernel)
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+                if (k.lane_ok[j]) Px::store(k.dst + (ptrdiff_t)k.row * k.pitch, k.xoff[j], v.v[j]);
             k.row += 1;
             if (!STEADY && k.first_store < 0) k.first_store = it;
         }
     }
 };
 
-template <class Px, bool REV, int LdsIdx, class S, class... Rest> struct Chain<Px, REV, LdsIdx, S, Rest...> {
-    typename S::template State<Px> st;
+template <class Px, bool REV, int T, int LdsIdx, class S, class... Rest> struct Chain<Px, REV, T, LdsIdx, S, Rest...> {
+    typename S::template State<Px, T> st;
     // wave-uniform schedule
     int a;        // first input row
     int oa;       // first output row
     int flush;    // replications of the last input row (frame bottom edge)
     int tprev;    // iteration of the upstream stage's last emission
     int cnt;      // input rows consumed
-    Chain<Px, REV, LdsIdx + S::LDS_ROWS, Rest...> next;
+    Chain<Px, REV, T, LdsIdx + S::LDS_ROWS, Rest...> next;
 
     // given the rows the LAST stage must emit, derive what each stage must emit/consume
     RF_DEV void plan_backward(int oa_last, int ob_last, int lo, int hi, int& in_a, int& in_b)
@@ -360,19 +488,22 @@ template <class Px, bool REV, int LdsIdx, class S, class... Rest> struct Chain<P
         tprev = tp;
         return next.plan_forward(tp + flush);
     }
+    RF_DEV f4* lds_of(const Lane<T>& L) const { return L.lds + LdsIdx * 64 * T; }
     // A row (or a flush tick) enters this stage.  STEADY = every stage receives a real row,
     // is past its first row and emits: the schedule tests fold away at compile time.
-    template <bool STEADY> RF_DEV void step(bool has_prev, f4 v, int it, const Lane& L, Sink& k, const ParamPack<S, Rest...>& P)
+    template <int MODE> RF_DEV void step(bool has_prev, const Tex<T>& v, int it, const Lane<T>& L, Sink<T>& k, const ParamPack<S, Rest...>& P)
     {
+        constexpr bool STEADY = MODE != 0;
+        constexpr bool KEEP = MODE == 0 || MODE == 3;   // phases that may hold a stage's last real row
         bool has = false;
-        f4 out = f4_zero();
+        Tex<T> out = tex_zero<T>();
         if constexpr (STEADY) {
-            S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, v, true, false, true, out);
+            S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), v, true, false, true, out);
             cnt += 1;
             has = true;
         } else if constexpr (S::RV == 0) {
             if (has_prev) {              // row-local stage: one row in, one row out, never flushed
-                S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, v, true, cnt == 0, true, out);
+                S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), v, true, cnt == 0, true, out);
                 cnt += 1;
                 has = true;
             }
@@ -380,11 +511,11 @@ template <class Px, bool REV, int LdsIdx, class S, class... Rest> struct Chain<P
             const bool flushing = !has_prev && it > tprev && it <= tprev + flush;
             if (has_prev || flushing) {
                 has = (a + cnt - S::RV) >= oa;
-                S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, v, has_prev, cnt == 0, has, out);
+                S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), v, has_prev, cnt == 0, has, out);
                 cnt += 1;
             }
         }
-        next.template step<STEADY>(has, out, it, L, k, P.rest);
+        next.template step<MODE>(has, out, it, L, k, P.rest);
     }
     // first stage: the row comes from the source feed; once it is consumed its ring slot is
     // refilled and the NEXT row's values are fetched into registers
@@ -393,16 +524,17 @@ template <class Px, bool REV, int LdsIdx, class S, class... Rest> struct Chain<P
     // there yet (wait on the loads alone); 2 = the steady state; 3 = every row issued already
     // (the last PF source rows): nothing to issue, plain wait.
     template <int MODE, class Feed, class Src>
-    RF_DEV void step_first(bool has0, Feed& feed, const Src& src, int it, const Lane& L, Sink& k, const ParamPack<S, Rest...>& P)
+    RF_DEV void step_first(bool has0, Feed& feed, const Src& src, int it, const Lane<T>& L, Sink<T>& k, const ParamPack<S, Rest...>& P)
     {
         constexpr bool STEADY = MODE != 0;
+        constexpr bool KEEP = MODE == 0 || MODE == 3;
         bool has = false;
-        f4 out = f4_zero();
+        Tex<T> out = tex_zero<T>();
         if constexpr (STEADY) {
-            if constexpr (std::is_same<Feed, OwnFeed<Px>>::value)
-                S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), true, false, true, out);
+            if constexpr (std::is_same<Feed, OwnFeed<Px, T>>::value)
+                S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), feed.own(), true, false, true, out);
             else
-                out = S::from_taps(P.p, feed);
+                out = S::template from_taps<T>(P.p, feed);
             cnt += 1;
             has = true;
             if constexpr (MODE == 3) {
@@ -412,17 +544,17 @@ template <class Px, bool REV, int LdsIdx, class S, class... Rest> struct Chain<P
                 }
             } else {
                 src.issue(it + Src::SLOTS);
-                if constexpr (MODE == 1) wait_vmcnt<Src::SLOTS - 1>();
-                else wait_vmcnt<2 * Src::SLOTS - 2>();
+                if constexpr (MODE == 1) wait_vmcnt<(Src::SLOTS - 1) * T>();
+                else wait_vmcnt<(2 * Src::SLOTS - 2) * T>();
                 feed.fetch(src, it + 1, L);
             }
         } else {
             if constexpr (S::RV == 0) {
                 if (has0) {
-                    if constexpr (std::is_same<Feed, OwnFeed<Px>>::value)
-                        S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), true, cnt == 0, true, out);
+                    if constexpr (std::is_same<Feed, OwnFeed<Px, T>>::value)
+                        S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), feed.own(), true, cnt == 0, true, out);
                     else
-                        out = S::from_taps(P.p, feed);
+                        out = S::template from_taps<T>(P.p, feed);
                     cnt += 1;
                     has = true;
                 }
@@ -430,7 +562,7 @@ template <class Px, bool REV, int LdsIdx, class S, class... Rest> struct Chain<P
                 const bool flushing = !has0 && it > tprev && it <= tprev + flush;
                 if (has0 || flushing) {
                     has = (a + cnt - S::RV) >= oa;
-                    S::template advance<Px, REV>(P.p, st, L, L.lds + LdsIdx * 64, feed.own(), has0, cnt == 0, has, out);
+                    S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), feed.own(), has0, cnt == 0, has, out);
                     cnt += 1;
                 }
             }
@@ -442,7 +574,7 @@ template <class Px, bool REV, int LdsIdx, class S, class... Rest> struct Chain<P
                 }
             }
         }
-        next.template step<STEADY>(has, out, it, L, k, P.rest);
+        next.template step<MODE>(has, out, it, L, k, P.rest);
     }
 };
 
@@ -464,27 +596,30 @@ constexpr int kWavesPerBlock = RF_WAVES_PER_BLOCK;
 
 // One wave's walk over rows [y0, y1) of its strip.  REV = bottom-up: rows are addressed with
 // negated pitches and mirrored bounds, so the schedule code sees an ordinary top-down walk.
-template <class Px, int PF, bool REV, class... S>
-RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane& L, int wave, char* ring_wave, unsigned ring_lds, int y0, int y1)
+template <class Px, int PF, int T, bool REV, class... S>
+RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane<T>& L, int wave, char* ring_wave, unsigned ring_lds, int y0, int y1)
 {
     constexpr int RH = SumRH<S...>::value;
-    typedef Source<Px, PF> Src;
-    typedef typename FirstOf<S...>::type::template Feed<Px> Feed;
+    typedef Source<Px, PF, T> Src;
+    typedef typename FirstOf<S...>::type::template Feed<Px, T> Feed;
     (void)wave;
 
     // the walk's own row coordinate v: v = y top-down, v = -y bottom-up
     const int v0 = REV ? -(y1 - 1) : y0, v1 = REV ? -y0 + 1 : y1;
     const int lo = REV ? -A.row_hi : A.row_lo, hi = REV ? -A.row_lo : A.row_hi;
 
-    Sink k;
+    Sink<T> k;
     k.dst = A.dst;
     k.pitch = REV ? -(ptrdiff_t)A.dst_pitch : (ptrdiff_t)A.dst_pitch;
-    k.xoff = (unsigned)min(max(L.x, 0), A.W - 1) * (unsigned)Px::BPP;
-    k.lane_ok = (L.lane >= RH) && (L.lane < 64 - RH) && (L.x < A.W);
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        k.xoff[j] = (unsigned)min(max(L.col(j), 0), A.W - 1) * (unsigned)Px::BPP;
+        k.lane_ok[j] = (L.pos(j) >= RH) && (L.pos(j) < 64 * T - RH) && (L.col(j) < A.W);
+    }
     k.row = v0;
     k.first_store = -1;
 
-    Chain<Px, REV, 0, S...> chain;
+    Chain<Px, REV, T, 0, S...> chain;
     Src src;
     int b0;
     chain.plan_backward(v0, v1 - 1, lo, hi, src.a0, b0);
@@ -492,7 +627,8 @@ RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane& L, int wave, char
     const int total = chain.plan_forward(src.n0 - 1) + 1;
 
     // source: rows a0..b0, column clamp(x)
-    src.src = A.src + k.xoff;
+#pragma unroll
+    for (int j = 0; j < T; ++j) src.src[j] = A.src + k.xoff[j];
     src.pitch = REV ? -(ptrdiff_t)A.src_pitch : (ptrdiff_t)A.src_pitch;
     src.ring = ring_wave;
     src.lds_base = ring_lds;
@@ -521,14 +657,14 @@ RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane& L, int wave, char
     for (; it < total; ++it) chain.template step_first<0>(it < src.n0, feed, src, it, L, k, A.params);
 }
 
-template <class Px, int PF, class... S>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void stream_kernel(const StreamArgs<S...> A)
+template <class Px, int PF, int T, class... S>
+__global__ __launch_bounds__(64 * kWavesPerBlock, T > 1 ? 2 : 1) void stream_kernel(const StreamArgs<S...> A)
 {
     constexpr int RH = SumRH<S...>::value;
-    constexpr int VALID = 64 - 2 * RH;
+    constexpr int VALID = 64 * T - 2 * RH;
     constexpr int LDSR = SumLDS<S...>::value;
-    typedef Source<Px, PF> Src;
-    __shared__ f4 smem[kWavesPerBlock][(LDSR > 0 ? LDSR : 1) * 64];
+    typedef Source<Px, PF, T> Src;
+    __shared__ f4 smem[kWavesPerBlock][(LDSR > 0 ? LDSR : 1) * 64 * T];
     __shared__ __attribute__((aligned(16))) char ring[kWavesPerBlock][Src::SLOTS * Src::SLOT_BYTES];
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -547,10 +683,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void stream_kernel(const Strea
     const int y1 = min(y0 + A.rows_per_chunk, A.y1);
     if (y0 >= y1) return;
 
-    Lane L;
+    Lane<T> L;
     L.lane = (int)(threadIdx.x & 63);
     L.x0 = strip * VALID - RH;
-    L.x = L.x0 + L.lane;
+    // T > 1: every one of the T stores of a row must have an active lane (the counted vmcnt waits
+    // assume T stores are really issued; hipcc branches around a store whose exec mask is empty).
+    // The last strip is therefore moved left until it ends at the frame edge -- it recomputes a
+    // few columns of its neighbour and writes the same values (the host launches T > 1 only when
+    // W >= 64 T and the launch is not in place).
+    if constexpr (T > 1) {
+        if (L.x0 + 64 * T - RH > A.W) L.x0 = A.W - 64 * T + RH;
+    }
     L.W = A.W;
     L.lds = smem[wave];
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane(
@@ -562,15 +705,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void stream_kernel(const Strea
     // halo and always walk top-down.
     constexpr bool kHasHalo = SumRV<S...>::value > 0;
     if (kHasHalo && A.alternate && (chunk & 1))
-        stream_wave<Px, PF, true, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
+        stream_wave<Px, PF, T, true, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
     else
-        stream_wave<Px, PF, false, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
+        stream_wave<Px, PF, T, false, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
 }
 
 // ---------------------------------------------------------------------------------
 // Host side: op list -> stage list -> kernel instantiation
 // ---------------------------------------------------------------------------------
-static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo_rows, int bpp, const StreamTuning& tune)
+static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo_rows, int bpp, const StreamTuning& tune, bool top_down)
 {
     if (tune.rows_per_chunk > 0) return tune.rows_per_chunk;
     // A wave walks its chunk row by row (0.2-0.5 us per row), so a small frame is bound by the
@@ -590,7 +733,9 @@ static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo
     const int max_chunks = slots / strip_groups > 1 ? slots / strip_groups : 1;
     const long fit = (rows + max_chunks - 1) / max_chunks;
     const int lo = h > 4 ? 2 * h : 8;
-    const int hi = narrow ? (12 * h > 16 ? 12 * h : 16) : (h <= 4 ? (8 * h > 8 ? 8 * h : 8) : 16 * h);   // 5-stage chain (h = 7) at 16384^2: 128-row 2.03 ms, 96-row 2.08, 84-row 2.12
+    // all-top-down walks share no halo rows through L2: each chunk fetches its own, so they are taller (16384^2 5-stage chain,
+    // two texels per lane: 112-row chunks 1.87 ms, 256-row 1.81, 384-row 2.01)
+    const int hi = narrow ? (12 * h > 16 ? 12 * h : 16) : (h <= 4 ? (8 * h > 8 ? 8 * h : 8) : (top_down ? 36 * h : 16 * h));   // 5-stage chain (h = 7) at 16384^2: 128-row 2.03 ms, 96-row 2.08, 84-row 2.12
     // a frame that fits ONE round at up to twice the cap keeps the single round (4K 3-stage chain:
     // 36-row chunks = 1020 workgroups on 1024 slots, 194.6k Mpx/s; 24-row 191k; 44-row 180k)
     int rpc = (int)(fit < lo ? lo : (fit > 2 * hi ? hi : fit));
@@ -613,7 +758,7 @@ static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo
 }
 
 // workgroups of this kernel the whole chip holds at once
-template <class Px, int PF, class... S> static int resident_workgroups()
+template <class Px, int PF, int T, class... S> static int resident_workgroups()
 {
     static int slots_of[64] = {};                    // per device: a process may hold contexts on several GPUs
     int dev = 0;
@@ -621,20 +766,20 @@ template <class Px, int PF, class... S> static int resident_workgroups()
     int& slots = slots_of[dev];
     if (slots == 0) {
         int per_cu = 0, cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_kernel<Px, PF, S...>, 64 * kWavesPerBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_kernel<Px, PF, T, S...>, 64 * kWavesPerBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         slots = per_cu * (cus > 0 ? cus : 256);
     }
     return slots;
 }
 
-template <class Px, int PF, class... S>
-static hipError_t launch_stream(Image src, Image dst, const Geom& g, const StreamTuning& tune, hipStream_t stream,
-                                const ParamPack<S...>& params, int halo_rows)
+template <class Px, int PF, int T, class... S>
+static hipError_t launch_stream_t(Image src, Image dst, const Geom& g, const StreamTuning& tune, hipStream_t stream,
+                                  const ParamPack<S...>& params, int halo_rows)
 {
     constexpr int RH = SumRH<S...>::value;
-    constexpr int VALID = 64 - 2 * RH;
-    static_assert(VALID > 0, "horizontal halo too wide for a 64-lane strip");
+    constexpr int VALID = 64 * T - 2 * RH;
+    static_assert(VALID > 0, "horizontal halo too wide for the strip");
     StreamArgs<S...> A;
     A.src = static_cast<const char*>(src.base);
     A.src_pitch = src.pitch;
@@ -648,27 +793,68 @@ static hipError_t launch_stream(Image src, Image dst, const Geom& g, const Strea
     A.n_strips = (g.W + VALID - 1) / VALID;
     const int rows = g.y1 - g.y0;
     if (rows <= 0 || g.W <= 0) return hipSuccess;
-    A.rows_per_chunk = choose_rows_per_chunk(rows, (A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock, resident_workgroups<Px, PF, S...>(),
-                                             halo_rows, Px::BPP, tune);
+    A.rows_per_chunk = choose_rows_per_chunk(rows, (A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock, resident_workgroups<Px, PF, T, S...>(),
+                                             halo_rows, Px::BPP, tune, tune.walk == 2);
     A.params = params;
     A.n_work = ((A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock) * ((rows + A.rows_per_chunk - 1) / A.rows_per_chunk);
-    A.alternate = tune.no_alternate ? 0 : 1;
+    A.alternate = tune.walk == 2 ? 0 : 1;
     dim3 grid((unsigned)((A.n_work + 7) / 8 * 8));   // 1-D, a multiple of the 8 XCDs (see the kernel's block order)
-    hipLaunchKernelGGL((stream_kernel<Px, PF, S...>), grid, dim3(64 * kWavesPerBlock), 0, stream, A);
+    hipLaunchKernelGGL((stream_kernel<Px, PF, T, S...>), grid, dim3(64 * kWavesPerBlock), 0, stream, A);
     return hipGetLastError();
+}
+
+// multiply-adds per texel and row of a stage list: what decides whether a pipeline is bound by
+// vector issue (the 5-stage BASELINE chain: 33 taps) or by the memory path (3-stage chain: 15)
+template <class S> struct TapsOf { static constexpr int value = 0; };
+template <int R> struct TapsOf<StHTap<R>> { static constexpr int value = 2 * R + 1; };
+template <int R> struct TapsOf<StVTap<R>> { static constexpr int value = 2 * R + 1; };
+template <> struct TapsOf<StCross3> { static constexpr int value = 5; };
+template <> struct TapsOf<StGrade> { static constexpr int value = 3; };
+template <class... S> struct MaxRV { static constexpr int value = 0; };
+template <class S, class... Rest> struct MaxRV<S, Rest...> { static constexpr int value = S::RV > MaxRV<Rest...>::value ? S::RV : MaxRV<Rest...>::value; };
+template <class... S> struct SumTaps { static constexpr int value = 0; };
+template <class S, class... Rest> struct SumTaps<S, Rest...> { static constexpr int value = TapsOf<S>::value + SumTaps<Rest...>::value; };
+
+// Walk policy of a launch (measured with scripts/walk_probe.py on MI355X):
+//  * ISSUE-BOUND pipelines (>= kHeavyTaps multiply-adds per texel) walk every chunk TOP-DOWN and, on large
+//    rgba32f frames, take TWO texels per lane: 128-wide strips halve the share of halo
+//    lanes and the per-row scalar work, and top-down walks run the vertical taps in scatter form
+//    (StVTap: no window shifts).  5-stage chain: 16384^2 2.04 -> 1.86 ms, 8K 0.260 -> 0.241 ms.
+//  * everything else keeps one texel per lane and ALTERNATING walks: it is bound by the memory
+//    path, more waves in flight and halo rows shared through L2 matter more (3-stage chain at 4K:
+//    42.2 us alternating, 43.4 top-down, 43.7 with two texels).
+// Two texels per lane are never used in place (the last strip overlaps its neighbour: see
+// stream_kernel), for rgba8 (its lanes would issue four 256-B DMAs per row) or for narrow frames.
+constexpr int kHeavyTaps = 24;
+constexpr long kTwoTexelMinPixels = 24L << 20;   // two texels per lane from 8K frames up (5-stage chain at 4K: 64.4 us with one, 68.3 with two)
+
+template <class Px, int PF, class... S>
+static hipError_t launch_stream(Image src, Image dst, const Geom& g, const StreamTuning& tune, hipStream_t stream,
+                                const ParamPack<S...>& params, int halo_rows)
+{
+    StreamTuning t = tune;
+    const long px = (long)g.W * (long)(g.y1 - g.y0);
+    const bool heavy = SumTaps<S...>::value >= kHeavyTaps;
+    if (t.walk == 0) t.walk = heavy ? 2 : 1;
+    if constexpr (!Px::QUANT && SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4) {   // (a radius-6 window of two texels no longer fits 256 VGPRs)
+        const bool can2 = src.base != dst.base && g.W >= 256;
+        const bool two = t.texels_per_lane == 2 || (t.texels_per_lane == 0 && heavy && px >= kTwoTexelMinPixels);
+        if (two && can2) return launch_stream_t<Px, (PF > 4 ? 4 : PF), 2, S...>(src, dst, g, t, stream, params, halo_rows);
+    }
+    return launch_stream_t<Px, PF, 1, S...>(src, dst, g, t, stream, params, halo_rows);
 }
 
 // ---- op -> params helpers -------------------------------------------------------
 template <int R> static typename StHTap<R>::Params htap_params(const Op& op)
 {
     typename StHTap<R>::Params p;
-    for (int i = 0; i <= R; ++i) p.w[i] = op.w[i];
+    for (int i = 0; i <= R; ++i) p.w[i] = v2f{op.w[i], op.w[i]};
     return p;
 }
 template <int R> static typename StVTap<R>::Params vtap_params(const Op& op)
 {
     typename StVTap<R>::Params p;
-    for (int i = 0; i <= R; ++i) p.w[i] = op.w[i];
+    for (int i = 0; i <= R; ++i) p.w[i] = v2f{op.w[i], op.w[i]};
     return p;
 }
 static StGrade::Params grade_params(const Op& op) { return {op.slope, op.offset, op.saturation}; }

@@ -1,0 +1,26 @@
+"""Exploration (GPU box): walk direction (alternating vs all top-down), texels per lane and chunk height.
+usage: walk_probe.py name:WxH[:rpc,rpc,...] ..."""
+import sys
+sys.path.insert(0, ".")
+import bench
+import reforge_amd as rf
+ctx = rf.Context(0)
+TEXTS = {"chain5": bench.CHAIN5, "chain3": bench.CHAIN3, "gauss9": bench.WORKLOADS["gauss9_8k"]["text"], "pass": "input -> passthrough -> output",
+         "sharpen": "input -> sh -> output\nsh: sharpen { amount: 0.5 }", "gauss5": "input -> blur -> output\nblur: gaussian5 { sigma: 1.0 }"}
+for sp in sys.argv[1:]:
+    parts = sp.split(":")
+    name, dims = parts[0], parts[1]
+    rpcs = [int(x) for x in parts[2].split(",")] if len(parts) > 2 else [0]
+    W, H = map(int, dims.split("x"))
+    for t in (1, 2):
+        line = []
+        for ex in (rf.RF_EXEC_ALTERNATE, rf.RF_EXEC_NO_ALTERNATE):
+            for rpc in rpcs:
+                g = rf.Graph(ctx, rf.Config(TEXTS[name]), W, H, 1, texels_per_lane=t, rows_per_chunk=rpc, exec_flags=ex)
+                g.fill_synthetic(1)
+                g.execute(); g.wait()
+                n = max(4, int(20 / max(g.time_frames(2) / 2, 0.02)))
+                ms = sorted(g.time_frames(n) / n for _ in range(5))
+                line.append("%s%d:%.4f" % ("fwd" if ex == rf.RF_EXEC_NO_ALTERNATE else "alt", rpc, ms[0]))
+                g.close()
+        print(name, dims, "T=%d" % t, " ".join(line), flush=True)

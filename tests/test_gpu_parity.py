@@ -364,6 +364,28 @@ def test_row_strips_overfetch_on_one_gpu(text, world, flags):
         util.assert_same(np.concatenate(strips, axis=0), want, "world=%d flags=%d fmt=%d" % (world, flags, fmt))
 
 
+@pytest.mark.parametrize("t", [1, 2])
+@pytest.mark.parametrize("walk", ["alternate", "top-down"])
+def test_texels_per_lane_and_walk_direction(ctx, t, walk):
+    """One or two texels per lane (64- / 128-wide strips; the two-texel launch moves its last strip left so
+    that every store of a row has an active lane) and both walk policies (odd chunks bottom-up with the
+    vertical taps in window form, or every chunk top-down with the taps in scatter form): all four
+    combinations must reproduce the oracle bit for bit -- several chunks per strip, ragged widths around
+    the 128-column strips, heights that end inside a chunk, frame edges inside the halo."""
+    ex = rf.RF_EXEC_ALTERNATE if walk == "alternate" else rf.RF_EXEC_NO_ALTERNATE
+    for text in (util.CHAIN5, util.CHAIN3, NODES["gaussian9"], NODES["sharpen"], NODES["gaussian_r7"], util.DIAMOND):
+        for W, H in ((256, 37), (257, 70), (371, 45), (640, 121)):
+            x = util.synthetic(W, H, util.F32, seed=W + H)
+            want = util.run_oracle(text, x)
+            for rpc in (0, 16, 29):
+                g = rf.Graph(ctx, rf.Config(text), W, H, util.F32, rows_per_chunk=rpc, exec_flags=ex, texels_per_lane=t)
+                g.upload_raw(x)
+                g.execute(); g.wait()
+                got = g.download_raw()
+                g.close()
+                util.assert_same(got, want, "T=%d %s %dx%d rpc=%d" % (t, walk, W, H, rpc))
+
+
 def test_interior_boundary_split(ctx):
     """Exchange mode overlaps the halo exchange with the interior rows by issuing a stencil
     launch in three parts (interior, top r rows, bottom r rows).  RF_FORCE_SPLIT=1 takes that

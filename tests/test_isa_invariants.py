@@ -1,11 +1,11 @@
 """CPU: invariants of the generated gfx950 code that the stream kernel's correctness rests on.
 
 The kernel waits for its LDS-DMA rows with a COUNTED `s_waitcnt vmcnt(N)` (rf_stream.hip,
-Source::wait_row): that is only right if, per row, a wave issues exactly one vector-memory load
-(the DMA) and one vector-memory store, in a fixed order.  hipcc cross-compiles without a GPU,
-so the assembly is checked here: every steady loop of every stream_kernel instantiation has
-exactly one `global_load_lds_*`, exactly one `global_store_*`, no other vector-memory
-instruction, and the kernels use no scratch and no workgroup barrier."""
+Source::wait_row): that is only right if, per row, a wave issues exactly T vector-memory loads
+(the DMAs; T = texels per lane) and T vector-memory stores, in a fixed order.  hipcc
+cross-compiles without a GPU, so the assembly is checked here: every steady loop of every
+stream_kernel instantiation has exactly T `global_load_lds_*`, exactly T `global_store_*`, no
+other vector-memory instruction, and the kernels use no scratch and no workgroup barrier."""
 import os
 import re
 import subprocess
@@ -44,12 +44,14 @@ def kernels(lines):
 
 
 def prefetch_depth(name):
-    return int(re.search(r"stream_kernelINS_\w+?ELi(\d+)E", name).group(1))
+    """(PF, T) of stream_kernel<Px, PF, T, stages...>"""
+    m = re.search(r"stream_kernelINS_\w+?ELi(\d+)ELi(\d+)E", name)
+    return int(m.group(1)), int(m.group(2))
 
 
-def steady_loops(body, pf=4):
-    """instruction lists of the loops whose wait is the steady counted form vmcnt(2*PF-2)"""
-    steady, warm = "vmcnt(%d)" % (2 * pf - 2), "vmcnt(%d)" % (pf - 1)
+def steady_loops(body, pf=4, t=1):
+    """instruction lists of the loops whose wait is the steady counted form vmcnt((2*PF-2)*T)"""
+    steady, warm = "vmcnt(%d)" % ((2 * pf - 2) * t), "vmcnt(%d)" % ((pf - 1) * t)
     spans = []                                # (header line, last back-branch line) of every loop
     for h, l in enumerate(body):
         if not re.match(r"^\.LBB\d+_\d+:.*Loop Header", l):
@@ -89,16 +91,16 @@ def test_stream_kernels_keep_the_counted_wait_contract(stream_asm):
         for i, ins in enumerate(instrs):
             if ins.startswith("global_load_lds"):
                 assert any(p.startswith("s_waitcnt") and "lgkmcnt(0)" in p for p in instrs[max(0, i - 5):i]), name
-        pf = prefetch_depth(name)
-        for loop in steady_loops(body, pf):
+        pf, t = prefetch_depth(name)
+        for loop in steady_loops(body, pf, t):
             ops = [x.split()[0] for x in loop]
             vmem = [o for o in ops if o.startswith(("global_", "buffer_", "flat_"))]
-            assert sorted(vmem) in (["global_load_lds_dword", "global_store_dword"],
-                                    ["global_load_lds_dwordx4", "global_store_dwordx4"]), (name, vmem)
-            # program order inside an iteration: DMA issue, then the counted wait, then the store
-            i_dma = next(k for k, o in enumerate(ops) if o.startswith("global_load_lds"))
-            i_wait = next(k for k, x in enumerate(loop) if "vmcnt(%d)" % (2 * pf - 2) in x)
-            i_store = next(k for k, o in enumerate(ops) if o.startswith("global_store"))
+            assert sorted(vmem) in (["global_load_lds_dword"] * t + ["global_store_dword"] * t,
+                                    ["global_load_lds_dwordx4"] * t + ["global_store_dwordx4"] * t), (name, vmem)
+            # program order inside an iteration: the T DMAs, then the counted wait, then the T stores
+            i_dma = max(k for k, o in enumerate(ops) if o.startswith("global_load_lds"))
+            i_wait = next(k for k, x in enumerate(loop) if "vmcnt(%d)" % ((2 * pf - 2) * t) in x)
+            i_store = min(k for k, o in enumerate(ops) if o.startswith("global_store"))
             assert i_dma < i_wait < i_store, name
             checked += 1
     assert checked >= len(ks)                 # at least one steady loop each (two when the pipeline has a halo)
@@ -108,10 +110,10 @@ def test_fused_chain_steady_loop_is_lean(stream_asm):
     """The 3-stage rgba32f chain: all 68 fmaf per row are packed (v_pk_fma_f32), and the loop
     stays near 110 instructions (it was ~250 before the steady-state split)."""
     ks = kernels(stream_asm)
-    name = [n for n in ks if "PxF32ELi4E" in n and "StHTapILi2E" in n and "StGrade" in n and "StCross3EEEEv" in n]   # ends at the sharpen
+    name = [n for n in ks if "PxF32ELi4ELi1E" in n and "StHTapILi2E" in n and "StGrade" in n and "StCross3EEEEv" in n]   # ends at the sharpen
     assert len(name) == 1
     loops = steady_loops(ks[name[0]])
-    assert len(loops) == 2                    # top-down and bottom-up walks
+    assert len(loops) == 2                    # top-down (vertical taps in scatter form) and bottom-up walks
     for loop in loops:
         ops = [x.split()[0] for x in loop]
         assert ops.count("v_pk_fma_f32") >= 30
