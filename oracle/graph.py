@@ -197,11 +197,20 @@ def parse_config(text, expects_input=True):
 _IO = {"input_image": 0, "output_image": 1}
 _IO_RW = {"input_image": 0, "output_image": 1, "image": 2}
 
+def _gauss_params(radius, with_radius=False):
+    """sigma (+ radius) and the optional explicit weights w0 .. wR (shaders/gaussian*.comp)."""
+    p = {"sigma": "f32"}
+    if with_radius:
+        p["radius"] = "i32"
+    p.update({"w%d" % i: "f32" for i in range(radius + 1)})
+    return p
+
+
 NODE_TYPES = {
     "passthrough":  {"images": _IO,    "params": {}},
-    "gaussian5":    {"images": _IO,    "params": {"sigma": "f32"}},
-    "gaussian9":    {"images": _IO,    "params": {"sigma": "f32"}},
-    "gaussian":     {"images": _IO,    "params": {"sigma": "f32", "radius": "i32"}},
+    "gaussian5":    {"images": _IO,    "params": _gauss_params(2)},
+    "gaussian9":    {"images": _IO,    "params": _gauss_params(4)},
+    "gaussian":     {"images": _IO,    "params": _gauss_params(15, True)},
     "colour_grade": {"images": _IO_RW, "params": {"slope": "f32", "offset": "f32", "saturation": "f32"}},
     "sharpen":      {"images": _IO,    "params": {"amount": "f32"}},
     "conv2d":       {"images": _IO,    "params": {"ksize": "i32", "sigma": "f32"}},
@@ -209,6 +218,7 @@ NODE_TYPES = {
                      "params": {"mix": "f32"}},
 }
 NODE_TYPES["colour-grade"] = NODE_TYPES["colour_grade"]
+NODE_TYPES["colour_grade_inplace"] = {"images": {"image": 0}, "params": NODE_TYPES["colour_grade"]["params"]}
 NODE_TYPES["grade"] = NODE_TYPES["colour_grade"]
 
 
@@ -406,7 +416,7 @@ class GraphOracle:
             pixel.mix(img(by_binding[0]), img(by_binding[1]), p["mix"], dst=dst)
             return
         src = img(info.input_images[0][0])
-        if src is dst and t not in ("colour_grade", "colour-grade", "grade", "passthrough"):
+        if src is dst and t not in ("colour_grade", "colour-grade", "grade", "colour_grade_inplace", "passthrough"):
             raise ConfigError("in-place execution of a stencil node")
         if t == "passthrough":
             if src is not dst:
@@ -415,8 +425,12 @@ class GraphOracle:
             radius = {"gaussian5": 2, "gaussian9": 4}.get(t)
             if radius is None:
                 radius = min(max(int(p["radius"]), 0), pixel.MAX_RADIUS)
-            pixel.gaussian(src, radius, sigma=p["sigma"], dst=dst)
-        elif t in ("colour_grade", "colour-grade", "grade"):
+            given = [p["w%d" % i] for i in range(radius + 1)]
+            if any(w != 0 for w in given):      # explicit weights replace the derived kernel
+                pixel.gaussian(src, radius, weights=np.asarray(given, np.float32), dst=dst)
+            else:
+                pixel.gaussian(src, radius, sigma=p["sigma"], dst=dst)
+        elif t in ("colour_grade", "colour-grade", "grade", "colour_grade_inplace"):
             pixel.colour_grade(src, p["slope"], p["offset"], p["saturation"], dst=dst)
         elif t == "sharpen":
             pixel.sharpen(src, p["amount"], dst=dst)

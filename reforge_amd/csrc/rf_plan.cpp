@@ -35,13 +35,24 @@ const std::vector<NodeType>& registry()
     static const std::vector<std::pair<const char*, int>> io = {{"input_image", 0}, {"output_image", 1}};
     static const std::vector<std::pair<const char*, int>> io_rw = {{"input_image", 0}, {"output_image", 1}, {"image", 2}};
     static const std::vector<std::pair<const char*, int>> io2 = {{"input_image0", 0}, {"input_image1", 1}, {"output_image", 2}};
+    static const std::vector<std::pair<const char*, int>> rw = {{"image", 0}};   // shaders/colour_grade_inplace.comp: one read-write image
     static const std::vector<ParamDef> grade = {{"slope", PARAM_F32}, {"offset", PARAM_F32}, {"saturation", PARAM_F32}};
+    // gaussian types: sigma (+ radius) and the OPTIONAL explicit weights w0 .. wR of shaders/gaussian*.comp: all zero
+    // (not given) => derived from sigma on the host; given => used as they are (scripts/glsl_weights.py prints them)
+    static const char* wn[kMaxRadius + 1] = {"w0", "w1", "w2", "w3", "w4", "w5", "w6", "w7", "w8", "w9", "w10", "w11", "w12", "w13", "w14", "w15"};
+    auto gauss_params = [&](int r, bool with_radius) {
+        std::vector<ParamDef> v = {{"sigma", PARAM_F32}};
+        if (with_radius) v.push_back({"radius", PARAM_I32});
+        for (int i = 0; i <= r; ++i) v.push_back({wn[i], PARAM_F32});
+        return v;
+    };
     static const std::vector<NodeType> types = {
         {"passthrough", OP_PASSTHROUGH, 0, io, {}},
-        {"gaussian5", OP_GAUSSIAN, 2, io, {{"sigma", PARAM_F32}}},
-        {"gaussian9", OP_GAUSSIAN, 4, io, {{"sigma", PARAM_F32}}},
-        {"gaussian", OP_GAUSSIAN, -1, io, {{"sigma", PARAM_F32}, {"radius", PARAM_I32}}},
+        {"gaussian5", OP_GAUSSIAN, 2, io, gauss_params(2, false)},
+        {"gaussian9", OP_GAUSSIAN, 4, io, gauss_params(4, false)},
+        {"gaussian", OP_GAUSSIAN, -1, io, gauss_params(kMaxRadius, true)},
         {"colour_grade", OP_GRADE, 0, io_rw, grade},
+        {"colour_grade_inplace", OP_GRADE, 0, rw, grade},
         {"colour-grade", OP_GRADE, 0, io_rw, grade},
         {"grade", OP_GRADE, 0, io_rw, grade},
         {"sharpen", OP_SHARPEN, 1, io, {{"amount", PARAM_F32}}},
@@ -147,6 +158,13 @@ Op NodeParams::to_op(const float* dev_weights) const
             if (r < 0) r = std::min(std::max(pi(values, "radius"), 0), kMaxRadius);
             op.radius = r;
             gaussian_weights(pf(values, "sigma"), r, op.w);
+            {   // explicit weights (shaders/gaussian*.comp: `w0 .. wR`): any non-zero member replaces the derived kernel
+                static const char* wn[kMaxRadius + 1] = {"w0", "w1", "w2", "w3", "w4", "w5", "w6", "w7", "w8", "w9", "w10", "w11", "w12", "w13", "w14", "w15"};
+                bool given = false;
+                for (int i = 0; i <= r; ++i) given = given || pf(values, wn[i]) != 0.0f;
+                if (given)
+                    for (int i = 0; i <= r; ++i) op.w[i] = pf(values, wn[i]);
+            }
             break;
         }
         case OP_GRADE:

@@ -364,6 +364,26 @@ def test_row_strips_overfetch_on_one_gpu(text, world, flags):
         util.assert_same(np.concatenate(strips, axis=0), want, "world=%d flags=%d fmt=%d" % (world, flags, fmt))
 
 
+def test_explicit_gaussian_weights_and_the_in_place_grade_type(ctx):
+    """The members shaders/gaussian*.comp add to the plugin contract: explicit weights `w0 .. wR` (given => they replace
+    the kernel derived from sigma) and the `colour_grade_inplace` type (one read-write image named `image`).  The HIP
+    path must honour both exactly as the oracle does, fused and unfused."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import glsl_weights
+    same = "input -> gg -> output\ngg: gaussian9 { sigma: 7.0, %s }" % glsl_weights.as_params(2.0, 4)          # the weights of sigma 2, not 7
+    derived = "input -> gg -> output\ngg: gaussian9 { sigma: 2.0 }"
+    odd = "input -> gg -> sh -> output\ngg: gaussian5 { sigma: 1.0, w0: 0.5, w1: 0.125, w2: 0.375 }\nsh: sharpen { amount: 0.3 }"   # not even normalised
+    inplace = "input -> blur -> gg:image -> sh -> output\nblur: gaussian5 { sigma: 1.2 }\ngg: colour_grade_inplace { slope: 1.2, offset: 0.01, saturation: 0.7 }\nsh: sharpen { amount: 0.4 }"
+    for fmt in (util.F32, util.U8):
+        x = util.synthetic(150, 97, fmt, seed=11)
+        util.assert_same(util.run_hip(ctx, same, x), util.run_oracle(derived, x), "explicit weights equal to the derived ones")
+        for text in (same, odd, inplace):
+            want = util.run_oracle(text, x)
+            for flags in (0, NF):
+                util.assert_same(util.run_hip(ctx, text, x, flags=flags), want, "flags %d\n%s" % (flags, text))
+
+
 @pytest.mark.parametrize("t", [1, 2])
 @pytest.mark.parametrize("walk", ["alternate", "top-down"])
 def test_texels_per_lane_and_walk_direction(ctx, t, walk):
