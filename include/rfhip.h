@@ -59,6 +59,9 @@ typedef enum rf_param_type { RF_PARAM_F32 = 0, RF_PARAM_I32 = 1, RF_PARAM_BOOL =
 #define RF_GRAPH_HIPGRAPH    0x4u  /* replay the recorded frame as one hipGraph                 */
 #define RF_GRAPH_NO_HALO_XCHG 0x8u /* multi-rank: over-fetch the cumulative halo at upload
                                       instead of a per-node RCCL exchange                      */
+#define RF_GRAPH_NO_JIT      0x10u /* fuse only chains whose kernel is in the ahead-of-time catalogue: nothing is
+                                      compiled at graph creation (the reference compiles every node's shader
+                                      there, shader.rs:29-93; here only chains the catalogue lacks need it)      */
 
 typedef struct rf_ctx    rf_ctx;     /* VkCore            src/vulkan/core.rs:47-64   */
 typedef struct rf_config rf_config;  /* config::Config    src/config/config.rs:35-38 */
@@ -75,8 +78,6 @@ typedef struct rf_graph  rf_graph;   /* PipelineGraph + its frames  pipeline_gra
                                            exchange (how the multi-rank split is tested on one GPU) */
 #define RF_EXEC_NO_ALTERNATE      0x8u  /* every chunk walks top-down (default: chosen per launch)      */
 #define RF_EXEC_ALTERNATE         0x20u /* odd chunks walk bottom-up (halo rows shared through L2)      */
-#define RF_EXEC_NO_JIT            0x10u /* never compile a fused chain at graph creation: only the
-                                           ahead-of-time catalogue fuses                            */
 
 typedef struct rf_graph_options {
     int       width;        /* RenderInfo.width   src/render.rs:40 */
@@ -165,6 +166,20 @@ int         rf_plan_launch_radius(const rf_plan* plan, int i);
  * another launch of the layer reads or writes (an in-place point op beside a second consumer).
  * The reference runs such a layer concurrently (command.rs:194-240), a data race. */
 int         rf_plan_launch_serial(const rf_plan* plan, int i);
+/* Kernels compiled at graph creation.  A fused launch whose stage list the ahead-of-time kernel catalogue lacks is
+ * compiled by rf_graph_create with hiprtc from the library's own device source -- the counterpart of
+ * Shader::from_path + Pipeline::new_compute (src/vulkan/shader.rs:29-93, pipeline.rs:73-88), which run at the same
+ * point of the reference.  RF_GRAPH_NO_JIT (or env RF_NO_JIT=1) plans with the catalogue alone.
+ * Optional disk cache of code objects: env RF_JIT_CACHE_DIR. */
+/* [host] 1 if libhiprtc can be loaded and RF_NO_JIT is unset */
+int         rf_jit_available(void);
+/* [host] kernels this process has compiled so far (cache hits not counted) */
+int         rf_jit_compile_count(void);
+/* [host] 1 if launch i needs a kernel the catalogue does not hold */
+int         rf_plan_launch_needs_jit(const rf_plan* plan, int i);
+/* [host] compiles every such kernel of the plan for gfx950 WITHOUT a device (nothing is loaded): proves on a
+ * GPU-less machine that the generated instantiations build; *code_bytes = total code object size */
+rf_status   rf_plan_jit_compile(const rf_plan* plan, int format, size_t* code_bytes);
 /* [host] ghost-row schedule of a row-strip partition (new: SURVEY.md 8e).
  *   exchange != 0: before launch i its input's need_src[i] = radius edge rows are
  *                  exchanged with the neighbour ranks; need_dst[i] = 0.

@@ -28,12 +28,12 @@ RF_GRAPH_TIMERS = 0x1
 RF_GRAPH_NO_FUSION = 0x2
 RF_GRAPH_HIPGRAPH = 0x4
 RF_GRAPH_NO_HALO_XCHG = 0x8
+RF_GRAPH_NO_JIT = 0x10
 
 RF_EXEC_SYNC_LAUNCHES = 0x1
 RF_EXEC_CONCURRENT_LAYERS = 0x2
 RF_EXEC_FORCE_SPLIT = 0x4
 RF_EXEC_NO_ALTERNATE = 0x8
-RF_EXEC_NO_JIT = 0x10
 RF_EXEC_ALTERNATE = 0x20
 
 RF_CONV_AUTO, RF_CONV_TILE, RF_CONV_MFMA, RF_CONV_VALU, RF_CONV_HYBRID = 0, 1, 2, 3, 4
@@ -89,6 +89,10 @@ SIGNATURES = {
     "rf_plan_launch_output": (_cp, [_vp, _i]),
     "rf_plan_launch_radius": (_i, [_vp, _i]),
     "rf_plan_launch_serial": (_i, [_vp, _i]),
+    "rf_jit_available": (_i, []),
+    "rf_jit_compile_count": (_i, []),
+    "rf_plan_launch_needs_jit": (_i, [_vp, _i]),
+    "rf_plan_jit_compile": (_i, [_vp, _i, C.POINTER(C.c_size_t)]),
     "rf_plan_halo_schedule": (_i, [_vp, _i, _pi, _pi, _i, _pi, _pi]),
     "rf_registry_num_types": (_i, []),
     "rf_registry_type_name": (_cp, [_i]),

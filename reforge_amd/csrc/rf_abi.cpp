@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstring>
 
+#include "rf_jit.h"
 #include "rf_runtime.h"
 
 namespace rf {
@@ -276,6 +277,41 @@ extern "C" rf_status rf_plan_halo_schedule(const rf_plan* p, int exchange, int* 
         need_src[k] = l[k].need_src;
         need_dst[k] = l[k].need_dst;
     }
+    return RF_OK;
+}
+
+// ---- kernels compiled at graph creation (rf_jit.cpp) --------------------------------------------
+extern "C" int rf_jit_available(void) { return jit_available() ? 1 : 0; }
+extern "C" int rf_jit_compile_count(void) { return jit_compile_count(); }
+
+extern "C" int rf_plan_launch_needs_jit(const rf_plan* p, int i)
+{
+    const LaunchDesc* l = launch_at(p, i);
+    if (!l) return -1;
+    std::vector<Op> ops;
+    for (const auto& m : l->members) ops.push_back(p->plan.nodes.at(m).to_op(nullptr));
+    StageList sl;
+    if (ops.size() < 2 || !ops_to_stages(ops.data(), (int)ops.size(), sl)) return 0;
+    return stream_in_catalogue(sl) ? 0 : 1;
+}
+
+extern "C" rf_status rf_plan_jit_compile(const rf_plan* p, int format, size_t* code_bytes)
+{
+    if (!p) return fail(RF_ERR_INVALID, "rf_plan_jit_compile: null plan");
+    if (!p->launch_error.empty()) return fail(RF_ERR_GRAPH, p->launch_error);
+    if (format != RF_FORMAT_RGBA8 && format != RF_FORMAT_RGBA32F) return fail(RF_ERR_INVALID, "rf_plan_jit_compile: unknown format");
+    size_t total = 0;
+    for (const auto& l : p->launches) {
+        std::vector<Op> ops;
+        for (const auto& m : l.members) ops.push_back(p->plan.nodes.at(m).to_op(nullptr));
+        StageList sl;
+        if (ops.size() < 2 || !ops_to_stages(ops.data(), (int)ops.size(), sl) || stream_in_catalogue(sl)) continue;
+        std::string err;
+        const size_t n = jit_compile_only(format, 4, 1, sl, 4, err);
+        if (n == 0) return fail(RF_ERR_UNSUPPORTED, err);
+        total += n;
+    }
+    if (code_bytes) *code_bytes = total;
     return RF_OK;
 }
 

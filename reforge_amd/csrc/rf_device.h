@@ -5,14 +5,16 @@
 // bit-identical to oracle/rf_oracle.c for finite inputs.
 #pragma once
 
+#ifndef __HIPCC_RTC__   // hiprtc (rf_jit.cpp) supplies the HIP device headers itself and has no libc headers
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
 
-#include <type_traits>
-
 #include "rf_kernels.h"
+#endif
+
+#include <type_traits>
 
 namespace rf {
 
@@ -132,7 +134,9 @@ struct PxU8 {
     }
 };
 
+#ifndef __HIPCC_RTC__
 // dense KxK convolution launch (rf_conv.hip), called from launch_ops
 hipError_t launch_conv2d(int fmt, const Op& op, Image src, Image dst, const Geom& g, const StreamTuning& tune, hipStream_t stream);
+#endif
 
 }  // namespace rf

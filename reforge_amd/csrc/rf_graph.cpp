@@ -437,20 +437,71 @@ extern "C" rf_status rf_ctx_copy_bandwidth(rf_ctx* ctx, size_t bytes, int iters,
 // ---------------------------------------------------------------------------------
 // Graph
 // ---------------------------------------------------------------------------------
+// tuning and executor variants: rf_graph_options first, the environment overrides when set
+static void read_tuning(rf_graph* g)
+{
+    const rf_graph_options& opt = g->opt;
+    g->tune.rows_per_chunk = opt.rows_per_chunk;
+    g->tune.conv_path = opt.conv_path;
+    g->tune.texels_per_lane = opt.texels_per_lane;
+    g->tune.walk = (opt.exec_flags & RF_EXEC_NO_ALTERNATE) ? 2 : (opt.exec_flags & RF_EXEC_ALTERNATE) ? 1 : 0;
+    g->sync_launches = (opt.exec_flags & RF_EXEC_SYNC_LAUNCHES) != 0;
+    g->concurrent_layers = (opt.exec_flags & RF_EXEC_CONCURRENT_LAYERS) != 0;
+    g->force_split = (opt.exec_flags & RF_EXEC_FORCE_SPLIT) != 0;
+    if (const char* e = std::getenv("RF_ROWS_PER_CHUNK")) g->tune.rows_per_chunk = std::atoi(e);
+    if (const char* e = std::getenv("RF_CONV_PATH")) g->tune.conv_path = std::atoi(e);
+    if (const char* e = std::getenv("RF_TEXELS_PER_LANE")) g->tune.texels_per_lane = std::atoi(e);
+    if (const char* e = std::getenv("RF_SYNC_LAUNCHES")) g->sync_launches = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RF_CONCURRENT_LAYERS")) g->concurrent_layers = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RF_FORCE_SPLIT")) g->force_split = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RF_NO_ALTERNATE")) g->tune.walk = std::atoi(e) ? 2 : 1;
+    // Exchange mode shares ONE comm stream and one src_ready/halo_ready event pair per slot: two
+    // stencils of a layer reading the same source would each re-exchange its ghost rows while the
+    // other's boundary kernels may still read them.  Plan order on one stream keeps it ordered.
+    if (exchange_mode(g)) g->concurrent_layers = false;
+}
+
 static rf_status graph_build(rf_graph* g, const rf_config* cfg)
 {
     rf_ctx* ctx = g->ctx;
     const rf_graph_options& opt = g->opt;
     std::string err;
-    if (!build_plan(cfg->cfg, opt.flags, g->plan.plan, err)) return fail(RF_ERR_GRAPH, err);
+    uint32_t plan_flags = opt.flags;
+    if (!build_plan(cfg->cfg, plan_flags, g->plan.plan, err)) return fail(RF_ERR_GRAPH, err);
     g->plan.index();
+    HIP_TRY(hipSetDevice(ctx->device));
+    read_tuning(g);
+    // Kernels of fused chains the ahead-of-time catalogue lacks are compiled HERE, where the reference compiles its
+    // shaders (PipelineGraph::new -> Pipeline::new_compute, pipeline_graph.rs:509-545), never on the frame path.  If a
+    // chain cannot be compiled (no libhiprtc, or the compiler rejects it) the graph is planned again with
+    // catalogue-only fusion: same results, more launches.
+    if (!(plan_flags & (kPlanNoJit | kPlanNoFusion))) {
+        int Hs0, Hs1;
+        strip_rows(opt.height, ctx->world, ctx->rank, Hs0, Hs1);
+        bool ok = g->plan.launch_error.empty();
+        for (const auto& d : g->plan.launches) {
+            if (!ok) break;
+            std::vector<Op> ops;
+            for (const auto& m : d.members) ops.push_back(g->plan.plan.nodes.at(m).to_op(nullptr));
+            if (ops.size() < 2) continue;
+            std::string jerr;
+            if (!stream_prepare(opt.format, ops.data(), (int)ops.size(), opt.width, Hs1 - Hs0, g->tune, jerr)) {
+                g->jit_note = "catalogue-only fusion: " + jerr;
+                ok = false;
+            }
+        }
+        if (!ok && g->plan.launch_error.empty()) {
+            plan_flags |= kPlanNoJit;
+            g->plan = rf_plan();
+            if (!build_plan(cfg->cfg, plan_flags, g->plan.plan, err)) return fail(RF_ERR_GRAPH, err);
+            g->plan.index();
+        }
+    }
     const Plan& plan = g->plan.plan;
 
     strip_rows(opt.height, ctx->world, ctx->rank, g->strip_y0, g->strip_y1);
     const int Hs = strip_rows_of(g);
     if (Hs < 1) return fail(RF_ERR_INVALID, "frame has fewer rows than ranks");
-
-    HIP_TRY(hipSetDevice(ctx->device));
 
     // conv2d weight buffers (default weights; rf_graph_set_weights overrides)
     for (const auto& kv : plan.nodes) {
@@ -487,26 +538,6 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
     if (ctx->world > 1 && g->ghost > opt.height / ctx->world)
         return fail(RF_ERR_UNSUPPORTED, "strip height " + std::to_string(opt.height / ctx->world) +
                                             " is smaller than the halo " + std::to_string(g->ghost));
-
-    // tuning and executor variants: rf_graph_options first, the environment overrides when set
-    g->tune.rows_per_chunk = opt.rows_per_chunk;
-    g->tune.conv_path = opt.conv_path;
-    g->tune.texels_per_lane = opt.texels_per_lane;
-    g->tune.walk = (opt.exec_flags & RF_EXEC_NO_ALTERNATE) ? 2 : (opt.exec_flags & RF_EXEC_ALTERNATE) ? 1 : 0;
-    g->sync_launches = (opt.exec_flags & RF_EXEC_SYNC_LAUNCHES) != 0;
-    g->concurrent_layers = (opt.exec_flags & RF_EXEC_CONCURRENT_LAYERS) != 0;
-    g->force_split = (opt.exec_flags & RF_EXEC_FORCE_SPLIT) != 0;
-    if (const char* e = std::getenv("RF_ROWS_PER_CHUNK")) g->tune.rows_per_chunk = std::atoi(e);
-    if (const char* e = std::getenv("RF_CONV_PATH")) g->tune.conv_path = std::atoi(e);
-    if (const char* e = std::getenv("RF_TEXELS_PER_LANE")) g->tune.texels_per_lane = std::atoi(e);
-    if (const char* e = std::getenv("RF_SYNC_LAUNCHES")) g->sync_launches = std::atoi(e) != 0;
-    if (const char* e = std::getenv("RF_CONCURRENT_LAYERS")) g->concurrent_layers = std::atoi(e) != 0;
-    if (const char* e = std::getenv("RF_FORCE_SPLIT")) g->force_split = std::atoi(e) != 0;
-    if (const char* e = std::getenv("RF_NO_ALTERNATE")) g->tune.walk = std::atoi(e) ? 2 : 1;
-    // Exchange mode shares ONE comm stream and one src_ready/halo_ready event pair per slot: two
-    // stencils of a layer reading the same source would each re-exchange its ghost rows while the
-    // other's boundary kernels may still read them.  Plan order on one stream keeps it ordered.
-    if (exchange_mode(g)) g->concurrent_layers = false;
 
     // per-frame images, streams, events (PipelineGraphFrame::new, Frame::new)
     const size_t pitch = align_up((size_t)opt.width * bytes_per_pixel(opt.format), 256);

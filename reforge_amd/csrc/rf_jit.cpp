@@ -1,0 +1,246 @@
+// rf_jit.cpp -- see rf_jit.h.
+#include "rf_jit.h"
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace rf {
+
+namespace {
+
+// the device source: rf_device.h + rf_stream_dev.h, generated into build/ by the Makefile
+const char kSource[] =
+#include "build/rf_jit_source.inc"
+    ;
+
+typedef struct _hiprtcProgram* RtcProgram;
+struct Rtc {
+    void* handle = nullptr;
+    int (*CreateProgram)(RtcProgram*, const char*, const char*, int, const char**, const char**) = nullptr;
+    int (*AddNameExpression)(RtcProgram, const char*) = nullptr;
+    int (*CompileProgram)(RtcProgram, int, const char**) = nullptr;
+    int (*GetProgramLogSize)(RtcProgram, size_t*) = nullptr;
+    int (*GetProgramLog)(RtcProgram, char*) = nullptr;
+    int (*GetCodeSize)(RtcProgram, size_t*) = nullptr;
+    int (*GetCode)(RtcProgram, char*) = nullptr;
+    int (*GetLoweredName)(RtcProgram, const char*, const char**) = nullptr;
+    int (*DestroyProgram)(RtcProgram*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+Rtc* rtc()
+{
+    static Rtc lib;
+    static bool tried = false;
+    if (tried) return lib.handle ? &lib : nullptr;
+    tried = true;
+    for (const char* n : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"}) {
+        lib.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (lib.handle) break;
+    }
+    if (!lib.handle) return nullptr;
+    bool ok = true;
+    auto sym = [&](const char* name) {
+        void* p = dlsym(lib.handle, name);
+        if (!p) ok = false;
+        return p;
+    };
+    lib.CreateProgram = (decltype(lib.CreateProgram))sym("hiprtcCreateProgram");
+    lib.AddNameExpression = (decltype(lib.AddNameExpression))sym("hiprtcAddNameExpression");
+    lib.CompileProgram = (decltype(lib.CompileProgram))sym("hiprtcCompileProgram");
+    lib.GetProgramLogSize = (decltype(lib.GetProgramLogSize))sym("hiprtcGetProgramLogSize");
+    lib.GetProgramLog = (decltype(lib.GetProgramLog))sym("hiprtcGetProgramLog");
+    lib.GetCodeSize = (decltype(lib.GetCodeSize))sym("hiprtcGetCodeSize");
+    lib.GetCode = (decltype(lib.GetCode))sym("hiprtcGetCode");
+    lib.GetLoweredName = (decltype(lib.GetLoweredName))sym("hiprtcGetLoweredName");
+    lib.DestroyProgram = (decltype(lib.DestroyProgram))sym("hiprtcDestroyProgram");
+    lib.GetErrorString = (decltype(lib.GetErrorString))sym("hiprtcGetErrorString");
+    if (!ok) {
+        dlclose(lib.handle);
+        lib.handle = nullptr;
+        return nullptr;
+    }
+    return &lib;
+}
+
+struct Compiled {
+    std::vector<char> code;
+    std::string lowered;     // mangled kernel name
+};
+
+std::mutex g_mu;
+std::map<std::string, Compiled> g_code;                       // name expression -> code object (process cache)
+std::map<std::string, JitKernel> g_loaded;                    // "dev|name expression" -> loaded function
+int g_compiled = 0;
+
+std::string name_expression(int fmt, int pf, int texels, const StageList& sl)
+{
+    return std::string("rf::stream_kernel<") + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", " + std::to_string(pf) + ", " +
+           std::to_string(texels) + ", " + sl.type_list() + ">";
+}
+
+uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull)
+{
+    for (unsigned char c : s) {
+        h ^= c;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+// optional disk cache (RF_JIT_CACHE_DIR): <dir>/<hash of source + name + options>.{hsaco,name}
+std::string cache_path(const std::string& expr, int waves_per_block)
+{
+    const char* dir = std::getenv("RF_JIT_CACHE_DIR");
+    if (!dir || !*dir) return "";
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), "%016llx", (unsigned long long)fnv1a(expr + "|w" + std::to_string(waves_per_block), fnv1a(kSource)));
+    return std::string(dir) + "/rfjit_" + buf;
+}
+
+bool read_file(const std::string& p, std::vector<char>& out)
+{
+    std::ifstream f(p, std::ios::binary);
+    if (!f) return false;
+    out.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    return !out.empty();
+}
+
+const Compiled* compile(int fmt, int pf, int texels, const StageList& sl, int waves_per_block, std::string& err)
+{
+    const std::string expr = name_expression(fmt, pf, texels, sl);
+    auto it = g_code.find(expr);
+    if (it != g_code.end()) return &it->second;
+    const std::string cpath = cache_path(expr, waves_per_block);
+    if (!cpath.empty()) {
+        Compiled c;
+        std::vector<char> nm;
+        if (read_file(cpath + ".hsaco", c.code) && read_file(cpath + ".name", nm)) {
+            c.lowered.assign(nm.begin(), nm.end());
+            return &(g_code[expr] = std::move(c));
+        }
+    }
+    Rtc* r = rtc();
+    if (!r) { err = "libhiprtc.so could not be loaded"; return nullptr; }
+    RtcProgram prog = nullptr;
+    const std::string wpb = "-DRF_WAVES_PER_BLOCK=" + std::to_string(waves_per_block);
+    int rc = r->CreateProgram(&prog, kSource, "rf_stream_jit.hip", 0, nullptr, nullptr);
+    if (rc != 0) { err = std::string("hiprtcCreateProgram: ") + r->GetErrorString(rc); return nullptr; }
+    // the flags of the ahead-of-time build (Makefile): explicit fmaf only, no contraction -- bit-identical to the oracle
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", wpb.c_str()};
+    rc = r->AddNameExpression(prog, expr.c_str());
+    if (rc == 0) rc = r->CompileProgram(prog, 5, opts);
+    if (rc != 0) {
+        size_t ls = 0;
+        r->GetProgramLogSize(prog, &ls);
+        std::string log(ls, 0);
+        if (ls) r->GetProgramLog(prog, &log[0]);
+        err = std::string("hiprtc: ") + r->GetErrorString(rc) + " compiling " + expr + "\n" + log.substr(0, 2000);
+        r->DestroyProgram(&prog);
+        return nullptr;
+    }
+    Compiled c;
+    size_t cs = 0;
+    r->GetCodeSize(prog, &cs);
+    c.code.resize(cs);
+    r->GetCode(prog, c.code.data());
+    const char* low = nullptr;
+    r->GetLoweredName(prog, expr.c_str(), &low);
+    c.lowered = low ? low : "";
+    r->DestroyProgram(&prog);
+    if (c.lowered.empty() || c.code.empty()) { err = "hiprtc produced no code for " + expr; return nullptr; }
+    ++g_compiled;
+    if (!cpath.empty()) {
+        const char* dir = std::getenv("RF_JIT_CACHE_DIR");
+        (void)mkdir(dir, 0755);
+        const std::string tmp = cpath + ".tmp" + std::to_string((long)getpid());
+        {
+            std::ofstream f(tmp, std::ios::binary);
+            f.write(c.code.data(), (std::streamsize)c.code.size());
+        }
+        (void)std::rename(tmp.c_str(), (cpath + ".hsaco").c_str());
+        std::ofstream f(cpath + ".name", std::ios::binary);
+        f << c.lowered;
+    }
+    return &(g_code[expr] = std::move(c));
+}
+
+std::string loaded_key(const std::string& expr)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return std::to_string(dev) + "|" + expr;
+}
+
+}  // namespace
+
+bool jit_available()
+{
+    if (const char* e = std::getenv("RF_NO_JIT"))
+        if (std::atoi(e) != 0) return false;
+    std::lock_guard<std::mutex> lock(g_mu);
+    return rtc() != nullptr;
+}
+
+int jit_compile_count()
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    return g_compiled;
+}
+
+size_t jit_compile_only(int fmt, int pf, int texels, const StageList& sl, int waves_per_block, std::string& err)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    const Compiled* c = compile(fmt, pf, texels, sl, waves_per_block, err);
+    return c ? c->code.size() : 0;
+}
+
+bool jit_compile(int fmt, int pf, int texels, const StageList& sl, int waves_per_block, std::string& err)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    const std::string expr = name_expression(fmt, pf, texels, sl);
+    const std::string lk = loaded_key(expr);
+    if (g_loaded.count(lk)) return true;
+    const Compiled* c = compile(fmt, pf, texels, sl, waves_per_block, err);
+    if (!c) return false;
+    hipModule_t mod = nullptr;
+    hipError_t e = hipModuleLoadData(&mod, c->code.data());
+    if (e != hipSuccess) { err = std::string("hipModuleLoadData: ") + hipGetErrorString(e); return false; }
+    JitKernel k;
+    e = hipModuleGetFunction(&k.fn, mod, c->lowered.c_str());
+    if (e != hipSuccess) { err = std::string("hipModuleGetFunction(") + c->lowered + "): " + hipGetErrorString(e); return false; }
+    k.texels = texels;
+    (void)hipFuncGetAttribute(&k.vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k.fn);
+    (void)hipFuncGetAttribute(&k.scratch_bytes, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k.fn);
+    int per_cu = 0, cus = 256, dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k.fn, 64 * waves_per_block, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    k.resident_workgroups = per_cu * (cus > 0 ? cus : 256);
+    g_loaded[lk] = k;      // the module stays loaded for the life of the process (kernels are shared by every graph)
+    return true;
+}
+
+const JitKernel* jit_lookup(int fmt, int pf, int texels, const StageList& sl)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_loaded.find(loaded_key(name_expression(fmt, pf, texels, sl)));
+    return it == g_loaded.end() ? nullptr : &it->second;
+}
+
+hipError_t jit_launch(const JitKernel& k, unsigned grid, unsigned block, void* args, size_t size, hipStream_t stream)
+{
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(k.fn, grid, 1, 1, block, 1, 1, 0, stream, nullptr, config);
+}
+
+}  // namespace rf

@@ -1,0 +1,36 @@
+// rf_jit.h -- stream kernels compiled at graph creation (hiprtc): the counterpart of the reference compiling a
+// node's GLSL when the graph is built (src/vulkan/shader.rs:29-93, pipeline.rs:45-88).  The ahead-of-time catalogue
+// (rf_stream.hip) holds the kernels of single nodes and of the BASELINE chains; any other chain of fusable nodes
+// gets its stream_kernel<> instantiation generated from the SAME device source (rf_stream_dev.h, embedded in the
+// library) the first time a graph needs it.  libhiprtc is loaded on first use; without it nothing is compiled and
+// the planner cuts such a chain into catalogue pieces.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "rf_kernels.h"
+
+namespace rf {
+
+struct JitKernel {
+    hipFunction_t fn = nullptr;
+    int texels = 1;
+    int resident_workgroups = 512;    // workgroups of this kernel the chip holds at once (occupancy query)
+    int vgprs = 0, scratch_bytes = 0;
+};
+
+// libhiprtc can be loaded and RF_NO_JIT is not set (host only: no device needed to ask, nor to compile)
+bool jit_available();
+// compile (or fetch from the process / disk cache) and load stream_kernel<Px, pf, texels, stages...> on the current device
+bool jit_compile(int fmt, int pf, int texels, const StageList& sl, int waves_per_block, std::string& err);
+// the loaded kernel, nullptr if jit_compile has not produced it on the current device
+const JitKernel* jit_lookup(int fmt, int pf, int texels, const StageList& sl);
+hipError_t jit_launch(const JitKernel& k, unsigned grid, unsigned block, void* args, size_t size, hipStream_t stream);
+// number of kernels compiled by this process (not served from a cache): measurement / tests
+int jit_compile_count();
+// [host] compile only: code object size, 0 + err on failure (CPU tests: no device needed)
+size_t jit_compile_only(int fmt, int pf, int texels, const StageList& sl, int waves_per_block, std::string& err);
+
+}  // namespace rf

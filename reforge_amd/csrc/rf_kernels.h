@@ -11,12 +11,14 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <string>
+
 namespace rf {
 
 constexpr int kFmtRGBA8   = 0;
 constexpr int kFmtRGBA32F = 1;
 constexpr int kMaxRadius  = 15;     // conv2d up to 31x31, gaussian radius up to 15
-constexpr int kMaxFusedOps = 5;
+constexpr int kMaxFusedOps = 8;     // nodes one streaming launch may cover
 
 inline size_t bytes_per_pixel(int fmt) { return fmt == kFmtRGBA8 ? 4 : 16; }
 
@@ -64,8 +66,28 @@ struct StreamTuning {
     int conv_path = 0;        // RF_CONV_PATH: 0 = register-blocked VALU kernel, 1 = 16x16 LDS tile, 2 = MFMA (K >= 9), 3 = VALU
 };
 
-// true if `ops[0..n)` can run as ONE streaming launch (a fused pipeline)
-bool stream_supported(const Op* ops, int n);
+// Row stages of a streaming launch (rf_stream_dev.h): the run-time description that selects -- or, for a list the
+// ahead-of-time catalogue lacks, GENERATES -- the kernel, and lays out its parameter block.
+enum StageKind : int { ST_NODE_END = 0, ST_HTAP = 1, ST_VTAP = 2, ST_GRADE = 3, ST_CROSS3 = 4 };
+struct StageList {
+    static constexpr int kMax = 3 * kMaxFusedOps;
+    int n = 0;
+    struct { int kind, r; } st[kMax];
+    std::string key() const;          // "H2 V2 E G E C ": catalogue / cache key
+    std::string type_list() const;    // "rf::StHTap<2>, rf::StVTap<2>, ...": the template arguments of stream_kernel
+    int sum_rh() const, sum_rv() const, max_rv() const, taps() const;
+    int vgpr_estimate(int texels) const;
+};
+constexpr size_t kMaxParamBytes = 2048;
+bool ops_to_stages(const Op* ops, int n, StageList& out);
+bool stream_in_catalogue(const StageList& sl);
+bool stream_jit_admissible(const StageList& sl);
+
+// true if `ops[0..n)` can run as ONE streaming launch (a fused pipeline): the catalogue holds the kernel, or
+// (allow_jit) it can be compiled when the graph is created
+bool stream_supported(const Op* ops, int n, bool allow_jit);
+// rf_graph_create: make the kernel of a fused launch available (compiles it if the catalogue lacks it); false + err if it cannot
+bool stream_prepare(int fmt, const Op* ops, int n, int W, int rows, const StreamTuning& tune, std::string& err);
 // horizontal / vertical halo a fused pipeline reads beyond its output
 int  ops_radius(const Op* ops, int n);
 

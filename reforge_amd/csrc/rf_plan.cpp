@@ -327,8 +327,11 @@ static bool is_simple(const PipelineInfo& p) { return p.input_images.size() == 1
 
 // Fuse chains of single-input/single-output nodes whose intermediate image has exactly
 // one producer and one consumer and is not the graph output (no reference counterpart:
-// the reference materialises every edge, pipeline_graph.rs:219-221).
-static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& infos)
+// the reference materialises every edge, pipeline_graph.rs:219-221).  A chain fuses whole when its
+// kernel is in the ahead-of-time catalogue or -- allow_jit -- can be compiled when the graph is
+// created (rf_jit.cpp: any list of passthrough / gaussian / colour_grade / sharpen nodes whose state
+// fits the register file); otherwise it is cut greedily into the longest pieces that do.
+static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& infos, bool allow_jit)
 {
     std::map<std::string, std::vector<std::string>> producers, consumers;
     for (const auto& kv : infos) {
@@ -399,7 +402,7 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
             for (size_t len = std::min(chain.size() - i, (size_t)kMaxFusedOps); len >= 2; --len) {
                 std::vector<Op> ops;
                 for (size_t k = 0; k < len; ++k) ops.push_back(plan.nodes.at(chain[i + k]).to_op(nullptr));
-                if (!stream_supported(ops.data(), (int)len)) continue;
+                if (!stream_supported(ops.data(), (int)len, allow_jit)) continue;
                 if (!side_effects_stay_inside(std::vector<std::string>(chain.begin() + i, chain.begin() + i + len))) continue;
                 best = len;
                 break;
@@ -470,7 +473,7 @@ bool build_plan(const Config& cfg, uint32_t flags, Plan& plan, std::string& err)
 
     if (!(flags & kPlanNoFusion)) {
         size_t before = plan.infos.size();
-        fuse_chains(plan, plan.infos);
+        fuse_chains(plan, plan.infos, !(flags & kPlanNoJit));
         plan.fused = plan.infos.size() != before;
     }
 

@@ -106,6 +106,7 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
 void halo_schedule(std::vector<LaunchDesc>& launches, bool multi_rank, bool exchange, int& need_input, int& ghost);
 
 constexpr uint32_t kPlanNoFusion = 0x2u;   // == RF_GRAPH_NO_FUSION
+constexpr uint32_t kPlanNoJit = 0x10u;     // == RF_GRAPH_NO_JIT: fuse only what the ahead-of-time kernel catalogue holds
 
 bool build_plan(const Config& cfg, uint32_t flags, Plan& out, std::string& err);
 

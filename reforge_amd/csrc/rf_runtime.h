@@ -105,4 +105,5 @@ struct rf_graph {
     uint8_t* d_staging = nullptr;      // RGBA8 staging rows (render.rs:552-564)
     size_t staging_bytes = 0;
     std::vector<std::string> time_names;   // scratch for rf_graph_node_times
+    std::string jit_note;                  // why the graph fell back to catalogue-only fusion ("" if it did not)
 };

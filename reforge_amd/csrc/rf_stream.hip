@@ -25,690 +25,15 @@
 // Numerics: every multiply-add is an explicit fmaf in the oracle's tap order (packed two at a
 // time, each half still a single-rounding fma); this file is compiled with -ffp-contract=off,
 // so results are bit-identical to oracle/rf_oracle.c for finite inputs.
-#include "rf_device.h"
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "rf_stream_dev.h"
+#include "rf_jit.h"
 
 namespace rf {
-
-// ---------------------------------------------------------------------------------
-// Per-lane context of a streaming wave.  A wave's strip is 64*T texels wide: lane l owns the
-// T texels at strip positions l, l + 64, ... (texel j of the lane = position l + 64 j), so every
-// global access and every LDS row access of a wave instruction is 64 consecutive texels -- one
-// fully coalesced 1 KiB segment for rgba32f -- whatever T is.  T = 2 halves the share of halo
-// lanes (2 RH of 128 instead of 2 RH of 64) and the per-row scalar work per texel.
-// ---------------------------------------------------------------------------------
-template <int T> struct Tex { f4 v[T]; };
-
-template <int T> RF_DEV Tex<T> tex_zero()
-{
-    Tex<T> z;
-#pragma unroll
-    for (int j = 0; j < T; ++j) z.v[j] = f4_zero();
-    return z;
-}
-
-template <int T> struct Lane {
-    int lane;   // 0..63
-    int x0;     // frame column of strip position 0 (may be negative: left halo)
-    int W;
-    f4* lds;    // wave-private LDS rows, 64*T texels each
-    RF_DEV int pos(int j) const { return lane + 64 * j; }          // strip position of the lane's texel j
-    RF_DEV int col(int j) const { return x0 + lane + 64 * j; }     // its frame column (may lie outside [0,W) in the halo)
-    // LDS slot holding column clamp(col(j)+dx) -- clamp-to-edge at the frame border, and
-    // kept inside the wave's row for the halo lanes (whose results are discarded)
-    RF_DEV int nbr(int j, int dx) const
-    {
-        int c = min(max(col(j) + dx, 0), W - 1) - x0;
-        return min(max(c, 0), 64 * T - 1);
-    }
-};
-
-// LDS operations of one wave execute in issue order, so a wave-private exchange
-// needs no s_barrier: only the compiler has to be told not to reorder.
-RF_DEV void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// ---------------------------------------------------------------------------------
-// Source: the wave's input rows, streamed global -> LDS by LDS-DMA (global_load_lds_*:
-// no VGPR destination) into a wave-private ring of PF row slots, PF rows ahead.
-//
-// Why hand-written: with compiler-visible loads hipcc drains EVERY load in flight
-// (s_waitcnt vmcnt(0)) at each use, because loads and stores share vmcnt on gfx9 and its
-// wait-count pass treats mixed pending events as out of order.  The DMA is issued from an
-// asm statement (invisible to that pass) and waited for with a COUNTED vmcnt: vector
-// memory operations retire in issue order, and a wave issues exactly T DMAs per input
-// row and T stores per output row, in a fixed program order (see wait_row).
-// ---------------------------------------------------------------------------------
-template <int N> RF_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-template <int T> struct Sink {
-    char* dst;          // address of local row 0
-    ptrdiff_t pitch;    // negative when the wave walks bottom-up
-    unsigned xoff[T];   // byte offset of the lane's texel j in a row
-    bool lane_ok[T];    // the lane owns an output texel at j
-    int row;            // next output row
-    int first_store;    // iteration of the first store, -1 before it (wave-uniform)
-};
-
-template <class Px, int PF, int T> struct Source {
-    static_assert(PF >= 2, "the ring needs at least two slots");
-    static constexpr int SLOTS = PF;
-    static constexpr int SLOT_BYTES = 64 * T * Px::BPP;
-    const char* src[T];   // address of local row 0, already offset by the column of the lane's texel j
-    ptrdiff_t pitch;
-    int a0, n0;           // first source row, number of source rows
-    unsigned lds_base;    // LDS byte address of slot 0 (wave-uniform)
-    const char* ring;     // the same ring through a generic pointer
-
-    RF_DEV const char* slot(int r) const { return ring + (size_t)(r % SLOTS) * SLOT_BYTES; }
-
-    // DMA source row r into slot r % PF.  Program order inside iteration `it` is
-    //   [first stage consumes row it] -> issue(it+PF) -> wait_row(it+1) -> ... -> store
-    // The slot being refilled is the one row `it` was read from (ds_read, one iteration ago).
-    // The DMA's data arrives through the memory path, not through the LDS instruction queue, and
-    // the compiler is free to sink the first USE of that ds_read -- and with it the only
-    // s_waitcnt lgkmcnt that proves the read has executed -- below this asm.  An L2 hit (the
-    // neighbour chunk has just fetched the same halo rows) then overtakes a ds_read still queued
-    // behind other waves' LDS traffic and the stage computes on the NEXT row's texels: wrong
-    // first rows of a walk, seen only on busy chips (tests/test_gpu_fullsize.py::
-    // test_random_graphs_1080p_whole_frame).  Hence the lgkmcnt(0) in front of the DMA: by then
-    // the taps of the row have normally been consumed and the wait is free.
-    RF_DEV void issue(int r) const
-    {
-        const unsigned dst0 = lds_base + (unsigned)(r % SLOTS) * (unsigned)SLOT_BYTES;
-#pragma unroll
-        for (int j = 0; j < T; ++j) {
-            const char* g = src[j] + (ptrdiff_t)(a0 + r) * pitch;
-            const unsigned dst = dst0 + (unsigned)(j * 64 * Px::BPP);
-            unsigned keep;
-            if constexpr (Px::BPP == 16)
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
-            else
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
-        }
-    }
-    RF_DEV void prologue() const
-    {
-        for (int r = 0; r < PF && r < n0; ++r) issue(r);
-    }
-    // Wait until row r has landed, leaving younger operations in flight.  Younger than
-    // row r's DMAs at this point: the DMAs of rows r+1 .. r+PF-1 (when they exist) and, once
-    // the pipeline emits a row per iteration, the stores of the PF-1 iterations in between
-    // (T of each per row).
-    RF_DEV void wait_row(int r, const Sink<T>& k) const
-    {
-        if (n0 - 1 - r >= PF - 1) {
-            if (k.first_store >= 0 && k.first_store <= r - PF) wait_vmcnt<(2 * PF - 2) * T>();
-            else wait_vmcnt<(PF - 1) * T>();
-        } else {
-            wait_vmcnt<0>();
-        }
-    }
-};
-
-// what the first stage is handed each iteration, fetched from the ring one iteration
-// ahead so the LDS latency hides behind the previous row's arithmetic
-template <class Px, int T> struct OwnFeed {      // the lane's own texels
-    typename Px::Raw nxt[T];
-    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane<T>& L)
-    {
-#pragma unroll
-        for (int j = 0; j < T; ++j) nxt[j] = *reinterpret_cast<const typename Px::Raw*>(s.slot(r) + (size_t)L.pos(j) * Px::BPP);
-    }
-    RF_DEV Tex<T> own() const
-    {
-        Tex<T> o;
-#pragma unroll
-        for (int j = 0; j < T; ++j) o.v[j] = Px::decode(nxt[j]);
-        return o;
-    }
-};
-template <int R, int T> struct TapFeed {         // rgba32f: the 2R+1 horizontal taps, straight from the DMA ring
-    f4 t[T][2 * R + 1];
-    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane<T>& L)
-    {
-        const f4* row = reinterpret_cast<const f4*>(s.slot(r));
-#pragma unroll
-        for (int j = 0; j < T; ++j) {
-#pragma unroll
-            for (int i = -R; i <= R; ++i) t[j][i + R] = row[L.nbr(j, i)];
-        }
-    }
-    RF_DEV Tex<T> own() const
-    {
-        Tex<T> o;
-#pragma unroll
-        for (int j = 0; j < T; ++j) o.v[j] = t[j][R];
-        return o;
-    }
-};
-
-// ---------------------------------------------------------------------------------
-// Row stages.  advance() is called once per row entering the stage:
-//   v      the row's texels for this lane (undefined when !real)
-//   real   a new input row; false = the newest row repeated (clamp-to-edge below the frame)
-//   first  the stage's first row: it primes the whole window (clamp-to-edge above the frame,
-//          or rows that are shifted out again before anything is emitted)
-//   emit   the window's centre row is wanted downstream (wave-uniform, from the schedule)
-// ---------------------------------------------------------------------------------
-struct NoState {};
-
-// horizontal taps of the separable gaussian: sum_i w[|i|] * in[x+i], ascending i
-template <int R> struct StHTap {
-    static constexpr int RV = 0, RH = R, LDS_ROWS = (R > 0) ? 1 : 0;
-    struct Params { v2f w[R + 1]; };   // each weight twice: the operand pair of a packed fma (see fma4)
-    template <class Px, int T> using State = NoState;
-    // as the FIRST stage of an rgba32f pipeline the taps come straight from the DMA ring
-    // (up to radius 7: beyond that 2R+1 prefetched taps crowd the vertical window out of the register
-    // file -- radius 10 at 4K: 209 us with the prefetch, 119 us through the LDS exchange)
-    template <class Px, int T> using Feed = typename std::conditional<(Px::QUANT || R > 7 || T > 1), OwnFeed<Px, T>, TapFeed<R, T>>::type;
-    template <int T> RF_DEV static Tex<T> from_taps(const Params& p, const TapFeed<R, T>& f)
-    {
-        Tex<T> o;
-#pragma unroll
-        for (int j = 0; j < T; ++j) {
-            f4 acc = f4_zero();
-#pragma unroll
-            for (int i = -R; i <= R; ++i) acc = fma4(p.w[i < 0 ? -i : i], f.t[j][i + R], acc);
-            o.v[j] = acc;
-        }
-        return o;
-    }
-    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, NoState&, const Lane<T>& L, f4* lds, const Tex<T>& v, bool, bool, bool, Tex<T>& out)
-    {
-        if constexpr (R > 0) {
-#pragma unroll
-            for (int j = 0; j < T; ++j) lds[L.pos(j)] = v.v[j];
-            wave_sync();
-        }
-#pragma unroll
-        for (int j = 0; j < T; ++j) {
-            f4 acc = f4_zero();
-#pragma unroll
-            for (int i = -R; i <= R; ++i) {
-                f4 t = (i == 0) ? v.v[j] : lds[L.nbr(j, i)];
-                acc = fma4(p.w[i < 0 ? -i : i], t, acc);
-            }
-            out.v[j] = acc;
-        }
-    }
-};
-
-// vertical taps: sum_j w[|j|] * tmp[y+j], ascending j.
-//
-// Walking top-down the rows arrive in ascending order, which IS the tap order of every output row:
-// the stage then keeps one running sum per pending output row instead of a window of input rows
-// (SCATTER form).  Row r contributes  acc[y] = fma(w|r-y|, tmp[r], acc[y])  to the 2R+1 outputs it
-// reaches; the oldest of them, y = r - R, takes its last tap and is emitted.  Each output still
-// sums its taps in ascending j from 0 -- bit-identical to the window form -- but the slide of the
-// pending rows is done by the fma itself (destination = the slot one up from its addend), where a
-// window of rows has to be shifted with moves: 2 x 2R v_mov_b64 per row and texel.
-// Walking bottom-up (REV) the rows arrive in DESCENDING order, so the sums cannot be formed on
-// arrival; those walks keep the window of rows (GATHER form).
-template <int R> struct StVTap {
-    static constexpr int RV = R, RH = 0, LDS_ROWS = 0;
-    struct Params { v2f w[R + 1]; };
-    // scatter: acc[k] = running sum of output row (newest - R + 1 + k), k = 0 .. 2R-1; last = newest real row (bottom-edge flush)
-    // gather:  win[i] = input row (newest - 2R + i)
-    template <class Px, int T> struct State { Tex<T> win[2 * R + 1]; };
-    template <class Px, int T> using Feed = OwnFeed<Px, T>;
-
-    // running sums 0 .. 2R-2 slide down by one while taking their tap (compile-time recursion: every weight
-    // index is a constant for the front end already, so the parameter block stays in scalar registers)
-    template <int K, int T> RF_DEV static void slide(const Params& p, Tex<T>* acc, const f4& v, int t)
-    {
-        if constexpr (K + 1 < 2 * R) {
-            constexpr int j = R - 1 - K;                                       // row newest-R+1+K takes tap j
-            acc[K].v[t] = fma4(p.w[j < 0 ? -j : j], v, acc[K + 1].v[t]);
-            slide<K + 1, T>(p, acc, v, t);
-        }
-    }
-    template <int T> RF_DEV static void scatter_row(const Params& p, Tex<T>* acc, const Tex<T>& v, Tex<T>& out)
-    {
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            out.v[t] = fma4(p.w[R], v.v[t], acc[0].v[t]);                       // j = +R: the last tap of row newest-R
-            slide<0, T>(p, acc, v.v[t], t);
-            acc[2 * R - 1].v[t] = fma4(p.w[R], v.v[t], f4_zero());              // j = -R: the first tap of row newest+R
-        }
-    }
-    // KEEP: the row may be the stage's last real one (tail and generic loop phases): remember it for the flush
-    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, State<Px, T>& s, const Lane<T>&, f4*, const Tex<T>& v, bool real, bool first, bool emit, Tex<T>& out)
-    {
-        if constexpr (R == 0) {
-            out = tex_zero<T>();
-#pragma unroll
-            for (int t = 0; t < T; ++t) out.v[t] = fma4(p.w[0], v.v[t], f4_zero());
-        } else if constexpr (!REV) {
-            // s.win[0 .. 2R-1] are the running sums, s.win[2R] the newest real row
-            if (first) {
-                // clamp-to-edge above the stage's first row: as if 2R more copies of it had arrived before
-#pragma unroll
-                for (int k = 0; k < 2 * R; ++k) s.win[k] = tex_zero<T>();
-                Tex<T> dummy;
-#pragma unroll
-                for (int n = 0; n < 2 * R; ++n) scatter_row<T>(p, s.win, v, dummy);
-            }
-            Tex<T> in;                        // by value: a reference picked between two objects would pin both to memory
-#pragma unroll
-            for (int t = 0; t < T; ++t) in.v[t] = real ? v.v[t] : s.win[2 * R].v[t];
-            Tex<T> o;
-            scatter_row<T>(p, s.win, in, o);
-            if (emit) out = o;
-            if constexpr (KEEP) {
-                if (real) s.win[2 * R] = v;
-            }
-        } else {
-            if (first) {                     // the first row primes the whole window (it is always a real row)
-#pragma unroll
-                for (int i = 0; i <= 2 * R; ++i) s.win[i] = v;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 2 * R; ++i) s.win[i] = s.win[i + 1];
-                if (real) s.win[2 * R] = v;
-            }
-            if (emit) {
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    f4 acc = f4_zero();
-#pragma unroll
-                    // taps are accumulated in ascending FRAME row order; walking bottom-up the window
-                    // holds the rows the other way round
-                    for (int j = -R; j <= R; ++j) acc = fma4(p.w[j < 0 ? -j : j], s.win[R - j].v[t], acc);
-                    out.v[t] = acc;
-                }
-            }
-        }
-    }
-};
-
-// colour grade point op
-struct StGrade {
-    static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
-    struct Params { float slope, offset, saturation; };
-    template <class Px, int T> using State = NoState;
-    template <class Px, int T> using Feed = OwnFeed<Px, T>;
-    RF_DEV static float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
-    RF_DEV static f4 grade(const Params& p, f4 c)
-    {
-        float tr = fmaf(c.x, p.slope, p.offset);
-        float tg = fmaf(c.y, p.slope, p.offset);
-        float tb = fmaf(c.z, p.slope, p.offset);
-        float luma = fmaf(0.0722f, tb, fmaf(0.7152f, tg, 0.2126f * tr));
-        return make_float4(clamp01(fmaf(p.saturation, tr - luma, luma)), clamp01(fmaf(p.saturation, tg - luma, luma)),
-                           clamp01(fmaf(p.saturation, tb - luma, luma)), c.w);
-    }
-    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, NoState&, const Lane<T>&, f4*, const Tex<T>& c, bool, bool, bool, Tex<T>& out)
-    {
-#pragma unroll
-        for (int j = 0; j < T; ++j) out.v[j] = grade(p, c.v[j]);
-    }
-};
-
-// 3x3 sharpen cross [0,s,0; s,c,s; 0,s,0], taps in ascending (y outer, x inner) order.
-// The horizontal neighbours of a row are fetched through LDS when the row ARRIVES and
-// are first used one iteration later, when that row is the centre: the LDS round trip
-// hides behind a whole iteration instead of stalling the wave.
-struct StCross3 {
-    static constexpr int RV = 1, RH = 1, LDS_ROWS = 1;
-    struct Params { float wc, ws; };
-    template <class Px, int T> struct State { Tex<T> n, c, cw, ce; };   // rows y-1, y and y's left/right neighbours
-    template <class Px, int T> using Feed = OwnFeed<Px, T>;
-    template <int T> RF_DEV static void exchange(const Lane<T>& L, f4* lds, const Tex<T>& v, Tex<T>& w, Tex<T>& e)
-    {
-#pragma unroll
-        for (int j = 0; j < T; ++j) lds[L.pos(j)] = v.v[j];
-        wave_sync();
-#pragma unroll
-        for (int j = 0; j < T; ++j) {
-            w.v[j] = lds[L.nbr(j, -1)];
-            e.v[j] = lds[L.nbr(j, +1)];
-        }
-    }
-    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, State<Px, T>& s, const Lane<T>& L, f4* lds, const Tex<T>& v, bool real, bool first, bool emit, Tex<T>& out)
-    {
-        if (first) {                     // window = [v, v, (next row)]
-            s.n = v;
-            s.c = v;
-            exchange(L, lds, v, s.cw, s.ce);
-            return;
-        }
-        const Tex<T> below = real ? v : s.c;
-        if (emit) {
-#pragma unroll
-            for (int j = 0; j < T; ++j) {
-                f4 acc = f4_zero();
-                // frame order N, W, C, E, S: walking bottom-up the older row is the one BELOW
-                acc = fma4(p.ws, REV ? below.v[j] : s.n.v[j], acc);
-                acc = fma4(p.ws, s.cw.v[j], acc);
-                acc = fma4(p.wc, s.c.v[j], acc);
-                acc = fma4(p.ws, s.ce.v[j], acc);
-                acc = fma4(p.ws, REV ? s.n.v[j] : below.v[j], acc);
-                out.v[j] = acc;
-            }
-        }
-        s.n = s.c;
-        if (real) {
-            s.c = v;
-            exchange(L, lds, v, s.cw, s.ce);
-        }
-    }
-};
-
-// node boundary inside a fused chain: the store + load the unfused graph performs
-// (UNORM8 re-quantisation for rgba8, nothing for rgba32f)
-struct StNodeEnd {
-    static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
-    struct Params {};
-    template <class Px, int T> using State = NoState;
-    template <class Px, int T> using Feed = OwnFeed<Px, T>;
-    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params&, NoState&, const Lane<T>&, f4*, const Tex<T>& v, bool, bool, bool, Tex<T>& out)
-    {
-#pragma unroll
-        for (int j = 0; j < T; ++j) out.v[j] = Px::requant(v.v[j]);
-    }
-};
-
-// ---------------------------------------------------------------------------------
-// Parameter pack (kernel argument) and the stage chain (per-wave state)
-// ---------------------------------------------------------------------------------
-template <class... S> struct ParamPack;
-template <> struct ParamPack<> {};
-template <class S, class... Rest> struct ParamPack<S, Rest...> {
-    typename S::Params p;
-    ParamPack<Rest...> rest;
-};
-
-template <class... S> struct SumRH { static constexpr int value = 0; };
-template <class S, class... Rest> struct SumRH<S, Rest...> { static constexpr int value = S::RH + SumRH<Rest...>::value; };
-template <class... S> struct SumLDS { static constexpr int value = 0; };
-template <class S, class... Rest> struct SumLDS<S, Rest...> { static constexpr int value = S::LDS_ROWS + SumLDS<Rest...>::value; };
-template <class... S> struct SumRV { static constexpr int value = 0; };
-template <class S, class... Rest> struct SumRV<S, Rest...> { static constexpr int value = S::RV + SumRV<Rest...>::value; };
-template <class S, class...> struct FirstOf { typedef S type; };
-
-// REV: the wave walks its chunk bottom-up (rows are addressed with a negated pitch, so the
-// schedule below is unchanged); stages whose tap order depends on the row direction read it.
-template <class Px, bool REV, int T, int LdsIdx, class... S> struct Chain;
-
-// end of the chain: the store
-template <class Px, bool REV, int T, int LdsIdx> struct Chain<Px, REV, T, LdsIdx> {
-    RF_DEV void plan_backward(int oa, int ob, int, int, int& in_a, int& in_b) { in_a = oa; in_b = ob; }
-    RF_DEV int plan_forward(int tprev) { return tprev; }
-    template <int MODE> RF_DEV void step(bool has, const Tex<T>& v, int it, const Lane<T>&, Sink<T>& k, const ParamPack<>&)
-    {
-        constexpr bool STEADY = MODE != 0;
-        if (STEADY || has) {
-            // the row's values are computed HERE, under the full exec mask: left to itself hipcc sinks the
-            // last stage's arithmetic into the exec-masked store block and schedules it there as one
-            // serial chain per half texel with an s_nop between dependent packed fmas
-#pragma unroll
-            for (int j = 0; j < T; ++j) asm volatile("" ::"v"(v.v[j].x), "v"(v.v[j].y), "v"(v.v[j].z), "v"(v.v[j].w));
-            // exactly T vector-memory instructions per emitted row: Source::wait_row counts on it
-            // (every one of them has at least one active lane: see the strip placement in stream_kernel)
-#pragma unroll
-            for (int j = 0; j < T; ++j)
-                if (k.lane_ok[j]) Px::store(k.dst + (ptrdiff_t)k.row * k.pitch, k.xoff[j], v.v[j]);
-            k.row += 1;
-            if (!STEADY && k.first_store < 0) k.first_store = it;
-        }
-    }
-};
-
-template <class Px, bool REV, int T, int LdsIdx, class S, class... Rest> struct Chain<Px, REV, T, LdsIdx, S, Rest...> {
-    typename S::template State<Px, T> st;
-    // wave-uniform schedule
-    int a;        // first input row
-    int oa;       // first output row
-    int flush;    // replications of the last input row (frame bottom edge)
-    int tprev;    // iteration of the upstream stage's last emission
-    int cnt;      // input rows consumed
-    Chain<Px, REV, T, LdsIdx + S::LDS_ROWS, Rest...> next;
-
-    // given the rows the LAST stage must emit, derive what each stage must emit/consume
-    RF_DEV void plan_backward(int oa_last, int ob_last, int lo, int hi, int& in_a, int& in_b)
-    {
-        int need_a, need_b;
-        next.plan_backward(oa_last, ob_last, lo, hi, need_a, need_b);
-        oa = need_a;
-        a = max(lo, need_a - S::RV);
-        int b = min(hi, need_b + S::RV);
-        flush = need_b + S::RV - b;
-        cnt = 0;
-        in_a = a;
-        in_b = b;
-    }
-    RF_DEV int plan_forward(int tp)
-    {
-        tprev = tp;
-        return next.plan_forward(tp + flush);
-    }
-    RF_DEV f4* lds_of(const Lane<T>& L) const { return L.lds + LdsIdx * 64 * T; }
-    // A row (or a flush tick) enters this stage.  STEADY = every stage receives a real row,
-    // is past its first row and emits: the schedule tests fold away at compile time.
-    template <int MODE> RF_DEV void step(bool has_prev, const Tex<T>& v, int it, const Lane<T>& L, Sink<T>& k, const ParamPack<S, Rest...>& P)
-    {
-        constexpr bool STEADY = MODE != 0;
-        constexpr bool KEEP = MODE == 0 || MODE == 3;   // phases that may hold a stage's last real row
-        bool has = false;
-        Tex<T> out = tex_zero<T>();
-        if constexpr (STEADY) {
-            S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), v, true, false, true, out);
-            cnt += 1;
-            has = true;
-        } else if constexpr (S::RV == 0) {
-            if (has_prev) {              // row-local stage: one row in, one row out, never flushed
-                S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), v, true, cnt == 0, true, out);
-                cnt += 1;
-                has = true;
-            }
-        } else {
-            const bool flushing = !has_prev && it > tprev && it <= tprev + flush;
-            if (has_prev || flushing) {
-                has = (a + cnt - S::RV) >= oa;
-                S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), v, has_prev, cnt == 0, has, out);
-                cnt += 1;
-            }
-        }
-        next.template step<MODE>(has, out, it, L, k, P.rest);
-    }
-    // first stage: the row comes from the source feed; once it is consumed its ring slot is
-    // refilled and the NEXT row's values are fetched into registers
-    // MODE 0: generic (schedule tests).  Modes 1-3 are branch-free: every stage takes a real row
-    // and emits one.  1 = rows still being issued, stores of the last PF iterations not all
-    // there yet (wait on the loads alone); 2 = the steady state; 3 = every row issued already
-    // (the last PF source rows): nothing to issue, plain wait.
-    template <int MODE, class Feed, class Src>
-    RF_DEV void step_first(bool has0, Feed& feed, const Src& src, int it, const Lane<T>& L, Sink<T>& k, const ParamPack<S, Rest...>& P)
-    {
-        constexpr bool STEADY = MODE != 0;
-        constexpr bool KEEP = MODE == 0 || MODE == 3;
-        bool has = false;
-        Tex<T> out = tex_zero<T>();
-        if constexpr (STEADY) {
-            if constexpr (std::is_same<Feed, OwnFeed<Px, T>>::value)
-                S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), feed.own(), true, false, true, out);
-            else
-                out = S::template from_taps<T>(P.p, feed);
-            cnt += 1;
-            has = true;
-            if constexpr (MODE == 3) {
-                if (it + 1 < src.n0) {
-                    wait_vmcnt<0>();
-                    feed.fetch(src, it + 1, L);
-                }
-            } else {
-                src.issue(it + Src::SLOTS);
-                if constexpr (MODE == 1) wait_vmcnt<(Src::SLOTS - 1) * T>();
-                else wait_vmcnt<(2 * Src::SLOTS - 2) * T>();
-                feed.fetch(src, it + 1, L);
-            }
-        } else {
-            if constexpr (S::RV == 0) {
-                if (has0) {
-                    if constexpr (std::is_same<Feed, OwnFeed<Px, T>>::value)
-                        S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), feed.own(), true, cnt == 0, true, out);
-                    else
-                        out = S::template from_taps<T>(P.p, feed);
-                    cnt += 1;
-                    has = true;
-                }
-            } else {
-                const bool flushing = !has0 && it > tprev && it <= tprev + flush;
-                if (has0 || flushing) {
-                    has = (a + cnt - S::RV) >= oa;
-                    S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), feed.own(), has0, cnt == 0, has, out);
-                    cnt += 1;
-                }
-            }
-            if (has0) {
-                if (it + Src::SLOTS < src.n0) src.issue(it + Src::SLOTS);
-                if (it + 1 < src.n0) {
-                    src.wait_row(it + 1, k);
-                    feed.fetch(src, it + 1, L);
-                }
-            }
-        }
-        next.template step<MODE>(has, out, it, L, k, P.rest);
-    }
-};
-
-template <class... S> struct StreamArgs {
-    const char* src;
-    size_t src_pitch;
-    char* dst;
-    size_t dst_pitch;
-    int W, row_lo, row_hi, y0, y1, rows_per_chunk, n_strips;
-    int n_work;   // workgroups with work = strip groups x chunks (the grid is padded to a multiple of 8)
-    int alternate;   // odd chunks walk bottom-up (halo rows shared through L2)
-    ParamPack<S...> params;
-};
-
-#ifndef RF_WAVES_PER_BLOCK
-#define RF_WAVES_PER_BLOCK 4
-#endif
-constexpr int kWavesPerBlock = RF_WAVES_PER_BLOCK;
-
-// One wave's walk over rows [y0, y1) of its strip.  REV = bottom-up: rows are addressed with
-// negated pitches and mirrored bounds, so the schedule code sees an ordinary top-down walk.
-template <class Px, int PF, int T, bool REV, class... S>
-RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane<T>& L, int wave, char* ring_wave, unsigned ring_lds, int y0, int y1)
-{
-    constexpr int RH = SumRH<S...>::value;
-    typedef Source<Px, PF, T> Src;
-    typedef typename FirstOf<S...>::type::template Feed<Px, T> Feed;
-    (void)wave;
-
-    // the walk's own row coordinate v: v = y top-down, v = -y bottom-up
-    const int v0 = REV ? -(y1 - 1) : y0, v1 = REV ? -y0 + 1 : y1;
-    const int lo = REV ? -A.row_hi : A.row_lo, hi = REV ? -A.row_lo : A.row_hi;
-
-    Sink<T> k;
-    k.dst = A.dst;
-    k.pitch = REV ? -(ptrdiff_t)A.dst_pitch : (ptrdiff_t)A.dst_pitch;
-#pragma unroll
-    for (int j = 0; j < T; ++j) {
-        k.xoff[j] = (unsigned)min(max(L.col(j), 0), A.W - 1) * (unsigned)Px::BPP;
-        k.lane_ok[j] = (L.pos(j) >= RH) && (L.pos(j) < 64 * T - RH) && (L.col(j) < A.W);
-    }
-    k.row = v0;
-    k.first_store = -1;
-
-    Chain<Px, REV, T, 0, S...> chain;
-    Src src;
-    int b0;
-    chain.plan_backward(v0, v1 - 1, lo, hi, src.a0, b0);
-    src.n0 = b0 - src.a0 + 1;                        // source rows
-    const int total = chain.plan_forward(src.n0 - 1) + 1;
-
-    // source: rows a0..b0, column clamp(x)
-#pragma unroll
-    for (int j = 0; j < T; ++j) src.src[j] = A.src + k.xoff[j];
-    src.pitch = REV ? -(ptrdiff_t)A.src_pitch : (ptrdiff_t)A.src_pitch;
-    src.ring = ring_wave;
-    src.lds_base = ring_lds;
-    src.prologue();
-    Feed feed;
-    src.wait_row(0, k);
-    feed.fetch(src, 0, L);
-
-    // Phases: the generic loop (per-stage schedule tests) until the pipeline has emitted its
-    // first row -- from then on every stage takes a real row and emits one for as long as
-    // source rows arrive, and the branch-free modes run: 1 while the stores of the last PF
-    // iterations are not all there yet, 2 the steady state, 3 the last PF source rows (nothing
-    // left to issue) -- and the generic loop again for the bottom-edge flush.
-    int it = 0;
-    while (it < total && k.first_store < 0) {
-        chain.template step_first<0>(it < src.n0, feed, src, it, L, k, A.params);
-        ++it;
-    }
-    if (k.first_store >= 0) {
-        const int steady_end = src.n0 - PF;                      // iterations with a row left to issue
-        const int warm_end = min(k.first_store + PF, steady_end);
-        for (; it < warm_end; ++it) chain.template step_first<1>(true, feed, src, it, L, k, A.params);
-        for (; it < steady_end; ++it) chain.template step_first<2>(true, feed, src, it, L, k, A.params);
-        for (; it < src.n0; ++it) chain.template step_first<3>(true, feed, src, it, L, k, A.params);
-    }
-    for (; it < total; ++it) chain.template step_first<0>(it < src.n0, feed, src, it, L, k, A.params);
-}
-
-template <class Px, int PF, int T, class... S>
-__global__ __launch_bounds__(64 * kWavesPerBlock, T > 1 ? 2 : 1) void stream_kernel(const StreamArgs<S...> A)
-{
-    constexpr int RH = SumRH<S...>::value;
-    constexpr int VALID = 64 * T - 2 * RH;
-    constexpr int LDSR = SumLDS<S...>::value;
-    typedef Source<Px, PF, T> Src;
-    __shared__ f4 smem[kWavesPerBlock][(LDSR > 0 ? LDSR : 1) * 64 * T];
-    __shared__ __attribute__((aligned(16))) char ring[kWavesPerBlock][Src::SLOTS * Src::SLOT_BYTES];
-
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // XCD-aware block order (guide T1): blocks are dealt round-robin over the 8 XCDs, so block
-    // b and b+8 share an L2.  Give each XCD a CONTIGUOUS range of work items (strip groups
-    // fastest, then chunks): workgroups that share halo columns or halo rows then share an L2.
-    // Speed only -- any placement gives the same result.
-    const int gx = (A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int per_xcd = (int)gridDim.x >> 3;
-    const int q = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (q >= A.n_work) return;
-    const int strip = (q % gx) * kWavesPerBlock + wave;
-    if (strip >= A.n_strips) return;                 // wave-uniform; no barriers below
-    const int chunk = q / gx;
-    const int y0 = A.y0 + chunk * A.rows_per_chunk;
-    const int y1 = min(y0 + A.rows_per_chunk, A.y1);
-    if (y0 >= y1) return;
-
-    Lane<T> L;
-    L.lane = (int)(threadIdx.x & 63);
-    L.x0 = strip * VALID - RH;
-    // T > 1: every one of the T stores of a row must have an active lane (the counted vmcnt waits
-    // assume T stores are really issued; hipcc branches around a store whose exec mask is empty).
-    // The last strip is therefore moved left until it ends at the frame edge -- it recomputes a
-    // few columns of its neighbour and writes the same values (the host launches T > 1 only when
-    // W >= 64 T and the launch is not in place).
-    if constexpr (T > 1) {
-        if (L.x0 + 64 * T - RH > A.W) L.x0 = A.W - 64 * T + RH;
-    }
-    L.W = A.W;
-    L.lds = smem[wave];
-    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(
-        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&ring[0][0]) + (unsigned)wave * (unsigned)(Src::SLOTS * Src::SLOT_BYTES));
-
-    // Odd chunks walk bottom-up: a chunk and its neighbour then read the halo rows they
-    // share at the same moment (both at their start, or both at their end), so the second
-    // read is served by the XCD's L2 instead of the fabric.  Stencil-free pipelines have no
-    // halo and always walk top-down.
-    constexpr bool kHasHalo = SumRV<S...>::value > 0;
-    if (kHasHalo && A.alternate && (chunk & 1))
-        stream_wave<Px, PF, T, true, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
-    else
-        stream_wave<Px, PF, T, false, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
-}
 
 // ---------------------------------------------------------------------------------
 // Host side: op list -> stage list -> kernel instantiation
@@ -757,6 +82,172 @@ static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo
     return rpc;
 }
 
+// ---------------------------------------------------------------------------------
+// Stage lists at run time.  A launch is described by the list of row stages its nodes contribute
+// (ops_to_stages): that list selects the kernel -- from the ahead-of-time CATALOGUE when it holds
+// the instantiation, otherwise compiled at graph creation (rf_jit.cpp) -- and lays out the
+// parameter block, which the host assembles as bytes (ParamPack in rf_stream_dev.h).
+// ---------------------------------------------------------------------------------
+std::string StageList::key() const
+{
+    std::string k;
+    for (int i = 0; i < n; ++i) {
+        switch (st[i].kind) {
+            case ST_HTAP: k += "H" + std::to_string(st[i].r); break;
+            case ST_VTAP: k += "V" + std::to_string(st[i].r); break;
+            case ST_GRADE: k += "G"; break;
+            case ST_CROSS3: k += "C"; break;
+            default: k += "E"; break;
+        }
+        k += ' ';
+    }
+    return k;
+}
+
+std::string StageList::type_list() const
+{
+    std::string t;
+    for (int i = 0; i < n; ++i) {
+        switch (st[i].kind) {
+            case ST_HTAP: t += "rf::StHTap<" + std::to_string(st[i].r) + ">"; break;
+            case ST_VTAP: t += "rf::StVTap<" + std::to_string(st[i].r) + ">"; break;
+            case ST_GRADE: t += "rf::StGrade"; break;
+            case ST_CROSS3: t += "rf::StCross3"; break;
+            default: t += "rf::StNodeEnd"; break;
+        }
+        if (i + 1 < n) t += ", ";
+    }
+    return t;
+}
+
+int StageList::sum_rh() const { int v = 0; for (int i = 0; i < n; ++i) v += (st[i].kind == ST_HTAP) ? st[i].r : (st[i].kind == ST_CROSS3 ? 1 : 0); return v; }
+int StageList::sum_rv() const { int v = 0; for (int i = 0; i < n; ++i) v += (st[i].kind == ST_VTAP) ? st[i].r : (st[i].kind == ST_CROSS3 ? 1 : 0); return v; }
+int StageList::max_rv() const { int v = 0; for (int i = 0; i < n; ++i) v = std::max(v, (st[i].kind == ST_VTAP) ? st[i].r : (st[i].kind == ST_CROSS3 ? 1 : 0)); return v; }
+int StageList::taps() const
+{
+    int v = 0;
+    for (int i = 0; i < n; ++i) v += (st[i].kind == ST_HTAP || st[i].kind == ST_VTAP) ? 2 * st[i].r + 1 : (st[i].kind == ST_CROSS3 ? 5 : (st[i].kind == ST_GRADE ? 3 : 0));
+    return v;
+}
+// registers the pipeline's loop-carried state takes (vertical windows / running sums, the sharpen rows, the first
+// stage's prefetched taps) + a fixed allowance: what decides whether a list may be fused at all
+int StageList::vgpr_estimate(int texels) const
+{
+    int v = 56;
+    for (int i = 0; i < n; ++i) {
+        if (st[i].kind == ST_VTAP) v += 4 * texels * (2 * st[i].r + 1);
+        if (st[i].kind == ST_CROSS3) v += 16 * texels;
+        if (st[i].kind == ST_HTAP) v += (i == 0 && texels == 1 && st[i].r <= 7) ? 4 * (2 * st[i].r + 1) : 0;
+    }
+    int transient = 0;
+    for (int i = 0; i < n; ++i)
+        if (st[i].kind == ST_HTAP) transient = std::max(transient, 4 * texels * 2 * st[i].r);
+    return v + transient / 2;
+}
+
+bool ops_to_stages(const Op* ops, int n, StageList& out)
+{
+    out.n = 0;
+    auto push = [&](int kind, int r) {
+        if (out.n >= StageList::kMax) return false;
+        out.st[out.n].kind = kind;
+        out.st[out.n].r = r;
+        ++out.n;
+        return true;
+    };
+    for (int i = 0; i < n; ++i) {
+        // node boundary inside a chain: the store + load the unfused graph performs.  A passthrough node IS such a
+        // boundary and nothing else; two boundaries in a row are one (re-quantising twice changes nothing).
+        // (a LEADING passthrough is the load itself: no stage at all)
+        if (i > 0 && out.n > 0 && out.st[out.n - 1].kind != ST_NODE_END)
+            if (!push(ST_NODE_END, 0)) return false;
+        switch (ops[i].kind) {
+            case OP_PASSTHROUGH: break;
+            case OP_GAUSSIAN:
+                if (ops[i].radius < 0 || ops[i].radius > kMaxRadius) return false;
+                if (!push(ST_HTAP, ops[i].radius) || !push(ST_VTAP, ops[i].radius)) return false;
+                break;
+            case OP_GRADE: if (!push(ST_GRADE, 0)) return false; break;
+            case OP_SHARPEN: if (!push(ST_CROSS3, 0)) return false; break;
+            default: return false;     // conv2d, combination: kernels of their own
+        }
+    }
+    if (out.n == 0) return push(ST_NODE_END, 0);      // a chain of passthroughs: the copy kernel
+    if (out.st[out.n - 1].kind == ST_NODE_END && out.n > 1) --out.n;   // a trailing boundary is the final store itself
+    return true;
+}
+
+// parameter block of a stage list from the ops of its nodes, as bytes (layout: ParamPack, rf_stream_dev.h)
+static size_t param_bytes(const StageList& sl, const Op* ops, int n_ops, unsigned char* buf, size_t cap)
+{
+    size_t off = 0;
+    int node = 0;
+    // stage -> node: a boundary stage closes a node; leading passthrough nodes own no stage at all
+    auto next_real_node = [&](int from) {
+        while (from < n_ops && ops[from].kind == OP_PASSTHROUGH) ++from;
+        return from;
+    };
+    node = next_real_node(0);
+    std::memset(buf, 0, cap);
+    for (int i = 0; i < sl.n; ++i) {
+        const int kind = sl.st[i].kind, r = sl.st[i].r;
+        size_t size = 8;
+        if (kind == ST_HTAP || kind == ST_VTAP) size = 8 * (size_t)(r + 1);
+        else if (kind == ST_GRADE) size = 16;
+        if (off + size + 8 > cap) return 0;
+        unsigned char* p = buf + off;
+        const Op* op = node < n_ops ? &ops[node] : nullptr;
+        if ((kind == ST_HTAP || kind == ST_VTAP) && op) {
+            for (int k = 0; k <= r; ++k) {
+                const float pair[2] = {op->w[k], op->w[k]};
+                std::memcpy(p + 8 * k, pair, 8);
+            }
+        } else if (kind == ST_GRADE && op) {
+            const float g[3] = {op->slope, op->offset, op->saturation};
+            std::memcpy(p, g, 12);
+        } else if (kind == ST_CROSS3 && op) {
+            const float c[2] = {op->wc, op->ws};
+            std::memcpy(p, c, 8);
+        }
+        off += size;
+        if (kind == ST_NODE_END) node = next_real_node(node + 1);
+    }
+    return off + 8;     // the closing empty slot
+}
+
+// ---------------------------------------------------------------------------------
+// Launch geometry shared by catalogue and run-time compiled kernels
+// ---------------------------------------------------------------------------------
+struct LaunchShape {
+    StreamHdr hdr;
+    unsigned grid;
+};
+
+static bool launch_shape(Image src, Image dst, const Geom& g, const StreamTuning& tune, int texels, int rh, int halo_rows, int bpp,
+                         int resident, LaunchShape& out)
+{
+    const int VALID = 64 * texels - 2 * rh;
+    StreamHdr& A = out.hdr;
+    A.src = static_cast<const char*>(src.base);
+    A.src_pitch = src.pitch;
+    A.dst = static_cast<char*>(dst.base);
+    A.dst_pitch = dst.pitch;
+    A.W = g.W;
+    A.row_lo = g.row_lo;
+    A.row_hi = g.row_hi;
+    A.y0 = g.y0;
+    A.y1 = g.y1;
+    A.n_strips = (g.W + VALID - 1) / VALID;
+    const int rows = g.y1 - g.y0;
+    if (rows <= 0 || g.W <= 0) return false;
+    const int groups = (A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock;
+    A.rows_per_chunk = choose_rows_per_chunk(rows, groups, resident, halo_rows, bpp, tune, tune.walk == 2);
+    A.n_work = groups * ((rows + A.rows_per_chunk - 1) / A.rows_per_chunk);
+    A.alternate = tune.walk == 2 ? 0 : 1;
+    out.grid = (unsigned)((A.n_work + 7) / 8 * 8);   // 1-D, a multiple of the 8 XCDs (see the kernel's block order)
+    return true;
+}
+
 // workgroups of this kernel the whole chip holds at once
 template <class Px, int PF, int T, class... S> static int resident_workgroups()
 {
@@ -773,146 +264,75 @@ template <class Px, int PF, int T, class... S> static int resident_workgroups()
     return slots;
 }
 
+// one catalogue entry: stream_kernel<Px, PF, T, S...> behind a type-erased launcher
 template <class Px, int PF, int T, class... S>
-static hipError_t launch_stream_t(Image src, Image dst, const Geom& g, const StreamTuning& tune, hipStream_t stream,
-                                  const ParamPack<S...>& params, int halo_rows)
+static hipError_t launch_aot(Image src, Image dst, const Geom& g, const StreamTuning& tune, hipStream_t stream,
+                             const unsigned char* pbytes, size_t psize, int halo_rows)
 {
     constexpr int RH = SumRH<S...>::value;
-    constexpr int VALID = 64 * T - 2 * RH;
-    static_assert(VALID > 0, "horizontal halo too wide for the strip");
+    static_assert(64 * T - 2 * RH > 0, "horizontal halo too wide for the strip");
+    static_assert(sizeof(StreamArgs<S...>) == sizeof(StreamHdr) + sizeof(ParamPack<S...>), "header, then the parameter slots");
+    if (psize != sizeof(ParamPack<S...>)) return hipErrorInvalidValue;   // the byte layout and the template disagree: a bug, never launch
+    LaunchShape sh;
+    if (!launch_shape(src, dst, g, tune, T, RH, halo_rows, Px::BPP, resident_workgroups<Px, PF, T, S...>(), sh)) return hipSuccess;
     StreamArgs<S...> A;
-    A.src = static_cast<const char*>(src.base);
-    A.src_pitch = src.pitch;
-    A.dst = static_cast<char*>(dst.base);
-    A.dst_pitch = dst.pitch;
-    A.W = g.W;
-    A.row_lo = g.row_lo;
-    A.row_hi = g.row_hi;
-    A.y0 = g.y0;
-    A.y1 = g.y1;
-    A.n_strips = (g.W + VALID - 1) / VALID;
-    const int rows = g.y1 - g.y0;
-    if (rows <= 0 || g.W <= 0) return hipSuccess;
-    A.rows_per_chunk = choose_rows_per_chunk(rows, (A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock, resident_workgroups<Px, PF, T, S...>(),
-                                             halo_rows, Px::BPP, tune, tune.walk == 2);
-    A.params = params;
-    A.n_work = ((A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock) * ((rows + A.rows_per_chunk - 1) / A.rows_per_chunk);
-    A.alternate = tune.walk == 2 ? 0 : 1;
-    dim3 grid((unsigned)((A.n_work + 7) / 8 * 8));   // 1-D, a multiple of the 8 XCDs (see the kernel's block order)
-    hipLaunchKernelGGL((stream_kernel<Px, PF, T, S...>), grid, dim3(64 * kWavesPerBlock), 0, stream, A);
+    static_cast<StreamHdr&>(A) = sh.hdr;
+    std::memcpy(&A.params, pbytes, psize);
+    hipLaunchKernelGGL((stream_kernel<Px, PF, T, S...>), dim3(sh.grid), dim3(64 * kWavesPerBlock), 0, stream, A);
     return hipGetLastError();
 }
 
-// multiply-adds per texel and row of a stage list: what decides whether a pipeline is bound by
-// vector issue (the 5-stage BASELINE chain: 33 taps) or by the memory path (3-stage chain: 15)
-template <class S> struct TapsOf { static constexpr int value = 0; };
-template <int R> struct TapsOf<StHTap<R>> { static constexpr int value = 2 * R + 1; };
-template <int R> struct TapsOf<StVTap<R>> { static constexpr int value = 2 * R + 1; };
-template <> struct TapsOf<StCross3> { static constexpr int value = 5; };
-template <> struct TapsOf<StGrade> { static constexpr int value = 3; };
-template <class... S> struct MaxRV { static constexpr int value = 0; };
-template <class S, class... Rest> struct MaxRV<S, Rest...> { static constexpr int value = S::RV > MaxRV<Rest...>::value ? S::RV : MaxRV<Rest...>::value; };
-template <class... S> struct SumTaps { static constexpr int value = 0; };
-template <class S, class... Rest> struct SumTaps<S, Rest...> { static constexpr int value = TapsOf<S>::value + SumTaps<Rest...>::value; };
+typedef hipError_t (*AotFn)(Image, Image, const Geom&, const StreamTuning&, hipStream_t, const unsigned char*, size_t, int);
+struct AotEntry {
+    AotFn fn[2][3] = {};      // [format][texels per lane]
+};
 
-// Walk policy of a launch (measured with scripts/walk_probe.py on MI355X):
-//  * ISSUE-BOUND pipelines (>= kHeavyTaps multiply-adds per texel) walk every chunk TOP-DOWN and, on large
-//    rgba32f frames, take TWO texels per lane: 128-wide strips halve the share of halo
-//    lanes and the per-row scalar work, and top-down walks run the vertical taps in scatter form
-//    (StVTap: no window shifts).  5-stage chain: 16384^2 2.04 -> 1.86 ms, 8K 0.260 -> 0.241 ms.
-//  * everything else keeps one texel per lane and ALTERNATING walks: it is bound by the memory
-//    path, more waves in flight and halo rows shared through L2 matter more (3-stage chain at 4K:
-//    42.2 us alternating, 43.4 top-down, 43.7 with two texels).
-// Two texels per lane are never used in place (the last strip overlaps its neighbour: see
-// stream_kernel), for rgba8 (its lanes would issue four 256-B DMAs per row) or for narrow frames.
-constexpr int kHeavyTaps = 24;
-constexpr long kTwoTexelMinPixels = 24L << 20;   // two texels per lane from 8K frames up (5-stage chain at 4K: 64.4 us with one, 68.3 with two)
-
-template <class Px, int PF, class... S>
-static hipError_t launch_stream(Image src, Image dst, const Geom& g, const StreamTuning& tune, hipStream_t stream,
-                                const ParamPack<S...>& params, int halo_rows)
-{
-    StreamTuning t = tune;
-    const long px = (long)g.W * (long)(g.y1 - g.y0);
-    const bool heavy = SumTaps<S...>::value >= kHeavyTaps;
-    if (t.walk == 0) t.walk = heavy ? 2 : 1;
-    if constexpr (!Px::QUANT && SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4) {   // (a radius-6 window of two texels no longer fits 256 VGPRs)
-        const bool can2 = src.base != dst.base && g.W >= 256;
-        const bool two = t.texels_per_lane == 2 || (t.texels_per_lane == 0 && heavy && px >= kTwoTexelMinPixels);
-        if (two && can2) return launch_stream_t<Px, (PF > 4 ? 4 : PF), 2, S...>(src, dst, g, t, stream, params, halo_rows);
-    }
-    return launch_stream_t<Px, PF, 1, S...>(src, dst, g, t, stream, params, halo_rows);
-}
-
-// ---- op -> params helpers -------------------------------------------------------
-template <int R> static typename StHTap<R>::Params htap_params(const Op& op)
-{
-    typename StHTap<R>::Params p;
-    for (int i = 0; i <= R; ++i) p.w[i] = v2f{op.w[i], op.w[i]};
-    return p;
-}
-template <int R> static typename StVTap<R>::Params vtap_params(const Op& op)
-{
-    typename StVTap<R>::Params p;
-    for (int i = 0; i <= R; ++i) p.w[i] = v2f{op.w[i], op.w[i]};
-    return p;
-}
-static StGrade::Params grade_params(const Op& op) { return {op.slope, op.offset, op.saturation}; }
-static StCross3::Params cross_params(const Op& op) { return {op.wc, op.ws}; }
+template <class S> struct StageKey;
+template <int R> struct StageKey<StHTap<R>> { static std::string get() { return "H" + std::to_string(R) + " "; } };
+template <int R> struct StageKey<StVTap<R>> { static std::string get() { return "V" + std::to_string(R) + " "; } };
+template <> struct StageKey<StGrade> { static std::string get() { return "G "; } };
+template <> struct StageKey<StCross3> { static std::string get() { return "C "; } };
+template <> struct StageKey<StNodeEnd> { static std::string get() { return "E "; } };
 
 #ifndef RF_PF_DEFAULT
 #define RF_PF_DEFAULT 4
 #endif
 constexpr int PF_DEFAULT = RF_PF_DEFAULT;   // rows in flight per wave (8 was measured slower, 3/5/6 see DESIGN.md)
 
-template <class Px> static hipError_t run_passthrough(Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
-{
-    ParamPack<StNodeEnd> P;
-    return launch_stream<Px, PF_DEFAULT, StNodeEnd>(s, d, g, t, st, P, 0);
-}
-
-template <class Px, int R> static hipError_t run_gauss(const Op& op, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
-{
-    ParamPack<StHTap<R>, StVTap<R>> P;
-    P.p = htap_params<R>(op);
-    P.rest.p = vtap_params<R>(op);
-    return launch_stream<Px, (R <= 4 ? PF_DEFAULT : 2), StHTap<R>, StVTap<R>>(s, d, g, t, st, P, R);
-}
-
-template <class Px, int R = 0>
-static hipError_t run_gauss_any(const Op& op, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
-{
-    if constexpr (R > kMaxRadius) {
-        return hipErrorInvalidValue;
-    } else {
-        if (op.radius == R) return run_gauss<Px, R>(op, s, d, g, t, st);
-        return run_gauss_any<Px, R + 1>(op, s, d, g, t, st);
-    }
-}
-
-template <class Px> static hipError_t run_grade(const Op& op, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
-{
-    ParamPack<StGrade> P;
-    P.p = grade_params(op);
-    return launch_stream<Px, PF_DEFAULT, StGrade>(s, d, g, t, st, P, 0);
-}
-
-template <class Px> static hipError_t run_sharpen(const Op& op, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
-{
-    ParamPack<StCross3> P;
-    P.p = cross_params(op);
-    return launch_stream<Px, PF_DEFAULT, StCross3>(s, d, g, t, st, P, 1);
-}
-
-// ---- fused chains -----------------------------------------------------------------
-// A fused launch is the concatenation of its nodes' stage lists with a StNodeEnd between
-// nodes.  Fusable node kinds: gaussian5 (G2), gaussian9 (G4), colour grade, sharpen.  Every
-// pair of them is instantiated, plus the triple gaussian -> grade -> sharpen and the whole
-// 5-stage chain of the BASELINE configs; anything else runs one launch per node.
 template <class... S> struct TL {};
 template <class A, class B> struct Concat;
 template <class... A, class... B> struct Concat<TL<A...>, TL<B...>> { typedef TL<A..., B...> type; };
 template <class A, class B> struct Join { typedef typename Concat<typename Concat<A, TL<StNodeEnd>>::type, B>::type type; };
+
+static std::map<std::string, AotEntry>& catalogue()
+{
+    static std::map<std::string, AotEntry> c;
+    return c;
+}
+
+template <int PF, class... S> static void add_to_catalogue(TL<S...>)
+{
+    std::string key;
+    const int dummy[] = {0, (key += StageKey<S>::get(), 0)...};
+    (void)dummy;
+    AotEntry& e = catalogue()[key];
+    e.fn[kFmtRGBA8][1] = &launch_aot<PxU8, PF, 1, S...>;
+    e.fn[kFmtRGBA32F][1] = &launch_aot<PxF32, PF, 1, S...>;
+    // two texels per lane: rgba32f only, and only where the doubled state still fits 256 VGPRs
+    if constexpr (SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4) e.fn[kFmtRGBA32F][2] = &launch_aot<PxF32, (PF > 4 ? 4 : PF), 2, S...>;
+}
+
+// The ahead-of-time catalogue: every node alone (gaussian radius 0..15), every ordered pair of
+// {gaussian5, gaussian9, grade, sharpen}, the triples gaussian(5|9) -> grade -> sharpen and the whole 5-stage chain of
+// the BASELINE configs.  Any other chain of fusable nodes is compiled when a graph that contains it is created
+// (rf_jit.cpp); with RF_GRAPH_NO_JIT, or without libhiprtc, it is cut into the longest pieces found here.
+template <int R> static void add_gaussians()
+{
+    if constexpr (R <= kMaxRadius) {
+        add_to_catalogue<(R <= 4 ? PF_DEFAULT : 2)>(TL<StHTap<R>, StVTap<R>>{});
+        add_gaussians<R + 1>();
+    }
+}
 
 template <int CODE> struct NodeTL;
 template <> struct NodeTL<0> { typedef TL<StHTap<2>, StVTap<2>> type; };
@@ -920,108 +340,50 @@ template <> struct NodeTL<1> { typedef TL<StHTap<4>, StVTap<4>> type; };
 template <> struct NodeTL<2> { typedef TL<StGrade> type; };
 template <> struct NodeTL<3> { typedef TL<StCross3> type; };
 
-static int node_code(const Op& o)
+template <int A, int B> static void add_pairs()
 {
-    if (o.kind == OP_GAUSSIAN && o.radius == 2) return 0;
-    if (o.kind == OP_GAUSSIAN && o.radius == 4) return 1;
-    if (o.kind == OP_GRADE) return 2;
-    if (o.kind == OP_SHARPEN) return 3;
-    return -1;
-}
-
-// parameters of a stage from the op of the node it belongs to
-template <int R> static void set_params(typename StHTap<R>::Params& p, const Op& op) { p = htap_params<R>(op); }
-template <int R> static void set_params(typename StVTap<R>::Params& p, const Op& op) { p = vtap_params<R>(op); }
-static void set_params(StGrade::Params& p, const Op& op) { p = grade_params(op); }
-static void set_params(StCross3::Params& p, const Op& op) { p = cross_params(op); }
-
-static void fill_params(ParamPack<>&, const Op*, int) {}
-template <class... Rest> static void fill_params(ParamPack<StNodeEnd, Rest...>& P, const Op* ops, int i) { fill_params(P.rest, ops, i + 1); }
-template <int R, class... Rest> static void fill_params(ParamPack<StHTap<R>, Rest...>& P, const Op* ops, int i)
-{
-    set_params<R>(P.p, ops[i]);
-    fill_params(P.rest, ops, i);
-}
-template <int R, class... Rest> static void fill_params(ParamPack<StVTap<R>, Rest...>& P, const Op* ops, int i)
-{
-    set_params<R>(P.p, ops[i]);
-    fill_params(P.rest, ops, i);
-}
-template <class... Rest> static void fill_params(ParamPack<StGrade, Rest...>& P, const Op* ops, int i)
-{
-    set_params(P.p, ops[i]);
-    fill_params(P.rest, ops, i);
-}
-template <class... Rest> static void fill_params(ParamPack<StCross3, Rest...>& P, const Op* ops, int i)
-{
-    set_params(P.p, ops[i]);
-    fill_params(P.rest, ops, i);
-}
-
-template <class Px, class... S>
-static hipError_t launch_list(TL<S...>, const Op* ops, int n, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
-{
-    ParamPack<S...> P;
-    fill_params(P, ops, 0);
-    return launch_stream<Px, PF_DEFAULT, S...>(s, d, g, t, st, P, ops_radius(ops, n));
-}
-
-template <class Px, int C0>
-static hipError_t launch_pair(const Op* o, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
-{
-    typedef typename NodeTL<C0>::type A;
-    switch (node_code(o[1])) {
-        case 0: return launch_list<Px>(typename Join<A, NodeTL<0>::type>::type{}, o, 2, s, d, g, t, st);
-        case 1: return launch_list<Px>(typename Join<A, NodeTL<1>::type>::type{}, o, 2, s, d, g, t, st);
-        case 2: return launch_list<Px>(typename Join<A, NodeTL<2>::type>::type{}, o, 2, s, d, g, t, st);
-        case 3: return launch_list<Px>(typename Join<A, NodeTL<3>::type>::type{}, o, 2, s, d, g, t, st);
-        default: return hipErrorInvalidValue;
+    if constexpr (A < 4) {
+        add_to_catalogue<PF_DEFAULT>(typename Join<typename NodeTL<A>::type, typename NodeTL<B>::type>::type{});
+        if constexpr (B + 1 < 4) add_pairs<A, B + 1>();
+        else add_pairs<A + 1, 0>();
     }
 }
 
-static bool is_chain5(const Op* o, int n)
+static const std::map<std::string, AotEntry>& built_catalogue()
 {
-    static const int pattern[5] = {0, 2, 3, 1, 2};
-    if (n != 5) return false;
-    for (int i = 0; i < 5; ++i)
-        if (node_code(o[i]) != pattern[i]) return false;
-    return true;
-}
-
-template <class Px>
-static hipError_t launch_fused(const Op* o, int n, Image s, Image d, const Geom& g, const StreamTuning& t, hipStream_t st)
-{
-    if (n == 2) {
-        switch (node_code(o[0])) {
-            case 0: return launch_pair<Px, 0>(o, s, d, g, t, st);
-            case 1: return launch_pair<Px, 1>(o, s, d, g, t, st);
-            case 2: return launch_pair<Px, 2>(o, s, d, g, t, st);
-            case 3: return launch_pair<Px, 3>(o, s, d, g, t, st);
-            default: return hipErrorInvalidValue;
-        }
-    }
-    if (n == 3 && node_code(o[1]) == 2 && node_code(o[2]) == 3) {
-        typedef typename Join<NodeTL<2>::type, NodeTL<3>::type>::type Tail;   // grade -> sharpen
-        if (node_code(o[0]) == 0) return launch_list<Px>(typename Join<NodeTL<0>::type, Tail>::type{}, o, 3, s, d, g, t, st);
-        if (node_code(o[0]) == 1) return launch_list<Px>(typename Join<NodeTL<1>::type, Tail>::type{}, o, 3, s, d, g, t, st);
-    }
-    if (is_chain5(o, n)) {   // gaussian5 -> grade -> sharpen -> gaussian9 -> grade: BASELINE configs[3], one read and one write for five nodes
-        typedef typename Join<NodeTL<0>::type, typename Join<NodeTL<2>::type, NodeTL<3>::type>::type>::type Head;
+    static bool done = false;
+    if (!done) {
+        done = true;
+        add_to_catalogue<PF_DEFAULT>(TL<StNodeEnd>{});
+        add_to_catalogue<PF_DEFAULT>(TL<StGrade>{});
+        add_to_catalogue<PF_DEFAULT>(TL<StCross3>{});
+        add_gaussians<0>();
+        add_pairs<0, 0>();
+        typedef typename Join<NodeTL<2>::type, NodeTL<3>::type>::type GradeSharp;
+        add_to_catalogue<PF_DEFAULT>(typename Join<NodeTL<0>::type, GradeSharp>::type{});
+        add_to_catalogue<PF_DEFAULT>(typename Join<NodeTL<1>::type, GradeSharp>::type{});
+        typedef typename Join<NodeTL<0>::type, GradeSharp>::type Head;
         typedef typename Join<NodeTL<1>::type, NodeTL<2>::type>::type Tail;
-        return launch_list<Px>(typename Join<Head, Tail>::type{}, o, 5, s, d, g, t, st);
+        add_to_catalogue<PF_DEFAULT>(typename Join<Head, Tail>::type{});      // gaussian5 -> grade -> sharpen -> gaussian9 -> grade
     }
-    return hipErrorInvalidValue;
+    return catalogue();
 }
 
-bool stream_supported(const Op* ops, int n)
+bool stream_in_catalogue(const StageList& sl) { return built_catalogue().count(sl.key()) != 0; }
+
+// what a run-time compiled kernel may be asked to hold: the planner's admission rule for a chain outside the catalogue
+bool stream_jit_admissible(const StageList& sl)
+{
+    return sl.n >= 1 && sl.sum_rh() <= 12 && sl.vgpr_estimate(1) <= 224;      // (up to 256 VGPRs = two waves per SIMD)
+}
+
+bool stream_supported(const Op* ops, int n, bool allow_jit)
 {
     if (n <= 0 || n > kMaxFusedOps) return false;
-    if (n == 1) return true;
-    for (int i = 0; i < n; ++i)
-        if (node_code(ops[i]) < 0) return false;
-    if (n == 2) return true;
-    if (n == 3) return ops[0].kind == OP_GAUSSIAN && node_code(ops[1]) == 2 && node_code(ops[2]) == 3;
-    return is_chain5(ops, n);
+    StageList sl;
+    if (!ops_to_stages(ops, n, sl)) return false;
+    if (stream_in_catalogue(sl)) return true;
+    return n >= 2 && allow_jit && stream_jit_admissible(sl) && jit_available();
 }
 
 int ops_radius(const Op* ops, int n)
@@ -1038,31 +400,106 @@ int ops_radius(const Op* ops, int n)
     return r;
 }
 
+// Walk policy of a launch (measured with scripts/walk_probe.py on MI355X):
+//  * ISSUE-BOUND pipelines (>= kHeavyTaps multiply-adds per texel) walk every chunk TOP-DOWN and, on large
+//    rgba32f frames, take TWO texels per lane: 128-wide strips halve the share of halo
+//    lanes and the per-row scalar work, and top-down walks run the vertical taps in scatter form
+//    (StVTap: no window shifts).  5-stage chain: 16384^2 2.04 -> 1.86 ms, 8K 0.260 -> 0.241 ms.
+//  * everything else keeps one texel per lane and ALTERNATING walks: it is bound by the memory
+//    path, more waves in flight and halo rows shared through L2 matter more (3-stage chain at 4K:
+//    42.2 us alternating, 43.4 top-down, 43.7 with two texels).
+// Two texels per lane are never used in place (the last strip overlaps its neighbour: see
+// stream_kernel), for rgba8 (its lanes would issue four 256-B DMAs per row) or for narrow frames.
+constexpr int kHeavyTaps = 24;
+constexpr long kTwoTexelMinPixels = 24L << 20;   // two texels per lane from 8K frames up (5-stage chain at 4K: 64.4 us with one, 68.3 with two)
+
+static int choose_texels(int fmt, const StageList& sl, Image src, Image dst, const Geom& g, StreamTuning& t)
+{
+    const long px = (long)g.W * (long)(g.y1 - g.y0);
+    const bool heavy = sl.taps() >= kHeavyTaps;
+    if (t.walk == 0) t.walk = heavy ? 2 : 1;
+    if (fmt != kFmtRGBA32F || sl.sum_rh() > 7 || sl.max_rv() > 4) return 1;
+    const bool can2 = src.base != dst.base && g.W >= 256;
+    const bool two = t.texels_per_lane == 2 || (t.texels_per_lane == 0 && heavy && px >= kTwoTexelMinPixels);
+    return (two && can2) ? 2 : 1;
+}
+
+// texels per lane a graph of this size would use for this list (so that rf_graph_create can compile that variant too)
+int stream_texels_for(int fmt, const Op* ops, int n, int W, int rows, const StreamTuning& tune)
+{
+    StageList sl;
+    if (!ops_to_stages(ops, n, sl)) return 1;
+    StreamTuning t = tune;
+    Geom g;
+    g.W = W;
+    g.y0 = 0;
+    g.y1 = rows;
+    Image a{(void*)16, 0}, b{(void*)32, 0};
+    return choose_texels(fmt, sl, a, b, g, t);
+}
+
+static hipError_t launch_stages(int fmt, const StageList& sl, const Op* ops, int n, Image src, Image dst, const Geom& g,
+                                const StreamTuning& tune, hipStream_t stream)
+{
+    if (g.y1 - g.y0 <= 0 || g.W <= 0) return hipSuccess;
+    StreamTuning t = tune;
+    const int texels = choose_texels(fmt, sl, src, dst, g, t);
+    unsigned char pbytes[kMaxParamBytes];
+    const size_t psize = param_bytes(sl, ops, n, pbytes, sizeof(pbytes));
+    if (psize == 0) return hipErrorInvalidValue;
+    const int halo = sl.sum_rv();
+    auto it = built_catalogue().find(sl.key());
+    if (it != built_catalogue().end()) {
+        AotFn fn = it->second.fn[fmt][texels];
+        if (!fn) fn = it->second.fn[fmt][1];
+        return fn(src, dst, g, t, stream, pbytes, psize, halo);
+    }
+    // compiled at graph creation (rf_graph_create -> stream_prepare); never compiled here, on the frame path
+    const JitKernel* k = jit_lookup(fmt, PF_DEFAULT, texels, sl);
+    if (!k && texels != 1) k = jit_lookup(fmt, PF_DEFAULT, 1, sl);
+    if (!k) return hipErrorInvalidDeviceFunction;
+    LaunchShape sh;
+    const int bpp = fmt == kFmtRGBA8 ? 4 : 16;
+    if (!launch_shape(src, dst, g, t, k->texels, sl.sum_rh(), halo, bpp, k->resident_workgroups, sh)) return hipSuccess;
+    unsigned char args[sizeof(StreamHdr) + kMaxParamBytes];
+    std::memcpy(args, &sh.hdr, sizeof(StreamHdr));
+    std::memcpy(args + sizeof(StreamHdr), pbytes, psize);
+    return jit_launch(*k, sh.grid, 64 * kWavesPerBlock, args, sizeof(StreamHdr) + psize, stream);
+}
+
+// rf_graph_create: make sure the kernel of this fused launch exists (compile it if the catalogue lacks it)
+bool stream_prepare(int fmt, const Op* ops, int n, int W, int rows, const StreamTuning& tune, std::string& err)
+{
+    StageList sl;
+    if (!ops_to_stages(ops, n, sl)) { err = "not a streaming launch"; return false; }
+    if (stream_in_catalogue(sl)) return true;
+    if (!jit_compile(fmt, PF_DEFAULT, 1, sl, kWavesPerBlock, err)) return false;
+    if (const JitKernel* k = jit_lookup(fmt, PF_DEFAULT, 1, sl)) {
+        // the admission rule is an estimate; a kernel that spills after all is not worth its launch
+        if (k->scratch_bytes > 0) { err = "the compiled chain " + sl.key() + "spills " + std::to_string(k->scratch_bytes) + " bytes per lane"; return false; }
+    }
+    if (stream_texels_for(fmt, ops, n, W, rows, tune) == 2) {
+        std::string e2;
+        (void)jit_compile(fmt, PF_DEFAULT, 2, sl, kWavesPerBlock, e2);      // optional variant: the one-texel kernel serves if it fails
+    }
+    return true;
+}
+
 template <class Px>
-static hipError_t launch_ops_px(const Op* ops, int n, Image src, Image dst, const Geom& g, const StreamTuning& tune,
+static hipError_t launch_ops_px(int fmt, const Op* ops, int n, Image src, Image dst, const Geom& g, const StreamTuning& tune,
                                 hipStream_t stream)
 {
-    if (n == 1) {
-        const Op& op = ops[0];
-        switch (op.kind) {
-            case OP_PASSTHROUGH: return run_passthrough<Px>(src, dst, g, tune, stream);
-            case OP_GAUSSIAN:
-                if (op.radius < 0 || op.radius > kMaxRadius) return hipErrorInvalidValue;
-                return run_gauss_any<Px>(op, src, dst, g, tune, stream);
-            case OP_GRADE: return run_grade<Px>(op, src, dst, g, tune, stream);
-            case OP_SHARPEN: return run_sharpen<Px>(op, src, dst, g, tune, stream);
-            case OP_CONV2D: return launch_conv2d(Px::QUANT ? kFmtRGBA8 : kFmtRGBA32F, op, src, dst, g, tune, stream);
-            default: return hipErrorInvalidValue;
-        }
-    }
-    return launch_fused<Px>(ops, n, src, dst, g, tune, stream);
+    if (n == 1 && ops[0].kind == OP_CONV2D) return launch_conv2d(fmt, ops[0], src, dst, g, tune, stream);
+    StageList sl;
+    if (!ops_to_stages(ops, n, sl)) return hipErrorInvalidValue;
+    return launch_stages(fmt, sl, ops, n, src, dst, g, tune, stream);
 }
 
 hipError_t launch_ops(int fmt, const Op* ops, int n, Image src, Image dst, const Geom& g, const StreamTuning& tune,
                       hipStream_t stream)
 {
-    if (fmt == kFmtRGBA8) return launch_ops_px<PxU8>(ops, n, src, dst, g, tune, stream);
-    if (fmt == kFmtRGBA32F) return launch_ops_px<PxF32>(ops, n, src, dst, g, tune, stream);
+    if (fmt == kFmtRGBA8) return launch_ops_px<PxU8>(fmt, ops, n, src, dst, g, tune, stream);
+    if (fmt == kFmtRGBA32F) return launch_ops_px<PxF32>(fmt, ops, n, src, dst, g, tune, stream);
     return hipErrorInvalidValue;
 }
 

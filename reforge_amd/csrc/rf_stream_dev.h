@@ -1,0 +1,701 @@
+// rf_stream_dev.h -- DEVICE code of the streaming stage-pipeline kernel (see rf_stream.hip for the design notes).
+//
+// This header is compiled twice: ahead of time by hipcc as part of rf_stream.hip (the kernel catalogue), and at
+// graph creation by hiprtc (rf_jit.cpp), which instantiates stream_kernel<> for a stage list the catalogue lacks --
+// the counterpart of the reference compiling a node's shader when the graph is built (src/vulkan/shader.rs:29-93).
+// It therefore includes nothing but rf_device.h and uses no host-side type.
+#pragma once
+#include "rf_device.h"
+
+namespace rf {
+
+// ---------------------------------------------------------------------------------
+// Per-lane context of a streaming wave.  A wave's strip is 64*T texels wide: lane l owns the
+// T texels at strip positions l, l + 64, ... (texel j of the lane = position l + 64 j), so every
+// global access and every LDS row access of a wave instruction is 64 consecutive texels -- one
+// fully coalesced 1 KiB segment for rgba32f -- whatever T is.  T = 2 halves the share of halo
+// lanes (2 RH of 128 instead of 2 RH of 64) and the per-row scalar work per texel.
+// ---------------------------------------------------------------------------------
+template <int T> struct Tex { f4 v[T]; };
+
+template <int T> RF_DEV Tex<T> tex_zero()
+{
+    Tex<T> z;
+#pragma unroll
+    for (int j = 0; j < T; ++j) z.v[j] = f4_zero();
+    return z;
+}
+
+template <int T> struct Lane {
+    int lane;   // 0..63
+    int x0;     // frame column of strip position 0 (may be negative: left halo)
+    int W;
+    f4* lds;    // wave-private LDS rows, 64*T texels each
+    RF_DEV int pos(int j) const { return lane + 64 * j; }          // strip position of the lane's texel j
+    RF_DEV int col(int j) const { return x0 + lane + 64 * j; }     // its frame column (may lie outside [0,W) in the halo)
+    // LDS slot holding column clamp(col(j)+dx) -- clamp-to-edge at the frame border, and
+    // kept inside the wave's row for the halo lanes (whose results are discarded)
+    RF_DEV int nbr(int j, int dx) const
+    {
+        int c = min(max(col(j) + dx, 0), W - 1) - x0;
+        return min(max(c, 0), 64 * T - 1);
+    }
+};
+
+// LDS operations of one wave execute in issue order, so a wave-private exchange
+// needs no s_barrier: only the compiler has to be told not to reorder.
+RF_DEV void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------
+// Source: the wave's input rows, streamed global -> LDS by LDS-DMA (global_load_lds_*:
+// no VGPR destination) into a wave-private ring of PF row slots, PF rows ahead.
+//
+// Why hand-written: with compiler-visible loads hipcc drains EVERY load in flight
+// (s_waitcnt vmcnt(0)) at each use, because loads and stores share vmcnt on gfx9 and its
+// wait-count pass treats mixed pending events as out of order.  The DMA is issued from an
+// asm statement (invisible to that pass) and waited for with a COUNTED vmcnt: vector
+// memory operations retire in issue order, and a wave issues exactly T DMAs per input
+// row and T stores per output row, in a fixed program order (see wait_row).
+// ---------------------------------------------------------------------------------
+template <int N> RF_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int T> struct Sink {
+    char* dst;          // address of local row 0
+    ptrdiff_t pitch;    // negative when the wave walks bottom-up
+    unsigned xoff[T];   // byte offset of the lane's texel j in a row
+    bool lane_ok[T];    // the lane owns an output texel at j
+    int row;            // next output row
+    int first_store;    // iteration of the first store, -1 before it (wave-uniform)
+};
+
+template <class Px, int PF, int T> struct Source {
+    static_assert(PF >= 2, "the ring needs at least two slots");
+    static constexpr int SLOTS = PF;
+    static constexpr int SLOT_BYTES = 64 * T * Px::BPP;
+    const char* src[T];   // address of local row 0, already offset by the column of the lane's texel j
+    ptrdiff_t pitch;
+    int a0, n0;           // first source row, number of source rows
+    unsigned lds_base;    // LDS byte address of slot 0 (wave-uniform)
+    const char* ring;     // the same ring through a generic pointer
+
+    RF_DEV const char* slot(int r) const { return ring + (size_t)(r % SLOTS) * SLOT_BYTES; }
+
+    // DMA source row r into slot r % PF.  Program order inside iteration `it` is
+    //   [first stage consumes row it] -> issue(it+PF) -> wait_row(it+1) -> ... -> store
+    // The slot being refilled is the one row `it` was read from (ds_read, one iteration ago).
+    // The DMA's data arrives through the memory path, not through the LDS instruction queue, and
+    // the compiler is free to sink the first USE of that ds_read -- and with it the only
+    // s_waitcnt lgkmcnt that proves the read has executed -- below this asm.  An L2 hit (the
+    // neighbour chunk has just fetched the same halo rows) then overtakes a ds_read still queued
+    // behind other waves' LDS traffic and the stage computes on the NEXT row's texels: wrong
+    // first rows of a walk, seen only on busy chips (tests/test_gpu_fullsize.py::
+    // test_random_graphs_1080p_whole_frame).  Hence the lgkmcnt(0) in front of the DMA: by then
+    // the taps of the row have normally been consumed and the wait is free.
+    RF_DEV void issue(int r) const
+    {
+        const unsigned dst0 = lds_base + (unsigned)(r % SLOTS) * (unsigned)SLOT_BYTES;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const char* g = src[j] + (ptrdiff_t)(a0 + r) * pitch;
+            const unsigned dst = dst0 + (unsigned)(j * 64 * Px::BPP);
+            unsigned keep;
+            if constexpr (Px::BPP == 16)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+        }
+    }
+    RF_DEV void prologue() const
+    {
+        for (int r = 0; r < PF && r < n0; ++r) issue(r);
+    }
+    // Wait until row r has landed, leaving younger operations in flight.  Younger than
+    // row r's DMAs at this point: the DMAs of rows r+1 .. r+PF-1 (when they exist) and, once
+    // the pipeline emits a row per iteration, the stores of the PF-1 iterations in between
+    // (T of each per row).
+    RF_DEV void wait_row(int r, const Sink<T>& k) const
+    {
+        if (n0 - 1 - r >= PF - 1) {
+            if (k.first_store >= 0 && k.first_store <= r - PF) wait_vmcnt<(2 * PF - 2) * T>();
+            else wait_vmcnt<(PF - 1) * T>();
+        } else {
+            wait_vmcnt<0>();
+        }
+    }
+};
+
+// what the first stage is handed each iteration, fetched from the ring one iteration
+// ahead so the LDS latency hides behind the previous row's arithmetic
+template <class Px, int T> struct OwnFeed {      // the lane's own texels
+    typename Px::Raw nxt[T];
+    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane<T>& L)
+    {
+#pragma unroll
+        for (int j = 0; j < T; ++j) nxt[j] = *reinterpret_cast<const typename Px::Raw*>(s.slot(r) + (size_t)L.pos(j) * Px::BPP);
+    }
+    RF_DEV Tex<T> own() const
+    {
+        Tex<T> o;
+#pragma unroll
+        for (int j = 0; j < T; ++j) o.v[j] = Px::decode(nxt[j]);
+        return o;
+    }
+};
+template <int R, int T> struct TapFeed {         // rgba32f: the 2R+1 horizontal taps, straight from the DMA ring
+    f4 t[T][2 * R + 1];
+    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane<T>& L)
+    {
+        const f4* row = reinterpret_cast<const f4*>(s.slot(r));
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+#pragma unroll
+            for (int i = -R; i <= R; ++i) t[j][i + R] = row[L.nbr(j, i)];
+        }
+    }
+    RF_DEV Tex<T> own() const
+    {
+        Tex<T> o;
+#pragma unroll
+        for (int j = 0; j < T; ++j) o.v[j] = t[j][R];
+        return o;
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// Row stages.  advance() is called once per row entering the stage:
+//   v      the row's texels for this lane (undefined when !real)
+//   real   a new input row; false = the newest row repeated (clamp-to-edge below the frame)
+//   first  the stage's first row: it primes the whole window (clamp-to-edge above the frame,
+//          or rows that are shifted out again before anything is emitted)
+//   emit   the window's centre row is wanted downstream (wave-uniform, from the schedule)
+// ---------------------------------------------------------------------------------
+struct NoState {};
+
+// horizontal taps of the separable gaussian: sum_i w[|i|] * in[x+i], ascending i
+template <int R> struct StHTap {
+    static constexpr int RV = 0, RH = R, LDS_ROWS = (R > 0) ? 1 : 0;
+    struct Params { v2f w[R + 1]; };   // each weight twice: the operand pair of a packed fma (see fma4)
+    template <class Px, int T> using State = NoState;
+    // as the FIRST stage of an rgba32f pipeline the taps come straight from the DMA ring
+    // (up to radius 7: beyond that 2R+1 prefetched taps crowd the vertical window out of the register
+    // file -- radius 10 at 4K: 209 us with the prefetch, 119 us through the LDS exchange)
+    template <class Px, int T> using Feed = typename std::conditional<(Px::QUANT || R > 7 || T > 1), OwnFeed<Px, T>, TapFeed<R, T>>::type;
+    template <int T> RF_DEV static Tex<T> from_taps(const Params& p, const TapFeed<R, T>& f)
+    {
+        Tex<T> o;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            f4 acc = f4_zero();
+#pragma unroll
+            for (int i = -R; i <= R; ++i) acc = fma4(p.w[i < 0 ? -i : i], f.t[j][i + R], acc);
+            o.v[j] = acc;
+        }
+        return o;
+    }
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, NoState&, const Lane<T>& L, f4* lds, const Tex<T>& v, bool, bool, bool, Tex<T>& out)
+    {
+        if constexpr (R > 0) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) lds[L.pos(j)] = v.v[j];
+            wave_sync();
+        }
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            f4 acc = f4_zero();
+#pragma unroll
+            for (int i = -R; i <= R; ++i) {
+                f4 t = (i == 0) ? v.v[j] : lds[L.nbr(j, i)];
+                acc = fma4(p.w[i < 0 ? -i : i], t, acc);
+            }
+            out.v[j] = acc;
+        }
+    }
+};
+
+// vertical taps: sum_j w[|j|] * tmp[y+j], ascending j.
+//
+// Walking top-down the rows arrive in ascending order, which IS the tap order of every output row:
+// the stage then keeps one running sum per pending output row instead of a window of input rows
+// (SCATTER form).  Row r contributes  acc[y] = fma(w|r-y|, tmp[r], acc[y])  to the 2R+1 outputs it
+// reaches; the oldest of them, y = r - R, takes its last tap and is emitted.  Each output still
+// sums its taps in ascending j from 0 -- bit-identical to the window form -- but the slide of the
+// pending rows is done by the fma itself (destination = the slot one up from its addend), where a
+// window of rows has to be shifted with moves: 2 x 2R v_mov_b64 per row and texel.
+// Walking bottom-up (REV) the rows arrive in DESCENDING order, so the sums cannot be formed on
+// arrival; those walks keep the window of rows (GATHER form).
+template <int R> struct StVTap {
+    static constexpr int RV = R, RH = 0, LDS_ROWS = 0;
+    struct Params { v2f w[R + 1]; };
+    // scatter: acc[k] = running sum of output row (newest - R + 1 + k), k = 0 .. 2R-1; last = newest real row (bottom-edge flush)
+    // gather:  win[i] = input row (newest - 2R + i)
+    template <class Px, int T> struct State { Tex<T> win[2 * R + 1]; };
+    template <class Px, int T> using Feed = OwnFeed<Px, T>;
+
+    // running sums 0 .. 2R-2 slide down by one while taking their tap (compile-time recursion: every weight
+    // index is a constant for the front end already, so the parameter block stays in scalar registers)
+    template <int K, int T> RF_DEV static void slide(const Params& p, Tex<T>* acc, const f4& v, int t)
+    {
+        if constexpr (K + 1 < 2 * R) {
+            constexpr int j = R - 1 - K;                                       // row newest-R+1+K takes tap j
+            acc[K].v[t] = fma4(p.w[j < 0 ? -j : j], v, acc[K + 1].v[t]);
+            slide<K + 1, T>(p, acc, v, t);
+        }
+    }
+    template <int T> RF_DEV static void scatter_row(const Params& p, Tex<T>* acc, const Tex<T>& v, Tex<T>& out)
+    {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            out.v[t] = fma4(p.w[R], v.v[t], acc[0].v[t]);                       // j = +R: the last tap of row newest-R
+            slide<0, T>(p, acc, v.v[t], t);
+            acc[2 * R - 1].v[t] = fma4(p.w[R], v.v[t], f4_zero());              // j = -R: the first tap of row newest+R
+        }
+    }
+    // KEEP: the row may be the stage's last real one (tail and generic loop phases): remember it for the flush
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, State<Px, T>& s, const Lane<T>&, f4*, const Tex<T>& v, bool real, bool first, bool emit, Tex<T>& out)
+    {
+        if constexpr (R == 0) {
+            out = tex_zero<T>();
+#pragma unroll
+            for (int t = 0; t < T; ++t) out.v[t] = fma4(p.w[0], v.v[t], f4_zero());
+        } else if constexpr (!REV) {
+            // s.win[0 .. 2R-1] are the running sums, s.win[2R] the newest real row
+            if (first) {
+                // clamp-to-edge above the stage's first row: as if 2R more copies of it had arrived before
+#pragma unroll
+                for (int k = 0; k < 2 * R; ++k) s.win[k] = tex_zero<T>();
+                Tex<T> dummy;
+#pragma unroll
+                for (int n = 0; n < 2 * R; ++n) scatter_row<T>(p, s.win, v, dummy);
+            }
+            Tex<T> in;                        // by value: a reference picked between two objects would pin both to memory
+#pragma unroll
+            for (int t = 0; t < T; ++t) in.v[t] = real ? v.v[t] : s.win[2 * R].v[t];
+            Tex<T> o;
+            scatter_row<T>(p, s.win, in, o);
+            if (emit) out = o;
+            if constexpr (KEEP) {
+                if (real) s.win[2 * R] = v;
+            }
+        } else {
+            if (first) {                     // the first row primes the whole window (it is always a real row)
+#pragma unroll
+                for (int i = 0; i <= 2 * R; ++i) s.win[i] = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2 * R; ++i) s.win[i] = s.win[i + 1];
+                if (real) s.win[2 * R] = v;
+            }
+            if (emit) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    f4 acc = f4_zero();
+#pragma unroll
+                    // taps are accumulated in ascending FRAME row order; walking bottom-up the window
+                    // holds the rows the other way round
+                    for (int j = -R; j <= R; ++j) acc = fma4(p.w[j < 0 ? -j : j], s.win[R - j].v[t], acc);
+                    out.v[t] = acc;
+                }
+            }
+        }
+    }
+};
+
+// colour grade point op
+struct StGrade {
+    static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
+    struct Params { float slope, offset, saturation; };
+    template <class Px, int T> using State = NoState;
+    template <class Px, int T> using Feed = OwnFeed<Px, T>;
+    RF_DEV static float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+    RF_DEV static f4 grade(const Params& p, f4 c)
+    {
+        float tr = fmaf(c.x, p.slope, p.offset);
+        float tg = fmaf(c.y, p.slope, p.offset);
+        float tb = fmaf(c.z, p.slope, p.offset);
+        float luma = fmaf(0.0722f, tb, fmaf(0.7152f, tg, 0.2126f * tr));
+        return make_float4(clamp01(fmaf(p.saturation, tr - luma, luma)), clamp01(fmaf(p.saturation, tg - luma, luma)),
+                           clamp01(fmaf(p.saturation, tb - luma, luma)), c.w);
+    }
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, NoState&, const Lane<T>&, f4*, const Tex<T>& c, bool, bool, bool, Tex<T>& out)
+    {
+#pragma unroll
+        for (int j = 0; j < T; ++j) out.v[j] = grade(p, c.v[j]);
+    }
+};
+
+// 3x3 sharpen cross [0,s,0; s,c,s; 0,s,0], taps in ascending (y outer, x inner) order.
+// The horizontal neighbours of a row are fetched through LDS when the row ARRIVES and
+// are first used one iteration later, when that row is the centre: the LDS round trip
+// hides behind a whole iteration instead of stalling the wave.
+struct StCross3 {
+    static constexpr int RV = 1, RH = 1, LDS_ROWS = 1;
+    struct Params { float wc, ws; };
+    template <class Px, int T> struct State { Tex<T> n, c, cw, ce; };   // rows y-1, y and y's left/right neighbours
+    template <class Px, int T> using Feed = OwnFeed<Px, T>;
+    template <int T> RF_DEV static void exchange(const Lane<T>& L, f4* lds, const Tex<T>& v, Tex<T>& w, Tex<T>& e)
+    {
+#pragma unroll
+        for (int j = 0; j < T; ++j) lds[L.pos(j)] = v.v[j];
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            w.v[j] = lds[L.nbr(j, -1)];
+            e.v[j] = lds[L.nbr(j, +1)];
+        }
+    }
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, State<Px, T>& s, const Lane<T>& L, f4* lds, const Tex<T>& v, bool real, bool first, bool emit, Tex<T>& out)
+    {
+        if (first) {                     // window = [v, v, (next row)]
+            s.n = v;
+            s.c = v;
+            exchange(L, lds, v, s.cw, s.ce);
+            return;
+        }
+        const Tex<T> below = real ? v : s.c;
+        if (emit) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                f4 acc = f4_zero();
+                // frame order N, W, C, E, S: walking bottom-up the older row is the one BELOW
+                acc = fma4(p.ws, REV ? below.v[j] : s.n.v[j], acc);
+                acc = fma4(p.ws, s.cw.v[j], acc);
+                acc = fma4(p.wc, s.c.v[j], acc);
+                acc = fma4(p.ws, s.ce.v[j], acc);
+                acc = fma4(p.ws, REV ? s.n.v[j] : below.v[j], acc);
+                out.v[j] = acc;
+            }
+        }
+        s.n = s.c;
+        if (real) {
+            s.c = v;
+            exchange(L, lds, v, s.cw, s.ce);
+        }
+    }
+};
+
+// node boundary inside a fused chain: the store + load the unfused graph performs
+// (UNORM8 re-quantisation for rgba8, nothing for rgba32f)
+struct StNodeEnd {
+    static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
+    struct Params {};
+    template <class Px, int T> using State = NoState;
+    template <class Px, int T> using Feed = OwnFeed<Px, T>;
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params&, NoState&, const Lane<T>&, f4*, const Tex<T>& v, bool, bool, bool, Tex<T>& out)
+    {
+#pragma unroll
+        for (int j = 0; j < T; ++j) out.v[j] = Px::requant(v.v[j]);
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// Parameter pack (kernel argument) and the stage chain (per-wave state)
+// ---------------------------------------------------------------------------------
+// Layout by construction: every stage owns a slot of max(8, sizeof(Params) rounded up to 8) bytes, in stage order,
+// closed by one empty 8-byte slot.  The host fills the block as BYTES (rf_stream.hip, param_bytes) -- the same code
+// for a catalogue kernel and for one compiled at graph creation, whose stage list no host template ever saw.
+template <class... S> struct ParamPack;
+template <> struct alignas(8) ParamPack<> {};
+template <class S, class... Rest> struct alignas(8) ParamPack<S, Rest...> {
+    alignas(8) typename S::Params p;
+    alignas(8) ParamPack<Rest...> rest;
+};
+
+template <class... S> struct SumRH { static constexpr int value = 0; };
+template <class S, class... Rest> struct SumRH<S, Rest...> { static constexpr int value = S::RH + SumRH<Rest...>::value; };
+template <class... S> struct SumLDS { static constexpr int value = 0; };
+template <class S, class... Rest> struct SumLDS<S, Rest...> { static constexpr int value = S::LDS_ROWS + SumLDS<Rest...>::value; };
+template <class... S> struct SumRV { static constexpr int value = 0; };
+template <class S, class... Rest> struct SumRV<S, Rest...> { static constexpr int value = S::RV + SumRV<Rest...>::value; };
+template <class... S> struct MaxRV { static constexpr int value = 0; };
+template <class S, class... Rest> struct MaxRV<S, Rest...> { static constexpr int value = S::RV > MaxRV<Rest...>::value ? S::RV : MaxRV<Rest...>::value; };
+template <class S, class...> struct FirstOf { typedef S type; };
+
+// REV: the wave walks its chunk bottom-up (rows are addressed with a negated pitch, so the
+// schedule below is unchanged); stages whose tap order depends on the row direction read it.
+template <class Px, bool REV, int T, int LdsIdx, class... S> struct Chain;
+
+// end of the chain: the store
+template <class Px, bool REV, int T, int LdsIdx> struct Chain<Px, REV, T, LdsIdx> {
+    RF_DEV void plan_backward(int oa, int ob, int, int, int& in_a, int& in_b) { in_a = oa; in_b = ob; }
+    RF_DEV int plan_forward(int tprev) { return tprev; }
+    template <int MODE> RF_DEV void step(bool has, const Tex<T>& v, int it, const Lane<T>&, Sink<T>& k, const ParamPack<>&)
+    {
+        constexpr bool STEADY = MODE != 0;
+        if (STEADY || has) {
+            // the row's values are computed HERE, under the full exec mask: left to itself hipcc sinks the
+            // last stage's arithmetic into the exec-masked store block and schedules it there as one
+            // serial chain per half texel with an s_nop between dependent packed fmas
+#pragma unroll
+            for (int j = 0; j < T; ++j) asm volatile("" ::"v"(v.v[j].x), "v"(v.v[j].y), "v"(v.v[j].z), "v"(v.v[j].w));
+            // exactly T vector-memory instructions per emitted row: Source::wait_row counts on it
+            // (every one of them has at least one active lane: see the strip placement in stream_kernel)
+#pragma unroll
+            for (int j = 0; j < T; ++j)
+                if (k.lane_ok[j]) Px::store(k.dst + (ptrdiff_t)k.row * k.pitch, k.xoff[j], v.v[j]);
+            k.row += 1;
+            if (!STEADY && k.first_store < 0) k.first_store = it;
+        }
+    }
+};
+
+template <class Px, bool REV, int T, int LdsIdx, class S, class... Rest> struct Chain<Px, REV, T, LdsIdx, S, Rest...> {
+    typename S::template State<Px, T> st;
+    // wave-uniform schedule
+    int a;        // first input row
+    int oa;       // first output row
+    int flush;    // replications of the last input row (frame bottom edge)
+    int tprev;    // iteration of the upstream stage's last emission
+    int cnt;      // input rows consumed
+    Chain<Px, REV, T, LdsIdx + S::LDS_ROWS, Rest...> next;
+
+    // given the rows the LAST stage must emit, derive what each stage must emit/consume
+    RF_DEV void plan_backward(int oa_last, int ob_last, int lo, int hi, int& in_a, int& in_b)
+    {
+        int need_a, need_b;
+        next.plan_backward(oa_last, ob_last, lo, hi, need_a, need_b);
+        oa = need_a;
+        a = max(lo, need_a - S::RV);
+        int b = min(hi, need_b + S::RV);
+        flush = need_b + S::RV - b;
+        cnt = 0;
+        in_a = a;
+        in_b = b;
+    }
+    RF_DEV int plan_forward(int tp)
+    {
+        tprev = tp;
+        return next.plan_forward(tp + flush);
+    }
+    RF_DEV f4* lds_of(const Lane<T>& L) const { return L.lds + LdsIdx * 64 * T; }
+    // A row (or a flush tick) enters this stage.  STEADY = every stage receives a real row,
+    // is past its first row and emits: the schedule tests fold away at compile time.
+    template <int MODE> RF_DEV void step(bool has_prev, const Tex<T>& v, int it, const Lane<T>& L, Sink<T>& k, const ParamPack<S, Rest...>& P)
+    {
+        constexpr bool STEADY = MODE != 0;
+        constexpr bool KEEP = MODE == 0 || MODE == 3;   // phases that may hold a stage's last real row
+        bool has = false;
+        Tex<T> out = tex_zero<T>();
+        if constexpr (STEADY) {
+            S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), v, true, false, true, out);
+            cnt += 1;
+            has = true;
+        } else if constexpr (S::RV == 0) {
+            if (has_prev) {              // row-local stage: one row in, one row out, never flushed
+                S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), v, true, cnt == 0, true, out);
+                cnt += 1;
+                has = true;
+            }
+        } else {
+            const bool flushing = !has_prev && it > tprev && it <= tprev + flush;
+            if (has_prev || flushing) {
+                has = (a + cnt - S::RV) >= oa;
+                S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), v, has_prev, cnt == 0, has, out);
+                cnt += 1;
+            }
+        }
+        next.template step<MODE>(has, out, it, L, k, P.rest);
+    }
+    // first stage: the row comes from the source feed; once it is consumed its ring slot is
+    // refilled and the NEXT row's values are fetched into registers
+    // MODE 0: generic (schedule tests).  Modes 1-3 are branch-free: every stage takes a real row
+    // and emits one.  1 = rows still being issued, stores of the last PF iterations not all
+    // there yet (wait on the loads alone); 2 = the steady state; 3 = every row issued already
+    // (the last PF source rows): nothing to issue, plain wait.
+    template <int MODE, class Feed, class Src>
+    RF_DEV void step_first(bool has0, Feed& feed, const Src& src, int it, const Lane<T>& L, Sink<T>& k, const ParamPack<S, Rest...>& P)
+    {
+        constexpr bool STEADY = MODE != 0;
+        constexpr bool KEEP = MODE == 0 || MODE == 3;
+        bool has = false;
+        Tex<T> out = tex_zero<T>();
+        if constexpr (STEADY) {
+            if constexpr (std::is_same<Feed, OwnFeed<Px, T>>::value)
+                S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), feed.own(), true, false, true, out);
+            else
+                out = S::template from_taps<T>(P.p, feed);
+            cnt += 1;
+            has = true;
+            if constexpr (MODE == 3) {
+                if (it + 1 < src.n0) {
+                    wait_vmcnt<0>();
+                    feed.fetch(src, it + 1, L);
+                }
+            } else {
+                src.issue(it + Src::SLOTS);
+                if constexpr (MODE == 1) wait_vmcnt<(Src::SLOTS - 1) * T>();
+                else wait_vmcnt<(2 * Src::SLOTS - 2) * T>();
+                feed.fetch(src, it + 1, L);
+            }
+        } else {
+            if constexpr (S::RV == 0) {
+                if (has0) {
+                    if constexpr (std::is_same<Feed, OwnFeed<Px, T>>::value)
+                        S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), feed.own(), true, cnt == 0, true, out);
+                    else
+                        out = S::template from_taps<T>(P.p, feed);
+                    cnt += 1;
+                    has = true;
+                }
+            } else {
+                const bool flushing = !has0 && it > tprev && it <= tprev + flush;
+                if (has0 || flushing) {
+                    has = (a + cnt - S::RV) >= oa;
+                    S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), feed.own(), has0, cnt == 0, has, out);
+                    cnt += 1;
+                }
+            }
+            if (has0) {
+                if (it + Src::SLOTS < src.n0) src.issue(it + Src::SLOTS);
+                if (it + 1 < src.n0) {
+                    src.wait_row(it + 1, k);
+                    feed.fetch(src, it + 1, L);
+                }
+            }
+        }
+        next.template step<MODE>(has, out, it, L, k, P.rest);
+    }
+};
+
+struct alignas(8) StreamHdr {
+    const char* src;
+    size_t src_pitch;
+    char* dst;
+    size_t dst_pitch;
+    int W, row_lo, row_hi, y0, y1, rows_per_chunk, n_strips;
+    int n_work;   // workgroups with work = strip groups x chunks (the grid is padded to a multiple of 8)
+    int alternate;   // odd chunks walk bottom-up (halo rows shared through L2)
+};
+template <class... S> struct StreamArgs : StreamHdr {
+    ParamPack<S...> params;      // at offset sizeof(StreamHdr) = 72
+};
+static_assert(sizeof(StreamHdr) == 72, "the host assembles kernel arguments as bytes: header, then the parameter slots");
+
+#ifndef RF_WAVES_PER_BLOCK
+#define RF_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = RF_WAVES_PER_BLOCK;
+
+// One wave's walk over rows [y0, y1) of its strip.  REV = bottom-up: rows are addressed with
+// negated pitches and mirrored bounds, so the schedule code sees an ordinary top-down walk.
+template <class Px, int PF, int T, bool REV, class... S>
+RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane<T>& L, int wave, char* ring_wave, unsigned ring_lds, int y0, int y1)
+{
+    constexpr int RH = SumRH<S...>::value;
+    typedef Source<Px, PF, T> Src;
+    typedef typename FirstOf<S...>::type::template Feed<Px, T> Feed;
+    (void)wave;
+
+    // the walk's own row coordinate v: v = y top-down, v = -y bottom-up
+    const int v0 = REV ? -(y1 - 1) : y0, v1 = REV ? -y0 + 1 : y1;
+    const int lo = REV ? -A.row_hi : A.row_lo, hi = REV ? -A.row_lo : A.row_hi;
+
+    Sink<T> k;
+    k.dst = A.dst;
+    k.pitch = REV ? -(ptrdiff_t)A.dst_pitch : (ptrdiff_t)A.dst_pitch;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        k.xoff[j] = (unsigned)min(max(L.col(j), 0), A.W - 1) * (unsigned)Px::BPP;
+        k.lane_ok[j] = (L.pos(j) >= RH) && (L.pos(j) < 64 * T - RH) && (L.col(j) < A.W);
+    }
+    k.row = v0;
+    k.first_store = -1;
+
+    Chain<Px, REV, T, 0, S...> chain;
+    Src src;
+    int b0;
+    chain.plan_backward(v0, v1 - 1, lo, hi, src.a0, b0);
+    src.n0 = b0 - src.a0 + 1;                        // source rows
+    const int total = chain.plan_forward(src.n0 - 1) + 1;
+
+    // source: rows a0..b0, column clamp(x)
+#pragma unroll
+    for (int j = 0; j < T; ++j) src.src[j] = A.src + k.xoff[j];
+    src.pitch = REV ? -(ptrdiff_t)A.src_pitch : (ptrdiff_t)A.src_pitch;
+    src.ring = ring_wave;
+    src.lds_base = ring_lds;
+    src.prologue();
+    Feed feed;
+    src.wait_row(0, k);
+    feed.fetch(src, 0, L);
+
+    // Phases: the generic loop (per-stage schedule tests) until the pipeline has emitted its
+    // first row -- from then on every stage takes a real row and emits one for as long as
+    // source rows arrive, and the branch-free modes run: 1 while the stores of the last PF
+    // iterations are not all there yet, 2 the steady state, 3 the last PF source rows (nothing
+    // left to issue) -- and the generic loop again for the bottom-edge flush.
+    int it = 0;
+    while (it < total && k.first_store < 0) {
+        chain.template step_first<0>(it < src.n0, feed, src, it, L, k, A.params);
+        ++it;
+    }
+    if (k.first_store >= 0) {
+        const int steady_end = src.n0 - PF;                      // iterations with a row left to issue
+        const int warm_end = min(k.first_store + PF, steady_end);
+        for (; it < warm_end; ++it) chain.template step_first<1>(true, feed, src, it, L, k, A.params);
+        for (; it < steady_end; ++it) chain.template step_first<2>(true, feed, src, it, L, k, A.params);
+        for (; it < src.n0; ++it) chain.template step_first<3>(true, feed, src, it, L, k, A.params);
+    }
+    for (; it < total; ++it) chain.template step_first<0>(it < src.n0, feed, src, it, L, k, A.params);
+}
+
+template <class Px, int PF, int T, class... S>
+__global__ __launch_bounds__(64 * kWavesPerBlock, T > 1 ? 2 : 1) void stream_kernel(const StreamArgs<S...> A)
+{
+    constexpr int RH = SumRH<S...>::value;
+    constexpr int VALID = 64 * T - 2 * RH;
+    constexpr int LDSR = SumLDS<S...>::value;
+    typedef Source<Px, PF, T> Src;
+    __shared__ f4 smem[kWavesPerBlock][(LDSR > 0 ? LDSR : 1) * 64 * T];
+    __shared__ __attribute__((aligned(16))) char ring[kWavesPerBlock][Src::SLOTS * Src::SLOT_BYTES];
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // XCD-aware block order (guide T1): blocks are dealt round-robin over the 8 XCDs, so block
+    // b and b+8 share an L2.  Give each XCD a CONTIGUOUS range of work items (strip groups
+    // fastest, then chunks): workgroups that share halo columns or halo rows then share an L2.
+    // Speed only -- any placement gives the same result.
+    const int gx = (A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int q = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (q >= A.n_work) return;
+    const int strip = (q % gx) * kWavesPerBlock + wave;
+    if (strip >= A.n_strips) return;                 // wave-uniform; no barriers below
+    const int chunk = q / gx;
+    const int y0 = A.y0 + chunk * A.rows_per_chunk;
+    const int y1 = min(y0 + A.rows_per_chunk, A.y1);
+    if (y0 >= y1) return;
+
+    Lane<T> L;
+    L.lane = (int)(threadIdx.x & 63);
+    L.x0 = strip * VALID - RH;
+    // T > 1: every one of the T stores of a row must have an active lane (the counted vmcnt waits
+    // assume T stores are really issued; hipcc branches around a store whose exec mask is empty).
+    // The last strip is therefore moved left until it ends at the frame edge -- it recomputes a
+    // few columns of its neighbour and writes the same values (the host launches T > 1 only when
+    // W >= 64 T and the launch is not in place).
+    if constexpr (T > 1) {
+        if (L.x0 + 64 * T - RH > A.W) L.x0 = A.W - 64 * T + RH;
+    }
+    L.W = A.W;
+    L.lds = smem[wave];
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&ring[0][0]) + (unsigned)wave * (unsigned)(Src::SLOTS * Src::SLOT_BYTES));
+
+    // Odd chunks walk bottom-up: a chunk and its neighbour then read the halo rows they
+    // share at the same moment (both at their start, or both at their end), so the second
+    // read is served by the XCD's L2 instead of the fabric.  Stencil-free pipelines have no
+    // halo and always walk top-down.
+    constexpr bool kHasHalo = SumRV<S...>::value > 0;
+    if (kHasHalo && A.alternate && (chunk & 1))
+        stream_wave<Px, PF, T, true, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
+    else
+        stream_wave<Px, PF, T, false, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
+}
+
+}  // namespace rf

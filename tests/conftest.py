@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# kernels compiled at graph creation (rf_jit.cpp) are kept on disk for the session: the parity tests build the same
+# fused chains many times, in several processes
+os.environ.setdefault("RF_JIT_CACHE_DIR", os.path.join(os.environ.get("TMPDIR", "/tmp"), "reforge_amd_jit_cache"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -181,10 +181,20 @@ def test_fusion_groups():
     assert p.launches() == ["blur+grade+sharp+wide+finish"]        # the whole BASELINE 5-stage chain is one launch
     assert p.halo_schedule(True) == ([7], [0], 0, 7)               # one exchange of 2+1+4 rows instead of three
     assert p.halo_schedule(False) == ([7], [0], 7, 7)              # over-fetch: the strip's input carries the 7 rows
-    # any other long chain splits greedily into the longest supported prefixes
+    # any other chain of fusable nodes is ONE launch too: its kernel is compiled when the graph is created (rf_jit.cpp) ...
     other = util.CHAIN5_SPLIT
     p = rf.Plan(rf.Config(other), 0)
-    assert p.launches() == ["blur+grade+sharp", "wide+finish"]
+    if rf.lib().rf_jit_available():
+        assert p.launches() == ["blur+grade+sharp+wide+finish"] and p.needs_jit() == [True]
+    # ... and with RF_GRAPH_NO_JIT it splits greedily into the longest prefixes the ahead-of-time catalogue holds
+    p = rf.Plan(rf.Config(other), rf.RF_GRAPH_NO_JIT)
+    assert p.launches() == ["blur+grade+sharp", "wide+finish"] and p.needs_jit() == [False, False]
+    # passthrough and gaussian{radius} nodes join chains; the admission rule keeps what a lane's registers can hold
+    mixed = "input -> aa -> bb -> cc -> dd -> output\naa: gaussian { sigma: 1.5, radius: 3 }\nbb: passthrough {}\ncc: sharpen { amount: 0.4 }\ndd: grade {}"
+    if rf.lib().rf_jit_available():
+        assert rf.Plan(rf.Config(mixed), 0).launches() == ["aa+bb+cc+dd"]
+        wide = "input -> aa -> bb -> output\naa: gaussian { sigma: 4.0, radius: 12 }\nbb: gaussian { sigma: 4.0, radius: 12 }"
+        assert rf.Plan(rf.Config(wide), 0).launches() == ["aa", "bb"]         # two radius-12 windows do not fit: not fused
     # a fused chain is planned as one node: the aliasing plan is recomputed on the fused
     # graph, so its output can never land on the image it reads
     assert p.resolve("rf:final-output") != "rf:file-input"
@@ -385,7 +395,9 @@ mx: combination { mix: 0.30 }"""
     assert info["n01"]["serial"] and info["n04"]["serial"]
     # with a single consumer the in-place node fuses like any other
     solo = "input -> n00 -> n01:image -> n02 -> output\nn00: sharpen {}\nn01: colour_grade {}\nn02: gaussian5 {}"
-    assert rf.Plan(rf.Config(solo), 0).launches() == ["n00+n01", "n02"] or rf.Plan(rf.Config(solo), 0).launches() == ["n00", "n01+n02"]
+    assert rf.Plan(rf.Config(solo), rf.RF_GRAPH_NO_JIT).launches() in (["n00+n01", "n02"], ["n00", "n01+n02"])
+    if rf.lib().rf_jit_available():
+        assert rf.Plan(rf.Config(solo), 0).launches() == ["n00+n01+n02"]
 
 
 def test_in_place_on_the_file_input_is_not_fused():
@@ -429,7 +441,9 @@ mx: combination { mix: 0.5 }"""
     assert sorted(rf.Plan(rf.Config(t), 0).launches()) == ["mx", "n00", "n01", "n02", "n03", "n04"]
     # the same run with no other reader fuses as before
     t = "input -> n00 -> n01:image -> n02:image -> output\nn00: gaussian5 {}\nn01: colour_grade {}\nn02: colour_grade {}"
-    assert len(rf.Plan(rf.Config(t), 0).launches()) == 2
+    assert len(rf.Plan(rf.Config(t), rf.RF_GRAPH_NO_JIT).launches()) == 2
+    if rf.lib().rf_jit_available():
+        assert rf.Plan(rf.Config(t), 0).launches() == ["n00+n01+n02"]
 
 
 def test_a_node_named_in_two_expressions_lists_its_output_once():

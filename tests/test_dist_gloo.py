@@ -135,7 +135,7 @@ def test_halo_schedules_kat():
     p = rf.Plan(rf.Config(util.CHAIN5), 0)                      # the whole chain is one launch
     assert [l["radius"] for l in p.launch_info()] == [7]
     assert p.halo_schedule(False) == ([7], [0], 7, 7)
-    two = util.CHAIN5.replace("gaussian9    { sigma: 2.0 }", "gaussian5    { sigma: 2.0 }")   # splits 3 + 2
-    p = rf.Plan(rf.Config(two), 0)
+    two = util.CHAIN5.replace("gaussian9    { sigma: 2.0 }", "gaussian5    { sigma: 2.0 }")   # catalogue-only fusion splits it 3 + 2
+    p = rf.Plan(rf.Config(two), rf.RF_GRAPH_NO_JIT)
     assert [l["radius"] for l in p.launch_info()] == [3, 2]
     assert p.halo_schedule(False) == ([5, 2], [2, 0], 5, 5)

@@ -384,6 +384,36 @@ def test_explicit_gaussian_weights_and_the_in_place_grade_type(ctx):
                 util.assert_same(util.run_hip(ctx, text, x, flags=flags), want, "flags %d\n%s" % (flags, text))
 
 
+JIT_CHAINS = [
+    "input -> aa -> bb -> cc -> dd -> ee -> output\naa: gaussian { sigma: 1.5, radius: 3 }\nbb: passthrough {}\ncc: sharpen { amount: 0.4 }\n"
+    "dd: colour_grade { slope: 1.1, offset: 0.01, saturation: 1.3 }\nee: gaussian5 { sigma: 0.8 }",
+    "input -> aa -> bb -> cc -> dd -> output\naa: sharpen { amount: 0.9 }\nbb: gaussian9 { sigma: 1.7 }\ncc: sharpen { amount: 0.2 }\ndd: gaussian { sigma: 0.7, radius: 1 }",
+    "input -> aa -> bb:image -> cc -> dd -> ee -> ff -> output\naa: gaussian5 { sigma: 1.1 }\nbb: colour_grade { slope: 0.9, offset: 0.02, saturation: 0.5 }\n"
+    "cc: passthrough {}\ndd: passthrough {}\nee: gaussian { sigma: 2.0, radius: 5 }\nff: colour_grade { slope: 1.0, offset: 0.0, saturation: 1.6 }",
+    "input -> aa -> bb -> cc -> output\naa: passthrough {}\nbb: passthrough {}\ncc: passthrough {}",
+    "input -> aa -> bb -> cc -> output\naa: gaussian { sigma: 2.5, radius: 7 }\nbb: colour_grade { slope: 1.2, offset: -0.05, saturation: 1.1 }\ncc: gaussian { sigma: 0.0, radius: 0 }",
+]
+
+
+@pytest.mark.parametrize("k", range(len(JIT_CHAINS)))
+def test_chains_compiled_at_graph_creation(ctx, k):
+    """Chains the ahead-of-time catalogue lacks: ONE launch whose kernel rf_graph_create compiled (rf_jit.cpp) from the
+    library's own device source.  Bit-identical to the oracle and to catalogue-only / unfused execution, both
+    formats, ragged sizes, several chunk heights, two texels per lane, a second graph reusing the loaded kernel."""
+    text = JIT_CHAINS[k]
+    p = rf.Plan(rf.Config(text))
+    assert len(p.launches()) == 1 and (p.needs_jit() == [True] or k == 3)      # (all-passthrough = the copy kernel)
+    before = rf.lib().rf_jit_compile_count()
+    for fmt in (util.F32, util.U8):
+        for W, H in ((67, 41), (300, 77), (129, 130)):
+            x = util.synthetic(W, H, fmt, seed=W)
+            want = util.run_oracle(text, x)
+            for kw in (dict(), dict(rows_per_chunk=19), dict(flags=rf.RF_GRAPH_NO_JIT), dict(flags=NF), dict(texels_per_lane=2),
+                       dict(exec_flags=rf.RF_EXEC_NO_ALTERNATE), dict(exec_flags=rf.RF_EXEC_FORCE_SPLIT)):
+                util.assert_same(util.run_hip(ctx, text, x, **kw), want, "jit chain %d %dx%d fmt=%d %r" % (k, W, H, fmt, kw))
+    assert rf.lib().rf_jit_compile_count() - before <= 4        # per format: the kernel and its two-texel variant, compiled once
+
+
 @pytest.mark.parametrize("t", [1, 2])
 @pytest.mark.parametrize("walk", ["alternate", "top-down"])
 def test_texels_per_lane_and_walk_direction(ctx, t, walk):
