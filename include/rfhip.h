@@ -156,7 +156,11 @@ const char* rf_plan_launch_label(const rf_plan* plan, int i);
 int         rf_plan_launch_layer(const rf_plan* plan, int i);
 int         rf_plan_launch_num_members(const rf_plan* plan, int i);
 const char* rf_plan_launch_member(const rf_plan* plan, int i, int k);
-/* allocated images a launch reads (1; 2 for `combination`) and writes */
+/* a fused fork/join launch (two branches from one image + the `combination` that joins them) lists the nodes of the branch
+ * feeding input_image0 (slot 1), then those of the branch feeding input_image1 (slot 2), then the join (slot 0); every member
+ * of any other launch has slot 0 */
+int         rf_plan_launch_member_slot(const rf_plan* plan, int i, int k);
+/* allocated images a launch reads (1; 2 for an unfused `combination`) and writes */
 int         rf_plan_launch_num_inputs(const rf_plan* plan, int i);
 const char* rf_plan_launch_input(const rf_plan* plan, int i, int k);
 const char* rf_plan_launch_output(const rf_plan* plan, int i);

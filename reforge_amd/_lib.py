@@ -84,6 +84,7 @@ SIGNATURES = {
     "rf_plan_launch_layer": (_i, [_vp, _i]),
     "rf_plan_launch_num_members": (_i, [_vp, _i]),
     "rf_plan_launch_member": (_cp, [_vp, _i, _i]),
+    "rf_plan_launch_member_slot": (_i, [_vp, _i, _i]),
     "rf_plan_launch_num_inputs": (_i, [_vp, _i]),
     "rf_plan_launch_input": (_cp, [_vp, _i, _i]),
     "rf_plan_launch_output": (_cp, [_vp, _i]),

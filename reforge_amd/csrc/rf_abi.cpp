@@ -284,12 +284,18 @@ extern "C" rf_status rf_plan_halo_schedule(const rf_plan* p, int exchange, int* 
 extern "C" int rf_jit_available(void) { return jit_available() ? 1 : 0; }
 extern "C" int rf_jit_compile_count(void) { return jit_compile_count(); }
 
+extern "C" int rf_plan_launch_member_slot(const rf_plan* p, int i, int k)
+{
+    const LaunchDesc* l = launch_at(p, i);
+    if (!l || k < 0 || k >= (int)l->members.size()) return -1;
+    return k < (int)l->member_slot.size() ? l->member_slot[(size_t)k] : 0;
+}
+
 extern "C" int rf_plan_launch_needs_jit(const rf_plan* p, int i)
 {
     const LaunchDesc* l = launch_at(p, i);
     if (!l) return -1;
-    std::vector<Op> ops;
-    for (const auto& m : l->members) ops.push_back(p->plan.nodes.at(m).to_op(nullptr));
+    std::vector<Op> ops = ops_of_members(p->plan, l->members, l->member_slot, nullptr);
     StageList sl;
     if (ops.size() < 2 || !ops_to_stages(ops.data(), (int)ops.size(), sl)) return 0;
     return stream_in_catalogue(sl) ? 0 : 1;
@@ -302,8 +308,7 @@ extern "C" rf_status rf_plan_jit_compile(const rf_plan* p, int format, size_t* c
     if (format != RF_FORMAT_RGBA8 && format != RF_FORMAT_RGBA32F) return fail(RF_ERR_INVALID, "rf_plan_jit_compile: unknown format");
     size_t total = 0;
     for (const auto& l : p->launches) {
-        std::vector<Op> ops;
-        for (const auto& m : l.members) ops.push_back(p->plan.nodes.at(m).to_op(nullptr));
+        std::vector<Op> ops = ops_of_members(p->plan, l.members, l.member_slot, nullptr);
         StageList sl;
         if (ops.size() < 2 || !ops_to_stages(ops.data(), (int)ops.size(), sl) || stream_in_catalogue(sl)) continue;
         std::string err;

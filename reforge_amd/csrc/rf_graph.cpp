@@ -274,12 +274,7 @@ rf_status issue_frame(rf_graph* g, FrameSlot& f, bool timers)
 void rebuild_ops(rf_graph* g)
 {
     for (auto& L : g->launches) {
-        L.ops.clear();
-        for (const auto& m : L.members) {
-            const NodeParams& np = g->plan.plan.nodes.at(m);
-            auto it = g->dev_weights.find(m);
-            L.ops.push_back(np.to_op(it == g->dev_weights.end() ? nullptr : it->second));
-        }
+        L.ops = ops_of_members(g->plan.plan, L.members, L.member_slot, &g->dev_weights);
     }
 }
 
@@ -481,8 +476,7 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
         bool ok = g->plan.launch_error.empty();
         for (const auto& d : g->plan.launches) {
             if (!ok) break;
-            std::vector<Op> ops;
-            for (const auto& m : d.members) ops.push_back(g->plan.plan.nodes.at(m).to_op(nullptr));
+            std::vector<Op> ops = ops_of_members(g->plan.plan, d.members, d.member_slot, nullptr);
             if (ops.size() < 2) continue;
             std::string jerr;
             if (!stream_prepare(opt.format, ops.data(), (int)ops.size(), opt.width, Hs1 - Hs0, g->tune, jerr)) {

@@ -41,6 +41,8 @@ struct Op {
     float slope = 0, offset = 0, saturation = 0;   // grade (slope doubles as the mix factor of OP_MIX)
     float wc = 1, ws = 0;            // sharpen centre / side weight
     const float* dev_weights = nullptr;   // conv2d: device pointer, [K][K]
+    int   slot = 0;                  // inside a fused fork/join launch: 1 = node of the branch feeding input_image0, 2 = of the branch
+                                     // feeding input_image1; 0 = before the fork, the join itself, after the join, or a plain chain
 };
 
 // A 2-D image (or a row strip of one with ghost rows): `base` addresses local row 0,
@@ -68,11 +70,13 @@ struct StreamTuning {
 
 // Row stages of a streaming launch (rf_stream_dev.h): the run-time description that selects -- or, for a list the
 // ahead-of-time catalogue lacks, GENERATES -- the kernel, and lays out its parameter block.
-enum StageKind : int { ST_NODE_END = 0, ST_HTAP = 1, ST_VTAP = 2, ST_GRADE = 3, ST_CROSS3 = 4 };
+enum StageKind : int { ST_NODE_END = 0, ST_HTAP = 1, ST_VTAP = 2, ST_GRADE = 3, ST_CROSS3 = 4, ST_DUP = 5, ST_MIX = 6 };
+enum StageSlot : int { SLOT_PLAIN = 0, SLOT_SOLO = 1, SLOT_ON0 = 2, SLOT_ON1 = 3 };   // wrapper of a stage in a fork/join (pair) pipeline
 struct StageList {
-    static constexpr int kMax = 3 * kMaxFusedOps;
+    static constexpr int kMax = 3 * kMaxFusedOps + 4;
     int n = 0;
-    struct { int kind, r; } st[kMax];
+    struct { int kind, r, slot, op; } st[kMax];   // op: index of the node (in the launch's op list) whose parameters the stage takes, -1 none
+    bool pair() const { return n > 0 && st[0].slot != SLOT_PLAIN; }
     std::string key() const;          // "H2 V2 E G E C ": catalogue / cache key
     std::string type_list() const;    // "rf::StHTap<2>, rf::StVTap<2>, ...": the template arguments of stream_kernel
     int sum_rh() const, sum_rv() const, max_rv() const, taps() const;

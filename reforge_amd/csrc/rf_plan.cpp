@@ -340,12 +340,12 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
     }
     auto next_of = [&](const std::string& n) -> std::string {
         const PipelineInfo& p = infos.at(n);
-        if (!is_simple(p)) return "";
+        if (!is_simple(p) || p.members.size() != 1) return "";          // (a fused fork/join unit stays a launch of its own)
         const std::string& r = p.output_images[0].first;
         if (r == kFinalOutput || r == kFileInput) return "";
         if (producers[r].size() != 1 || consumers[r].size() != 1) return "";
         const std::string& c = consumers[r][0];
-        if (c == n || !is_simple(infos.at(c))) return "";
+        if (c == n || !is_simple(infos.at(c)) || infos.at(c).members.size() != 1) return "";
         return c;
     };
     std::map<std::string, std::string> prev_of;
@@ -386,6 +386,96 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
         }
         return true;
     };
+    // ---- fork/join: a `combination` node whose two inputs descend from ONE image through chains of simple nodes is ONE
+    // launch (rf_stream_dev.h "Fork / join in ONE launch"): branch results are never stored, the forked image is read once.
+    // Conservative: no in-place node in a branch, every branch image has one producer and one consumer.
+    struct Diamond { std::vector<std::string> a, b; std::string mix, src; };
+    std::vector<Diamond> diamonds;
+    std::set<std::string> in_diamond;
+    for (const auto& kv : infos) {
+        const PipelineInfo& m = kv.second;
+        if (plan.nodes.at(kv.first).type->kind != OP_MIX || m.input_images.size() != 2 || m.output_images.size() != 1) continue;
+        std::string in0, in1;
+        for (const auto& in : m.input_images) (in.second == 0 ? in0 : in1) = in.first;
+        if (in0.empty() || in1.empty() || in0 == in1) continue;
+        auto trace = [&](std::string res, std::vector<std::string>& nodes, std::vector<std::string>& sources) {
+            // walk upstream while the image has ONE simple, not-in-place producer and this walk is its only consumer
+            sources.push_back(res);
+            for (;;) {
+                if (res == kFileInput || producers[res].size() != 1 || consumers[res].size() != 1) return;
+                const std::string& n = producers[res][0];
+                const PipelineInfo& pi = infos.at(n);
+                const int kind = plan.nodes.at(n).type->kind;
+                if (!is_simple(pi) || in_place(pi) || kind == OP_MIX || kind == OP_CONV2D) return;
+                nodes.insert(nodes.begin(), n);
+                res = pi.input_images[0].first;
+                sources.push_back(res);
+            }
+        };
+        std::vector<std::string> na, nb, sa, sb;
+        trace(in0, na, sa);
+        trace(in1, nb, sb);
+        // the nearest common image: branch a = nodes below it on a's walk, same for b
+        std::string common;
+        size_t ia = 0, ib = 0;
+        for (ia = 0; ia < sa.size() && common.empty(); ++ia)
+            for (ib = 0; ib < sb.size(); ++ib)
+                if (sa[ia] == sb[ib]) { common = sa[ia]; break; }
+        if (common.empty()) continue;
+        --ia;                                         // sa[ia] == sb[ib] == common; nodes below: the last ia (ib) of na (nb)
+        Diamond d;
+        d.a.assign(na.end() - (ptrdiff_t)ia, na.end());
+        d.b.assign(nb.end() - (ptrdiff_t)ib, nb.end());
+        if (d.a.empty() && d.b.empty()) continue;
+        d.mix = kv.first;
+        d.src = common;
+        // the common image is read by BOTH walks: consumers[common] holds two entries for them; anything inside a branch
+        // must have been single-consumer (trace), which the common image itself need not be
+        bool clash = false;
+        for (const auto& n : d.a) clash = clash || in_diamond.count(n);
+        for (const auto& n : d.b) clash = clash || in_diamond.count(n);
+        if (clash || in_diamond.count(d.mix)) continue;
+        std::vector<std::string> members = d.a;
+        members.insert(members.end(), d.b.begin(), d.b.end());
+        members.push_back(d.mix);
+        std::vector<int> slots(d.a.size(), 1);
+        slots.insert(slots.end(), d.b.size(), 2);
+        slots.push_back(0);
+        if (members.size() > (size_t)kMaxFusedOps) continue;
+        std::vector<Op> ops = ops_of_members(plan, members, slots, nullptr);
+        if (!stream_supported(ops.data(), (int)ops.size(), allow_jit)) continue;
+        for (const auto& n : members) in_diamond.insert(n);
+        diamonds.push_back(d);
+    }
+    for (const auto& d : diamonds) {
+        PipelineInfo f;
+        for (const auto& n : d.a) { f.members.push_back(n); f.member_slot.push_back(1); }
+        for (const auto& n : d.b) { f.members.push_back(n); f.member_slot.push_back(2); }
+        f.members.push_back(d.mix);
+        f.member_slot.push_back(0);
+        for (size_t k = 0; k < f.members.size(); ++k) f.name += (k ? "+" : "") + f.members[k];
+        f.input_images = {{d.src, 1000}};
+        f.output_images = {{infos.at(d.mix).output_images[0].first, 1001}};
+        for (const auto& n : f.members) infos.erase(n);
+        infos[f.name] = f;
+    }
+    if (!diamonds.empty()) {                          // the maps below describe the graph with the fused units in it
+        producers.clear();
+        consumers.clear();
+        for (const auto& kv : infos) {
+            for (const auto& o : kv.second.output_images) producers[o.first].push_back(kv.first);
+            for (const auto& i : kv.second.input_images) consumers[i.first].push_back(kv.first);
+        }
+        prev_of.clear();
+        for (const auto& kv : infos) {
+            std::string nx = next_of(kv.first);
+            if (!nx.empty()) prev_of[nx] = kv.first;
+        }
+        root_memo.clear();
+        readers_of_root.clear();
+        for (const auto& kv : infos)
+            for (const auto& in : kv.second.input_images) readers_of_root[root_of(in.first)].insert(kv.first);
+    }
     std::vector<std::vector<std::string>> groups;
     for (const auto& kv : infos) {
         if (prev_of.count(kv.first)) continue;   // not a chain head
@@ -400,8 +490,7 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
         while (i < chain.size()) {
             size_t best = 1;
             for (size_t len = std::min(chain.size() - i, (size_t)kMaxFusedOps); len >= 2; --len) {
-                std::vector<Op> ops;
-                for (size_t k = 0; k < len; ++k) ops.push_back(plan.nodes.at(chain[i + k]).to_op(nullptr));
+                std::vector<Op> ops = ops_of_members(plan, std::vector<std::string>(chain.begin() + i, chain.begin() + i + len), {}, nullptr);
                 if (!stream_supported(ops.data(), (int)len, allow_jit)) continue;
                 if (!side_effects_stay_inside(std::vector<std::string>(chain.begin() + i, chain.begin() + i + len))) continue;
                 best = len;
@@ -494,6 +583,23 @@ bool build_plan(const Config& cfg, uint32_t flags, Plan& plan, std::string& err)
     return true;
 }
 
+std::vector<Op> ops_of_members(const Plan& plan, const std::vector<std::string>& members, const std::vector<int>& member_slot,
+                               const std::map<std::string, float*>* dev_weights)
+{
+    std::vector<Op> ops;
+    for (size_t k = 0; k < members.size(); ++k) {
+        const float* w = nullptr;
+        if (dev_weights) {
+            auto it = dev_weights->find(members[k]);
+            if (it != dev_weights->end()) w = it->second;
+        }
+        Op op = plan.nodes.at(members[k]).to_op(w);
+        op.slot = k < member_slot.size() ? member_slot[k] : 0;
+        ops.push_back(op);
+    }
+    return ops;
+}
+
 static bool point_kind(int kind) { return kind == OP_PASSTHROUGH || kind == OP_GRADE; }
 
 bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string& err)
@@ -517,6 +623,7 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
             LaunchDesc L;
             L.label = unit;
             L.members = info.members;
+            L.member_slot = info.member_slot;
             L.layer = (int)layer;
             const int kind0 = plan.nodes.at(info.members[0]).type->kind;
             if (info.input_images.empty()) {
@@ -553,11 +660,8 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
                 }
             }
             bool all_point = true;
-            std::vector<Op> ops;
-            for (const auto& m : L.members) {
-                ops.push_back(plan.nodes.at(m).to_op(nullptr));
-                all_point = all_point && point_kind(ops.back().kind);
-            }
+            std::vector<Op> ops = ops_of_members(plan, L.members, L.member_slot, nullptr);
+            for (const auto& o : ops) all_point = all_point && point_kind(o.kind);
             L.radius = ops_radius(ops.data(), (int)ops.size());
             if (kind0 != OP_MIX && L.src[0] == L.dst && !all_point) {
                 err = "node '" + unit + "' would run a stencil in place";

@@ -53,6 +53,7 @@ ParamValue parse_param(const std::string* text, ParamType type);
 struct PipelineInfo {
     std::string name;                                      // node name, or "a+b+c" for a fused chain
     std::vector<std::string> members;                      // node names in execution order (1 unless fused)
+    std::vector<int> member_slot;                          // per member: 0, or 1 / 2 = node of the branch feeding input_image0 / 1 of a fused fork/join (empty = all 0)
     std::vector<std::pair<std::string, int>> input_images; // (resource name, binding)
     std::vector<std::pair<std::string, int>> output_images;
 };
@@ -82,6 +83,7 @@ struct Plan {
 struct LaunchDesc {
     std::string label;              // planned unit: node name or "a+b+c"
     std::vector<std::string> members;
+    std::vector<int> member_slot;   // as PipelineInfo::member_slot
     int layer = 0;
     std::vector<std::string> src;   // allocated image names (1; 2 for OP_MIX in binding order)
     std::string dst;                // allocated image name
@@ -91,6 +93,10 @@ struct LaunchDesc {
     bool serial = false;            // its layer holds a launch that writes an image another launch of the layer touches: the
                                     // layer runs in plan (name) order on one stream instead of concurrently
 };
+
+// device ops of a planned unit's members, in order, with their fork/join slots (weights: node name -> device pointer, may be null)
+std::vector<Op> ops_of_members(const Plan& plan, const std::vector<std::string>& members, const std::vector<int>& member_slot,
+                               const std::map<std::string, float*>* dev_weights);
 
 // planned units -> launches; validates what the kernels can execute (one input image,
 // two for `combination`; one output image; no in-place stencil)

@@ -88,19 +88,36 @@ static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo
 // the instantiation, otherwise compiled at graph creation (rf_jit.cpp) -- and lays out the
 // parameter block, which the host assembles as bytes (ParamPack in rf_stream_dev.h).
 // ---------------------------------------------------------------------------------
+static std::string stage_letter(int kind, int r)
+{
+    switch (kind) {
+        case ST_HTAP: return "H" + std::to_string(r);
+        case ST_VTAP: return "V" + std::to_string(r);
+        case ST_GRADE: return "G";
+        case ST_CROSS3: return "C";
+        case ST_DUP: return "D";
+        case ST_MIX: return "M";
+        default: return "E";
+    }
+}
+static std::string stage_type(int kind, int r)
+{
+    switch (kind) {
+        case ST_HTAP: return "rf::StHTap<" + std::to_string(r) + ">";
+        case ST_VTAP: return "rf::StVTap<" + std::to_string(r) + ">";
+        case ST_GRADE: return "rf::StGrade";
+        case ST_CROSS3: return "rf::StCross3";
+        case ST_DUP: return "rf::StDup";
+        case ST_MIX: return "rf::StMix";
+        default: return "rf::StNodeEnd";
+    }
+}
+
 std::string StageList::key() const
 {
+    static const char* pre[] = {"", "s", "a", "b"};
     std::string k;
-    for (int i = 0; i < n; ++i) {
-        switch (st[i].kind) {
-            case ST_HTAP: k += "H" + std::to_string(st[i].r); break;
-            case ST_VTAP: k += "V" + std::to_string(st[i].r); break;
-            case ST_GRADE: k += "G"; break;
-            case ST_CROSS3: k += "C"; break;
-            default: k += "E"; break;
-        }
-        k += ' ';
-    }
+    for (int i = 0; i < n; ++i) k += pre[st[i].slot] + stage_letter(st[i].kind, st[i].r) + ' ';
     return k;
 }
 
@@ -108,21 +125,19 @@ std::string StageList::type_list() const
 {
     std::string t;
     for (int i = 0; i < n; ++i) {
-        switch (st[i].kind) {
-            case ST_HTAP: t += "rf::StHTap<" + std::to_string(st[i].r) + ">"; break;
-            case ST_VTAP: t += "rf::StVTap<" + std::to_string(st[i].r) + ">"; break;
-            case ST_GRADE: t += "rf::StGrade"; break;
-            case ST_CROSS3: t += "rf::StCross3"; break;
-            default: t += "rf::StNodeEnd"; break;
-        }
+        const std::string base = stage_type(st[i].kind, st[i].r);
+        if (st[i].kind == ST_DUP || st[i].kind == ST_MIX || st[i].slot == SLOT_PLAIN) t += base;
+        else if (st[i].slot == SLOT_SOLO) t += "rf::StSolo<" + base + ">";
+        else t += std::string("rf::StOn<") + (st[i].slot == SLOT_ON0 ? "0" : "1") + ", " + base + ">";
         if (i + 1 < n) t += ", ";
     }
     return t;
 }
 
+static int stage_rv(int kind, int r) { return kind == ST_VTAP ? r : (kind == ST_CROSS3 ? 1 : 0); }
 int StageList::sum_rh() const { int v = 0; for (int i = 0; i < n; ++i) v += (st[i].kind == ST_HTAP) ? st[i].r : (st[i].kind == ST_CROSS3 ? 1 : 0); return v; }
-int StageList::sum_rv() const { int v = 0; for (int i = 0; i < n; ++i) v += (st[i].kind == ST_VTAP) ? st[i].r : (st[i].kind == ST_CROSS3 ? 1 : 0); return v; }
-int StageList::max_rv() const { int v = 0; for (int i = 0; i < n; ++i) v = std::max(v, (st[i].kind == ST_VTAP) ? st[i].r : (st[i].kind == ST_CROSS3 ? 1 : 0)); return v; }
+int StageList::sum_rv() const { int v = 0; for (int i = 0; i < n; ++i) v += stage_rv(st[i].kind, st[i].r); return v; }
+int StageList::max_rv() const { int v = 0; for (int i = 0; i < n; ++i) v = std::max(v, stage_rv(st[i].kind, st[i].r)); return v; }
 int StageList::taps() const
 {
     int v = 0;
@@ -130,14 +145,15 @@ int StageList::taps() const
     return v;
 }
 // registers the pipeline's loop-carried state takes (vertical windows / running sums, the sharpen rows, the first
-// stage's prefetched taps) + a fixed allowance: what decides whether a list may be fused at all
+// stage's prefetched taps, the delay lines of a fork/join) + a fixed allowance: what decides whether a list may be fused at all
 int StageList::vgpr_estimate(int texels) const
 {
-    int v = 56;
+    int v = 56 + (pair() ? 16 : 0);
     for (int i = 0; i < n; ++i) {
         if (st[i].kind == ST_VTAP) v += 4 * texels * (2 * st[i].r + 1);
         if (st[i].kind == ST_CROSS3) v += 16 * texels;
-        if (st[i].kind == ST_HTAP) v += (i == 0 && texels == 1 && st[i].r <= 7) ? 4 * (2 * st[i].r + 1) : 0;
+        if (st[i].kind == ST_HTAP) v += (i == 0 && texels == 1 && st[i].r <= 7 && !pair()) ? 4 * (2 * st[i].r + 1) : 0;
+        if (st[i].slot == SLOT_ON0 || st[i].slot == SLOT_ON1) v += 4 * texels * stage_rv(st[i].kind, st[i].r);     // the other slot's delay line
     }
     int transient = 0;
     for (int i = 0; i < n; ++i)
@@ -145,35 +161,82 @@ int StageList::vgpr_estimate(int texels) const
     return v + transient / 2;
 }
 
+// ops -> stages.  A plain chain: the nodes' stages with a boundary (the store + load the unfused graph performs) between
+// nodes.  A fork/join launch (ops carry slot 1 / 2 for the two branches, one OP_MIX is the join): nodes before the fork,
+// StDup, branch 0, branch 1, a boundary per non-empty branch, StMix, nodes after the join -- every stage wrapped for the
+// pair pipeline (rf_stream_dev.h, "Fork / join in ONE launch").
 bool ops_to_stages(const Op* ops, int n, StageList& out)
 {
     out.n = 0;
-    auto push = [&](int kind, int r) {
+    int mix = -1;
+    for (int i = 0; i < n; ++i)
+        if (ops[i].kind == OP_MIX) { if (mix >= 0) return false; mix = i; }
+    const bool pair = mix >= 0;
+    auto push = [&](int kind, int r, int slot, int op) {
         if (out.n >= StageList::kMax) return false;
         out.st[out.n].kind = kind;
         out.st[out.n].r = r;
+        out.st[out.n].slot = slot;
+        out.st[out.n].op = op;
         ++out.n;
         return true;
     };
-    for (int i = 0; i < n; ++i) {
-        // node boundary inside a chain: the store + load the unfused graph performs.  A passthrough node IS such a
-        // boundary and nothing else; two boundaries in a row are one (re-quantising twice changes nothing).
-        // (a LEADING passthrough is the load itself: no stage at all)
-        if (i > 0 && out.n > 0 && out.st[out.n - 1].kind != ST_NODE_END)
-            if (!push(ST_NODE_END, 0)) return false;
-        switch (ops[i].kind) {
-            case OP_PASSTHROUGH: break;
-            case OP_GAUSSIAN:
-                if (ops[i].radius < 0 || ops[i].radius > kMaxRadius) return false;
-                if (!push(ST_HTAP, ops[i].radius) || !push(ST_VTAP, ops[i].radius)) return false;
-                break;
-            case OP_GRADE: if (!push(ST_GRADE, 0)) return false; break;
-            case OP_SHARPEN: if (!push(ST_CROSS3, 0)) return false; break;
-            default: return false;     // conv2d, combination: kernels of their own
+    auto last_is_end = [&](int slot) { return out.n > 0 && out.st[out.n - 1].kind == ST_NODE_END && out.st[out.n - 1].slot == slot; };
+    // the stages of nodes [from, to) whose op.slot == want, wrapped as `slot`; `started`: something of this run came before (a
+    // boundary goes between nodes; a LEADING passthrough is the load itself, no stage at all)
+    auto run = [&](int from, int to, int want, int slot) {
+        bool started = false;
+        for (int i = from; i < to; ++i) {
+            if (ops[i].slot != want || ops[i].kind == OP_MIX) continue;
+            if (started && !last_is_end(slot))
+                if (!push(ST_NODE_END, 0, slot, -1)) return false;
+            switch (ops[i].kind) {
+                case OP_PASSTHROUGH: break;
+                case OP_GAUSSIAN:
+                    if (ops[i].radius < 0 || ops[i].radius > kMaxRadius) return false;
+                    if (!push(ST_HTAP, ops[i].radius, slot, i) || !push(ST_VTAP, ops[i].radius, slot, i)) return false;
+                    started = true;
+                    break;
+                case OP_GRADE: if (!push(ST_GRADE, 0, slot, i)) return false; started = true; break;
+                case OP_SHARPEN: if (!push(ST_CROSS3, 0, slot, i)) return false; started = true; break;
+                default: return false;     // conv2d: a kernel of its own
+            }
         }
+        return true;
+    };
+    if (!pair) {
+        for (int i = 0; i < n; ++i)
+            if (ops[i].slot != 0) return false;
+        if (!run(0, n, 0, SLOT_PLAIN)) return false;
+        if (out.n == 0) return push(ST_NODE_END, 0, SLOT_PLAIN, -1);      // a chain of passthroughs: the copy kernel
+        if (out.st[out.n - 1].kind == ST_NODE_END && out.n > 1) --out.n;   // a trailing boundary is the final store itself
+        return true;
     }
-    if (out.n == 0) return push(ST_NODE_END, 0);      // a chain of passthroughs: the copy kernel
-    if (out.st[out.n - 1].kind == ST_NODE_END && out.n > 1) --out.n;   // a trailing boundary is the final store itself
+    // ops order of a fork/join launch: [before the fork (slot 0)] [branch 0 (slot 1)] [branch 1 (slot 2)] [OP_MIX] [after the join (slot 0)]
+    int first_branch = mix;
+    for (int i = 0; i < mix; ++i)
+        if (ops[i].slot != 0) { first_branch = i; break; }
+    for (int i = first_branch; i < mix; ++i)
+        if (ops[i].slot == 0) return false;
+    for (int i = mix + 1; i < n; ++i)
+        if (ops[i].slot != 0) return false;
+    if (!run(0, first_branch, 0, SLOT_SOLO)) return false;
+    if (out.n > 0 && !last_is_end(SLOT_SOLO) && !push(ST_NODE_END, 0, SLOT_SOLO, -1)) return false;   // the forked image is stored and loaded
+    if (!push(ST_DUP, 0, SLOT_SOLO, -1)) return false;
+    for (int b = 0; b < 2; ++b) {
+        const int before = out.n, slot = b == 0 ? SLOT_ON0 : SLOT_ON1;
+        if (!run(first_branch, mix, b + 1, slot)) return false;
+        if (out.n > before && !last_is_end(slot) && !push(ST_NODE_END, 0, slot, -1)) return false;    // the branch result is stored and loaded by the join
+    }
+    if (!push(ST_MIX, 0, SLOT_SOLO, mix)) return false;
+    const int after = out.n;
+    bool any_after = false;
+    for (int i = mix + 1; i < n; ++i) any_after = any_after || ops[i].kind != OP_PASSTHROUGH;
+    if (any_after) {
+        if (!push(ST_NODE_END, 0, SLOT_SOLO, -1)) return false;
+        if (!run(mix + 1, n, 0, SLOT_SOLO)) return false;
+        if (out.n > after && last_is_end(SLOT_SOLO)) --out.n;
+    }
     return true;
 }
 
@@ -181,13 +244,6 @@ bool ops_to_stages(const Op* ops, int n, StageList& out)
 static size_t param_bytes(const StageList& sl, const Op* ops, int n_ops, unsigned char* buf, size_t cap)
 {
     size_t off = 0;
-    int node = 0;
-    // stage -> node: a boundary stage closes a node; leading passthrough nodes own no stage at all
-    auto next_real_node = [&](int from) {
-        while (from < n_ops && ops[from].kind == OP_PASSTHROUGH) ++from;
-        return from;
-    };
-    node = next_real_node(0);
     std::memset(buf, 0, cap);
     for (int i = 0; i < sl.n; ++i) {
         const int kind = sl.st[i].kind, r = sl.st[i].r;
@@ -196,11 +252,11 @@ static size_t param_bytes(const StageList& sl, const Op* ops, int n_ops, unsigne
         else if (kind == ST_GRADE) size = 16;
         if (off + size + 8 > cap) return 0;
         unsigned char* p = buf + off;
-        const Op* op = node < n_ops ? &ops[node] : nullptr;
+        const Op* op = (sl.st[i].op >= 0 && sl.st[i].op < n_ops) ? &ops[sl.st[i].op] : nullptr;
         if ((kind == ST_HTAP || kind == ST_VTAP) && op) {
             for (int k = 0; k <= r; ++k) {
-                const float pair[2] = {op->w[k], op->w[k]};
-                std::memcpy(p + 8 * k, pair, 8);
+                const float pr[2] = {op->w[k], op->w[k]};
+                std::memcpy(p + 8 * k, pr, 8);
             }
         } else if (kind == ST_GRADE && op) {
             const float g[3] = {op->slope, op->offset, op->saturation};
@@ -208,9 +264,10 @@ static size_t param_bytes(const StageList& sl, const Op* ops, int n_ops, unsigne
         } else if (kind == ST_CROSS3 && op) {
             const float c[2] = {op->wc, op->ws};
             std::memcpy(p, c, 8);
+        } else if (kind == ST_MIX && op) {
+            std::memcpy(p, &op->slope, 4);       // OP_MIX keeps its factor in `slope`
         }
         off += size;
-        if (kind == ST_NODE_END) node = next_real_node(node + 1);
     }
     return off + 8;     // the closing empty slot
 }
@@ -293,6 +350,10 @@ template <int R> struct StageKey<StVTap<R>> { static std::string get() { return 
 template <> struct StageKey<StGrade> { static std::string get() { return "G "; } };
 template <> struct StageKey<StCross3> { static std::string get() { return "C "; } };
 template <> struct StageKey<StNodeEnd> { static std::string get() { return "E "; } };
+template <> struct StageKey<StDup> { static std::string get() { return "sD "; } };
+template <> struct StageKey<StMix> { static std::string get() { return "sM "; } };
+template <class S> struct StageKey<StSolo<S>> { static std::string get() { return "s" + StageKey<S>::get(); } };
+template <int K, class S> struct StageKey<StOn<K, S>> { static std::string get() { return (K == 0 ? "a" : "b") + StageKey<S>::get(); } };
 
 #ifndef RF_PF_DEFAULT
 #define RF_PF_DEFAULT 4
@@ -319,7 +380,7 @@ template <int PF, class... S> static void add_to_catalogue(TL<S...>)
     e.fn[kFmtRGBA8][1] = &launch_aot<PxU8, PF, 1, S...>;
     e.fn[kFmtRGBA32F][1] = &launch_aot<PxF32, PF, 1, S...>;
     // two texels per lane: rgba32f only, and only where the doubled state still fits 256 VGPRs
-    if constexpr (SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4) e.fn[kFmtRGBA32F][2] = &launch_aot<PxF32, (PF > 4 ? 4 : PF), 2, S...>;
+    if constexpr (SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4 && MaxSlots<S...>::value == 1) e.fn[kFmtRGBA32F][2] = &launch_aot<PxF32, (PF > 4 ? 4 : PF), 2, S...>;
 }
 
 // The ahead-of-time catalogue: every node alone (gaussian radius 0..15), every ordered pair of
@@ -365,6 +426,8 @@ static const std::map<std::string, AotEntry>& built_catalogue()
         typedef typename Join<NodeTL<0>::type, GradeSharp>::type Head;
         typedef typename Join<NodeTL<1>::type, NodeTL<2>::type>::type Tail;
         add_to_catalogue<PF_DEFAULT>(typename Join<Head, Tail>::type{});      // gaussian5 -> grade -> sharpen -> gaussian9 -> grade
+        // the fork/join example of pipeline_graph.rs:462-468 (gaussian5 || sharpen -> combination) as ONE launch
+        add_to_catalogue<PF_DEFAULT>(TL<StDup, StOn<0, StHTap<2>>, StOn<0, StVTap<2>>, StOn<0, StNodeEnd>, StOn<1, StCross3>, StOn<1, StNodeEnd>, StMix>{});
     }
     return catalogue();
 }
@@ -418,7 +481,7 @@ static int choose_texels(int fmt, const StageList& sl, Image src, Image dst, con
     const long px = (long)g.W * (long)(g.y1 - g.y0);
     const bool heavy = sl.taps() >= kHeavyTaps;
     if (t.walk == 0) t.walk = heavy ? 2 : 1;
-    if (fmt != kFmtRGBA32F || sl.sum_rh() > 7 || sl.max_rv() > 4) return 1;
+    if (fmt != kFmtRGBA32F || sl.sum_rh() > 7 || sl.max_rv() > 4 || sl.pair()) return 1;
     const bool can2 = src.base != dst.base && g.W >= 256;
     const bool two = t.texels_per_lane == 2 || (t.texels_per_lane == 0 && heavy && px >= kTwoTexelMinPixels);
     return (two && can2) ? 2 : 1;

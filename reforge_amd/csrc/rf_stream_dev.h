@@ -395,6 +395,112 @@ struct StNodeEnd {
 };
 
 // ---------------------------------------------------------------------------------
+// Fork / join in ONE launch (the diamond of src/vulkan/pipeline_graph.rs:462-468: two branches read one image
+// and a `combination` node joins them).  Between the fork and the join the value that travels down the stage
+// chain is a PAIR of rows -- slot 0 = texels [0, T) of a Tex<2T>, slot 1 = [T, 2T) -- and the two branches are
+// laid end to end: a stage of branch K works on slot K while the other slot rides a delay line of the stage's
+// vertical radius, so both slots always hold the SAME frame row and the per-stage schedule of the linear chain
+// (first / flush / emit) needs no change.  The source rows cross the fabric once for both branches and neither
+// branch result is ever stored: the 4K diamond moves 2 image passes instead of 7.
+// ---------------------------------------------------------------------------------
+template <class S> struct SlotsOf { static constexpr int value = 1; };
+
+template <int T> RF_DEV Tex<T> take_slot(const Tex<2 * T>& v, int k)
+{
+    Tex<T> o;
+#pragma unroll
+    for (int j = 0; j < T; ++j) o.v[j] = v.v[k * T + j];
+    return o;
+}
+template <int T> RF_DEV void put_slot(Tex<2 * T>& v, int k, const Tex<T>& a)
+{
+#pragma unroll
+    for (int j = 0; j < T; ++j) v.v[k * T + j] = a.v[j];
+}
+
+// a plain stage inside a pair pipeline, before the fork or after the join: slot 0 only
+template <class S> struct StSolo {
+    static constexpr int RV = S::RV, RH = S::RH, LDS_ROWS = S::LDS_ROWS;
+    typedef typename S::Params Params;
+    template <class Px, int T> using State = typename S::template State<Px, T>;
+    template <class Px, int T> using Feed = OwnFeed<Px, T>;
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, State<Px, T>& s, const Lane<T>& L, f4* lds, const Tex<2 * T>& v, bool real, bool first, bool emit, Tex<2 * T>& out)
+    {
+        Tex<T> o = tex_zero<T>();
+        S::template advance<Px, REV, T, KEEP>(p, s, L, lds, take_slot<T>(v, 0), real, first, emit, o);
+        put_slot<T>(out, 0, o);
+    }
+};
+template <class S> struct SlotsOf<StSolo<S>> { static constexpr int value = 2; };
+
+// the fork: both branches start from the same row
+struct StDup {
+    static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
+    struct Params {};
+    template <class Px, int T> using State = NoState;
+    template <class Px, int T> using Feed = OwnFeed<Px, T>;
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params&, NoState&, const Lane<T>&, f4*, const Tex<2 * T>& v, bool, bool, bool, Tex<2 * T>& out)
+    {
+        put_slot<T>(out, 0, take_slot<T>(v, 0));
+        put_slot<T>(out, 1, take_slot<T>(v, 0));
+    }
+};
+template <> struct SlotsOf<StDup> { static constexpr int value = 2; };
+
+// stage S on slot K; the other slot is delayed by S::RV rows (a stage of vertical radius R emits the row that
+// arrived R iterations ago: the delay line hands out that same row of the other slot).  On flush ticks (rows
+// repeated below the frame) the line keeps shifting: the rows it still owes are real ones that arrived earlier.
+template <int K, class S> struct StOn {
+    static constexpr int RV = S::RV, RH = S::RH, LDS_ROWS = S::LDS_ROWS;
+    typedef typename S::Params Params;
+    template <class Px, int T> struct State {
+        typename S::template State<Px, T> inner;
+        Tex<T> line[RV > 0 ? RV : 1];
+    };
+    template <class Px, int T> using Feed = OwnFeed<Px, T>;
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, State<Px, T>& s, const Lane<T>& L, f4* lds, const Tex<2 * T>& v, bool real, bool first, bool emit, Tex<2 * T>& out)
+    {
+        Tex<T> o = tex_zero<T>();
+        S::template advance<Px, REV, T, KEEP>(p, s.inner, L, lds, take_slot<T>(v, K), real, first, emit, o);
+        put_slot<T>(out, K, o);
+        const Tex<T> other = take_slot<T>(v, 1 - K);
+        if constexpr (RV == 0) {
+            put_slot<T>(out, 1 - K, other);
+        } else {
+            if (first) {
+#pragma unroll
+                for (int i = 0; i < RV; ++i) s.line[i] = other;
+            }
+            put_slot<T>(out, 1 - K, s.line[0]);
+#pragma unroll
+            for (int i = 0; i + 1 < RV; ++i) s.line[i] = s.line[i + 1];
+            s.line[RV - 1] = other;
+        }
+    }
+};
+template <int K, class S> struct SlotsOf<StOn<K, S>> { static constexpr int value = 2; };
+
+// the join: combination, out = fma(mix, b - a, a) per channel (oracle/rf_oracle.c rfo_mix), a = slot 0, b = slot 1
+struct StMix {
+    static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
+    struct Params { float mix; };
+    template <class Px, int T> using State = NoState;
+    template <class Px, int T> using Feed = OwnFeed<Px, T>;
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, NoState&, const Lane<T>&, f4*, const Tex<2 * T>& v, bool, bool, bool, Tex<2 * T>& out)
+    {
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const f4 a = v.v[j], b = v.v[T + j];
+            out.v[j] = make_float4(fmaf(p.mix, b.x - a.x, a.x), fmaf(p.mix, b.y - a.y, a.y), fmaf(p.mix, b.z - a.z, a.z), fmaf(p.mix, b.w - a.w, a.w));
+        }
+    }
+};
+template <> struct SlotsOf<StMix> { static constexpr int value = 2; };
+
+template <class... S> struct MaxSlots { static constexpr int value = 1; };
+template <class S, class... Rest> struct MaxSlots<S, Rest...> { static constexpr int value = SlotsOf<S>::value > MaxSlots<Rest...>::value ? SlotsOf<S>::value : MaxSlots<Rest...>::value; };
+
+// ---------------------------------------------------------------------------------
 // Parameter pack (kernel argument) and the stage chain (per-wave state)
 // ---------------------------------------------------------------------------------
 // Layout by construction: every stage owns a slot of max(8, sizeof(Params) rounded up to 8) bytes, in stage order,
@@ -419,13 +525,13 @@ template <class S, class...> struct FirstOf { typedef S type; };
 
 // REV: the wave walks its chunk bottom-up (rows are addressed with a negated pitch, so the
 // schedule below is unchanged); stages whose tap order depends on the row direction read it.
-template <class Px, bool REV, int T, int LdsIdx, class... S> struct Chain;
+template <class Px, bool REV, int T, int NS, int LdsIdx, class... S> struct Chain;     // NS: slots of the value between stages (2 in a fork/join pipeline)
 
 // end of the chain: the store
-template <class Px, bool REV, int T, int LdsIdx> struct Chain<Px, REV, T, LdsIdx> {
+template <class Px, bool REV, int T, int NS, int LdsIdx> struct Chain<Px, REV, T, NS, LdsIdx> {
     RF_DEV void plan_backward(int oa, int ob, int, int, int& in_a, int& in_b) { in_a = oa; in_b = ob; }
     RF_DEV int plan_forward(int tprev) { return tprev; }
-    template <int MODE> RF_DEV void step(bool has, const Tex<T>& v, int it, const Lane<T>&, Sink<T>& k, const ParamPack<>&)
+    template <int MODE> RF_DEV void step(bool has, const Tex<T * NS>& v, int it, const Lane<T>&, Sink<T>& k, const ParamPack<>&)
     {
         constexpr bool STEADY = MODE != 0;
         if (STEADY || has) {
@@ -445,7 +551,9 @@ template <class Px, bool REV, int T, int LdsIdx> struct Chain<Px, REV, T, LdsIdx
     }
 };
 
-template <class Px, bool REV, int T, int LdsIdx, class S, class... Rest> struct Chain<Px, REV, T, LdsIdx, S, Rest...> {
+template <class Px, bool REV, int T, int NS, int LdsIdx, class S, class... Rest> struct Chain<Px, REV, T, NS, LdsIdx, S, Rest...> {
+    static_assert(NS == 1 || SlotsOf<S>::value == 2, "every stage of a fork/join pipeline works on the pair (StSolo / StDup / StOn / StMix)");
+    typedef Tex<T * NS> V;
     typename S::template State<Px, T> st;
     // wave-uniform schedule
     int a;        // first input row
@@ -453,7 +561,7 @@ template <class Px, bool REV, int T, int LdsIdx, class S, class... Rest> struct 
     int flush;    // replications of the last input row (frame bottom edge)
     int tprev;    // iteration of the upstream stage's last emission
     int cnt;      // input rows consumed
-    Chain<Px, REV, T, LdsIdx + S::LDS_ROWS, Rest...> next;
+    Chain<Px, REV, T, NS, LdsIdx + S::LDS_ROWS, Rest...> next;
 
     // given the rows the LAST stage must emit, derive what each stage must emit/consume
     RF_DEV void plan_backward(int oa_last, int ob_last, int lo, int hi, int& in_a, int& in_b)
@@ -474,14 +582,22 @@ template <class Px, bool REV, int T, int LdsIdx, class S, class... Rest> struct 
         return next.plan_forward(tp + flush);
     }
     RF_DEV f4* lds_of(const Lane<T>& L) const { return L.lds + LdsIdx * 64 * T; }
+    // the source feeds slot 0 (the first stage of a pair pipeline is an StSolo or the StDup itself)
+    RF_DEV static V widen(const Tex<T>& a)
+    {
+        V o = tex_zero<T * NS>();
+#pragma unroll
+        for (int j = 0; j < T; ++j) o.v[j] = a.v[j];
+        return o;
+    }
     // A row (or a flush tick) enters this stage.  STEADY = every stage receives a real row,
     // is past its first row and emits: the schedule tests fold away at compile time.
-    template <int MODE> RF_DEV void step(bool has_prev, const Tex<T>& v, int it, const Lane<T>& L, Sink<T>& k, const ParamPack<S, Rest...>& P)
+    template <int MODE> RF_DEV void step(bool has_prev, const V& v, int it, const Lane<T>& L, Sink<T>& k, const ParamPack<S, Rest...>& P)
     {
         constexpr bool STEADY = MODE != 0;
         constexpr bool KEEP = MODE == 0 || MODE == 3;   // phases that may hold a stage's last real row
         bool has = false;
-        Tex<T> out = tex_zero<T>();
+        V out = tex_zero<T * NS>();
         if constexpr (STEADY) {
             S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), v, true, false, true, out);
             cnt += 1;
@@ -514,10 +630,10 @@ template <class Px, bool REV, int T, int LdsIdx, class S, class... Rest> struct 
         constexpr bool STEADY = MODE != 0;
         constexpr bool KEEP = MODE == 0 || MODE == 3;
         bool has = false;
-        Tex<T> out = tex_zero<T>();
+        V out = tex_zero<T * NS>();
         if constexpr (STEADY) {
             if constexpr (std::is_same<Feed, OwnFeed<Px, T>>::value)
-                S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), feed.own(), true, false, true, out);
+                S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), widen(feed.own()), true, false, true, out);
             else
                 out = S::template from_taps<T>(P.p, feed);
             cnt += 1;
@@ -537,7 +653,7 @@ template <class Px, bool REV, int T, int LdsIdx, class S, class... Rest> struct 
             if constexpr (S::RV == 0) {
                 if (has0) {
                     if constexpr (std::is_same<Feed, OwnFeed<Px, T>>::value)
-                        S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), feed.own(), true, cnt == 0, true, out);
+                        S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), widen(feed.own()), true, cnt == 0, true, out);
                     else
                         out = S::template from_taps<T>(P.p, feed);
                     cnt += 1;
@@ -547,7 +663,7 @@ template <class Px, bool REV, int T, int LdsIdx, class S, class... Rest> struct 
                 const bool flushing = !has0 && it > tprev && it <= tprev + flush;
                 if (has0 || flushing) {
                     has = (a + cnt - S::RV) >= oa;
-                    S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), feed.own(), has0, cnt == 0, has, out);
+                    S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), widen(feed.own()), has0, cnt == 0, has, out);
                     cnt += 1;
                 }
             }
@@ -607,7 +723,7 @@ RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane<T>& L, int wave, c
     k.row = v0;
     k.first_store = -1;
 
-    Chain<Px, REV, T, 0, S...> chain;
+    Chain<Px, REV, T, MaxSlots<S...>::value, 0, S...> chain;
     Src src;
     int b0;
     chain.plan_backward(v0, v1 - 1, lo, hi, src.a0, b0);

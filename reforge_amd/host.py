@@ -147,6 +147,7 @@ class Plan:
         return [{"label": _s(L.rf_plan_launch_label(h, i)),
                  "layer": L.rf_plan_launch_layer(h, i),
                  "members": [_s(L.rf_plan_launch_member(h, i, k)) for k in range(L.rf_plan_launch_num_members(h, i))],
+                 "member_slots": [L.rf_plan_launch_member_slot(h, i, k) for k in range(L.rf_plan_launch_num_members(h, i))],
                  "inputs": [_s(L.rf_plan_launch_input(h, i, k)) for k in range(L.rf_plan_launch_num_inputs(h, i))],
                  "output": _s(L.rf_plan_launch_output(h, i)),
                  "radius": L.rf_plan_launch_radius(h, i),

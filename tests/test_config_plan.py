@@ -198,8 +198,14 @@ def test_fusion_groups():
     # a fused chain is planned as one node: the aliasing plan is recomputed on the fused
     # graph, so its output can never land on the image it reads
     assert p.resolve("rf:final-output") != "rf:file-input"
-    # branches are not fused across a fork/join
-    assert rf.Plan(rf.Config(util.DIAMOND), 0).launches() == ["blur", "sharp", "mixer"]
+    # a fork/join whose branches descend from one image is ONE launch: both branches ride the stage chain as a pair of rows
+    d = rf.Plan(rf.Config(util.DIAMOND), 0)
+    assert d.launches() == ["blur+sharp+mixer"] and d.needs_jit() == [False]        # (this very diamond is in the catalogue)
+    assert d.launch_info()[0]["inputs"] == ["rf:file-input"] and d.launch_info()[0]["radius"] == 3
+    assert d.images() == ["rf:file-input", "rf:final-output"]                       # neither branch result is materialised
+    assert rf.Plan(rf.Config(util.DIAMOND), NF).launches() == ["blur", "sharp", "mixer"]
+    # a branch image that somebody else reads keeps the fork/join unfused
+    assert "blur" in rf.Plan(rf.Config(util.DIAMOND.replace("mixer -> output", "mixer -> m2:input_image0\nblur -> m2:input_image1\nm2 -> output") + "\nm2: combination { mix: 0.5 }"), 0).launches()
     # an image that two nodes read is materialised
     fork = "input -> aa -> bb -> output\naa -> cc -> output\naa: gaussian5 {}\nbb: grade {}\ncc: grade {}"
     assert "aa" in rf.Plan(rf.Config(fork), 0).launches()

@@ -32,8 +32,15 @@ def _free_port():
     return p
 
 
-def _member_chain_text(cfg, members):
-    lines = ["input -> " + " -> ".join(members) + " -> output"]
+def _member_chain_text(cfg, members, slots=None):
+    slots = slots or [0] * len(members)
+    if any(slots):          # a fused fork/join launch: two branches from the launch's input, joined by the last member
+        a = [m for m, s in zip(members, slots) if s == 1]
+        b = [m for m, s in zip(members, slots) if s == 2]
+        mx = members[-1]
+        lines = ["input -> " + " -> ".join(a + [mx + ":input_image0"]), "input -> " + " -> ".join(b + [mx + ":input_image1"]), mx + " -> output"]
+    else:
+        lines = ["input -> " + " -> ".join(members) + " -> output"]
     for m in members:
         t = cfg.type_of(m)
         params = cfg.params_of(m)
@@ -87,11 +94,11 @@ def _worker(rank, world, port, text, W, H, fmt, exchange, fused, out_dir):
             row_lo, row_hi = max(-need_src[i], -y0), min(Hs - 1 + need_src[i], H - 1 - y0)
             o0, o1 = max(-need_dst[i], -y0), min(Hs + need_dst[i], H - y0)
             srcs = [images[s][ghost + row_lo:ghost + row_hi + 1] for s in L["inputs"]]
-            if cfg.type_of(L["members"][0]) == "combination":
+            if cfg.type_of(L["members"][0]) == "combination" and len(L["members"]) == 1:
                 t = float(np.float32(float(cfg.params_of(L["members"][0])["mix"])))
                 res = pixel.mix(srcs[0], srcs[1], t)
             else:
-                res = util.run_oracle(_member_chain_text(cfg, L["members"]), np.ascontiguousarray(srcs[0]))
+                res = util.run_oracle(_member_chain_text(cfg, L["members"], L["member_slots"]), np.ascontiguousarray(srcs[0]))
             images[L["output"]][ghost + o0:ghost + o1] = res[o0 - row_lo:o1 - row_lo]
 
         out = images[plan.resolve(rf.FINAL_OUTPUT)][ghost:ghost + Hs]

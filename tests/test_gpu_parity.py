@@ -414,6 +414,49 @@ def test_chains_compiled_at_graph_creation(ctx, k):
     assert rf.lib().rf_jit_compile_count() - before <= 4        # per format: the kernel and its two-texel variant, compiled once
 
 
+FORKS = [
+    util.DIAMOND,
+    # an empty branch: the unsharp-mask shape (the join reads the forked image itself)
+    "input -> blur -> mx:input_image0\ninput -> mx:input_image1\nmx -> output\nblur: gaussian9 { sigma: 3.0 }\nmx: combination { mix: -0.7 }",
+    # the forked image is produced by a node, both branches have several nodes, something follows the join
+    "input -> n0 -> aa -> bb -> mx:input_image0\nn0 -> cc -> dd -> mx:input_image1\nmx -> post -> output\nn0: gaussian5 { sigma: 1.0 }\naa: sharpen { amount: 0.5 }\n"
+    "bb: colour_grade { slope: 1.1, offset: 0.0, saturation: 1.3 }\ncc: gaussian9 { sigma: 2.0 }\ndd: passthrough {}\npost: sharpen { amount: 0.2 }\nmx: combination { mix: 0.4 }",
+    # branches swapped over the inputs; radius-0 and point-only branches
+    "input -> gg -> mx:input_image1\ninput -> sh -> mx:input_image0\nmx -> output\ngg: colour_grade { slope: 0.8, offset: 0.05, saturation: 0.4 }\nsh: gaussian { sigma: 1.0, radius: 0 }\nmx: combination { mix: 0.5 }",
+]
+
+
+@pytest.mark.parametrize("k", range(len(FORKS)))
+def test_fork_join_in_one_launch(ctx, k):
+    """A `combination` whose inputs descend from one image is fused with both branches into ONE launch (a pair of rows
+    travels the stage chain; the branch that is not being worked on rides a delay line).  Bit-identical to the oracle's
+    node-at-a-time execution: both formats, chunk seams, frame edges inside the halo, both walk directions, the three-part
+    split of exchange mode, and as row strips."""
+    text = FORKS[k]
+    fused = [l for l in rf.Plan(rf.Config(text)).launch_info() if any(l["member_slots"])]
+    assert len(fused) == 1, rf.Plan(rf.Config(text)).launches()
+    for fmt in (util.F32, util.U8):
+        for W, H in ((61, 47), (200, 90), (130, 33)):
+            x = util.synthetic(W, H, fmt, seed=W * 3 + k)
+            want = util.run_oracle(text, x)
+            for kw in (dict(), dict(rows_per_chunk=11), dict(flags=NF), dict(exec_flags=rf.RF_EXEC_NO_ALTERNATE), dict(exec_flags=rf.RF_EXEC_ALTERNATE, rows_per_chunk=8),
+                       dict(exec_flags=rf.RF_EXEC_FORCE_SPLIT), dict(flags=rf.RF_GRAPH_HIPGRAPH)):
+                util.assert_same(util.run_hip(ctx, text, x, **kw), want, "fork %d %dx%d fmt=%d %r" % (k, W, H, fmt, kw))
+    # as over-fetch row strips (every rank's context on GPU 0, no communicator)
+    W, H, world = 97, 120, 3
+    want = util.run_oracle(text, pixel.fill_synthetic(W, H, util.F32, 77))
+    strips = []
+    for rank in range(world):
+        c = rf.Context(0, rank, world, None)
+        g = rf.Graph(c, rf.Config(text), W, H, util.F32, flags=rf.RF_GRAPH_NO_HALO_XCHG)
+        g.fill_synthetic(77)
+        g.execute(); g.wait()
+        strips.append(g.download_raw())
+        g.close()
+        c.close()
+    util.assert_same(np.concatenate(strips, axis=0), want, "fork %d as strips" % k)
+
+
 @pytest.mark.parametrize("t", [1, 2])
 @pytest.mark.parametrize("walk", ["alternate", "top-down"])
 def test_texels_per_lane_and_walk_direction(ctx, t, walk):
