@@ -84,7 +84,7 @@ SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "diamo
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 MFMA peak (= f32 vector peak)
 MALL_BYTES = 256 << 20         # MI355X_MICROARCH.md: Infinity Cache
-CONV_PATHS = (("valu", 3), ("mfma", 2), ("hybrid", 4))
+CONV_PATHS = (("valu", 3), ("mfma", 2))
 
 
 def bpp_of(fmt):

@@ -87,8 +87,7 @@ typedef struct rf_graph_options {
     uint32_t  flags;        /* RF_GRAPH_* */
     /* tuning, 0 = the library's own choice (RF_ABI_VERSION >= 2; no reference counterpart) */
     int       rows_per_chunk; /* rows a wave walks per chunk (env RF_ROWS_PER_CHUNK)              */
-    int       conv_path;      /* conv2d kernel: 0 auto, 1 LDS tile, 2 MFMA band, 3 VALU, 4 hybrid
-                                 (env RF_CONV_PATH)                                               */
+    int       conv_path;      /* conv2d kernel: 0 auto, 1 LDS tile, 2 MFMA band, 3 VALU (env RF_CONV_PATH)      */
     uint32_t  exec_flags;     /* RF_EXEC_* */
     int       texels_per_lane;/* stream kernels, rgba32f: 0 auto, 1 = 64-wide strips, 2 = 128-wide
                                  (env RF_TEXELS_PER_LANE)                                         */

@@ -36,7 +36,7 @@ RF_EXEC_FORCE_SPLIT = 0x4
 RF_EXEC_NO_ALTERNATE = 0x8
 RF_EXEC_ALTERNATE = 0x20
 
-RF_CONV_AUTO, RF_CONV_TILE, RF_CONV_MFMA, RF_CONV_VALU, RF_CONV_HYBRID = 0, 1, 2, 3, 4
+RF_CONV_AUTO, RF_CONV_TILE, RF_CONV_MFMA, RF_CONV_VALU = 0, 1, 2, 3
 
 
 class GraphOptions(C.Structure):

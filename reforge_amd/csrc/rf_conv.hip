@@ -307,20 +307,32 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
         reinterpret_cast<float*>(wl)[i] = dx < K ? weights[dy * K + dx] : 0.0f;
     }
     const int first_in = cy0 - r;
-    int loaded_to = first_in;
+    auto fetch = [&](int rr, int c) {
+        const int gy = min(max(rr, row_lo), row_hi);
+        const int gx = min(max(x_out0 - r + c, 0), W - 1);
+        return Px::load(src + (ptrdiff_t)gy * (ptrdiff_t)src_pitch, (unsigned)gx * (unsigned)Px::BPP);
+    };
+    auto put = [&](int rr, int c, typename Px::Raw v) {
+        const int slot = (rr - first_in) % ring;
+        tile[slot * kRowTexels + (c % kCvT) * kCvSub + (c / kCvT)] = Px::decode(v);
+    };
+    // first fill: the ring's worth of rows of step 0 (32 + 2r rows)
+    int loaded_to = cy0 + kCvStepRows + r;
+    for (int i = tid; i < (loaded_to - first_in) * xin; i += 512) put(first_in + i / xin, i % xin, fetch(first_in + i / xin, i % xin));
+    // the 32 rows of the NEXT step travel global -> registers while this step's 31 weight rows compute, and go to the
+    // ring after it (the slots they take are the 32 oldest rows, free once every wave has passed the barrier)
+    constexpr int NPF = (kCvStepRows * xin + 511) / 512;
     for (int ys = cy0; ys < cy1; ys += kCvStepRows) {
-        const int need_to = ys + kCvStepRows + r;
-        const int nrows = need_to - loaded_to;
-        for (int i = tid; i < nrows * xin; i += 512) {
-            const int rr = loaded_to + i / xin, c = i % xin;
-            const int gy = min(max(rr, row_lo), row_hi);
-            const int gx = min(max(x_out0 - r + c, 0), W - 1);
-            const f4 v = Px::decode(Px::load(src + (ptrdiff_t)gy * (ptrdiff_t)src_pitch, (unsigned)gx * (unsigned)Px::BPP));
-            const int slot = (rr - first_in) % ring;
-            tile[slot * kRowTexels + (c % kCvT) * kCvSub + (c / kCvT)] = v;
-        }
-        loaded_to = need_to;
+        const bool has_next = ys + kCvStepRows < cy1;
+        typename Px::Raw pf[NPF];
         __syncthreads();
+        if (has_next) {
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) {
+                const int i = tid + 512 * q;
+                if (i < kCvStepRows * xin) pf[q] = fetch(loaded_to + i / xin, i % xin);
+            }
+        }
 
         f4 acc[kCvT];
 #pragma unroll
@@ -359,7 +371,15 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
                 if (ox < W) Px::store(orow, (unsigned)ox * (unsigned)Px::BPP, acc[t]);
             }
         }
-        __syncthreads();
+        __syncthreads();      // every wave is done with the 32 oldest rows
+        if (has_next) {
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) {
+                const int i = tid + 512 * q;
+                if (i < kCvStepRows * xin) put(loaded_to + i / xin, i % xin, pf[q]);
+            }
+            loaded_to += kCvStepRows;
+        }
     }
 }
 

@@ -22,7 +22,7 @@ for k, v in d.get("workloads", {}).items():
     if "error" in v:
         print(k, "ERROR", v["error"]); continue
     if k == "conv31_8k":
-        for p in ("valu", "mfma", "hybrid"):
+        for p in ("valu", "mfma"):
             print(k, p, v[p]["ms_per_frame"], v[p]["roofline"]["frac"], v[p].get("verified"))
     else:
         print(k, v["ms_per_frame"], v["roofline"]["frac"], v.get("frame_hbm_frac"), v.get("verified"))

@@ -9,7 +9,7 @@
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 TAG="$1"; shift
-WORKLOADS="${@:-chain3_4k chain3_4k_unfused gauss9_8k chain5_16k conv31_8k_valu conv31_8k_mfma conv31_8k_hybrid chain3_4k_u8 diamond_4k}"
+WORKLOADS="${@:-chain3_4k chain3_4k_unfused gauss9_8k chain5_16k conv31_8k_valu conv31_8k_mfma chain3_4k_u8 diamond_4k}"
 export TMPDIR=/tmp
 OUT="$ROOT/gpurun_out/prof"
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -20,7 +20,6 @@ for wl in $WORKLOADS; do
   case "$name" in
     conv31_8k_valu)   name=conv31_8k; extra="$extra --conv-path 3" ;;
     conv31_8k_mfma)   name=conv31_8k; extra="$extra --conv-path 2" ;;
-    conv31_8k_hybrid) name=conv31_8k; extra="$extra --conv-path 4" ;;
   esac
   case "$name" in
     chain3_4k|chain3_4k_u8|diamond_4k)  steps=40; fps=8; psteps=4 ;;

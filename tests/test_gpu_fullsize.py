@@ -92,9 +92,9 @@ def test_config5_conv31_8k_band(ctx):
     W, H, seed = 7680, 4320, 0x5EED0005
     out = gpu_frame(ctx, CONV31, W, H, util.F32, seed)
     band_check(out, CONV31, W, H, util.F32, seed, 15, [(0, 2), (2159, 2161), (4318, 4320)])
-    # every large-K kernel at the full size: the banded MFMA contraction north_star names, the
-    # register-blocked VALU kernel and the hybrid of the two must all produce the same frame
-    for path in (rf.RF_CONV_MFMA, rf.RF_CONV_VALU, rf.RF_CONV_HYBRID):
+    # every large-K kernel at the full size: the banded MFMA contraction north_star names and the
+    # register-blocked VALU kernel must produce the same frame
+    for path in (rf.RF_CONV_MFMA, rf.RF_CONV_VALU):
         assert gpu_frame(ctx, CONV31, W, H, util.F32, seed, conv_path=path).tobytes() == out.tobytes(), "conv path %d at 8K" % path
     # linearity in the input survives at full size: conv(x) of a constant frame is that
     # constant times the kernel sum, identical at every pixel away from nothing (clamp-to-edge

@@ -205,13 +205,13 @@ def test_non_finite_texels_propagate_like_the_oracle(ctx):
             assert ok.all(), "%s flags=%d: %d finite texels differ" % (name, flags, (~ok).sum())
 
 
-@pytest.mark.parametrize("path", [1, 2, 3, 4])
+@pytest.mark.parametrize("path", [1, 2, 3])
 def test_conv2d_every_kernel_path(ctx, path):
     """The three conv2d kernels (1 = 16x16 LDS tile, 2 = banded MFMA, 3 = register-blocked VALU)
     are all bit-identical to the oracle: ragged widths around the 64/128-column strips, heights
     around the 16/32-row steps (several steps per chunk: the register-prefetched ring refill),
     frame edges inside the halo.  K < 9 has no MFMA kernel: path 2 then takes the VALU kernel.
-    Path 4 is the MFMA + VALU hybrid (K >= 9, else VALU).  Selected through rf_graph_options."""
+    Selected through rf_graph_options."""
     for K, sigma in ((3, 0.8), (5, 1.0), (9, 1.5), (13, 2.0), (21, 3.5), (31, 5.0)):
         text = "input -> conv2d -> output\nconv2d: conv2d { ksize: %d, sigma: %.1f }" % (K, sigma)
         rng = np.random.RandomState(K)
