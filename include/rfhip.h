@@ -148,6 +148,13 @@ int         rf_plan_num_images(const rf_plan* plan);
 const char* rf_plan_image_name(const rf_plan* plan, int i);
 /* remap_resource_name (pipeline_graph.rs:75-79) */
 const char* rf_plan_resolve(const rf_plan* plan, const char* resource);
+/* storage buffers (SSBO edges: `kw:ConvWeights -> conv:ConvWeights`; pipeline_graph.rs:142-175, :240-265): the names
+ * allocated per graph (name-sorted), their size = max over users of the block's bytes, and the point-op aliasing
+ * (an output on the binding of an input is that input's buffer) */
+int         rf_plan_num_buffers(const rf_plan* plan);
+const char* rf_plan_buffer_name(const rf_plan* plan, int i);
+size_t      rf_plan_buffer_bytes(const rf_plan* plan, int i);
+const char* rf_plan_resolve_buffer(const rf_plan* plan, const char* resource);
 /* kernel launches per frame after fusion, and the nodes each one covers
  * ("a+b+c"); with RF_GRAPH_NO_FUSION one launch per node */
 int         rf_plan_num_launches(const rf_plan* plan);
@@ -202,6 +209,8 @@ int         rf_registry_num_types(void);
 const char* rf_registry_type_name(int t);
 /* binding index of an image variable name, -1 if the type has none */
 int         rf_registry_binding(const char* type_name, const char* descriptor);
+/* binding index of a storage buffer by its block TYPE name (shader.rs:144-147), -1 if the type has none */
+int         rf_registry_buffer_binding(const char* type_name, const char* block_type_name);
 /* vertical / horizontal stencil radius a node of this type reads (0 = point op);
  * radius-parameterised types report their maximum */
 int         rf_registry_radius(const char* type_name);
@@ -254,8 +263,9 @@ rf_status rf_graph_strip(const rf_graph* g, int* y0, int* y1);
  * `sigma` regenerates its default weights (replacing any set with rf_graph_set_weights). */
 rf_status rf_graph_set_param(rf_graph* g, const char* node, const char* name,
                              rf_param_type type, const void* value);
-/* conv2d weights, row-major [K][K] f32 with K = the node's resolved ksize
- * (no reference counterpart: SSBO contents are written by other nodes there) */
+/* K x K weights, row-major f32 with K = the node's resolved ksize: of a conv2d node that has its own, or of a
+ * conv2d_weights node (the contents of the ConvWeights storage buffer it writes).  A conv2d fed through a buffer edge
+ * has none of its own: RF_ERR_INVALID.  (No reference counterpart: SSBO contents are written by other nodes there.) */
 rf_status rf_graph_set_weights(rf_graph* g, const char* node, const float* weights, int count);
 /* update_ubos (render.rs:212-223): every member whose name ends in `_rf_time` */
 rf_status rf_graph_set_time(rf_graph* g, float seconds);

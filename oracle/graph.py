@@ -213,7 +213,11 @@ NODE_TYPES = {
     "gaussian":     {"images": _IO,    "params": _gauss_params(15, True)},
     "colour_grade": {"images": _IO_RW, "params": {"slope": "f32", "offset": "f32", "saturation": "f32"}},
     "sharpen":      {"images": _IO,    "params": {"amount": "f32"}},
-    "conv2d":       {"images": _IO,    "params": {"ksize": "i32", "sigma": "f32"}},
+    # storage buffers are found by the block TYPE name (shader.rs:144-147): "buffers" = name -> (binding, bytes)
+    "conv2d":       {"images": _IO,    "params": {"ksize": "i32", "sigma": "f32"}, "buffers": {"ConvWeights": (3, 961 * 4)}},
+    "conv2d_weights": {"images": _IO,  "params": {"ksize": "i32", "sigma": "f32"}, "buffers": {"ConvWeights": (3, 961 * 4)}},
+    # `phase_rf_time` receives the seconds since start every frame (render.rs:212-223)
+    "pulse":        {"images": _IO,    "params": {"amount": "f32", "phase_rf_time": "f32"}},
     "combination":  {"images": {"input_image0": 0, "input_image1": 1, "output_image": 2},
                      "params": {"mix": "f32"}},
 }
@@ -241,11 +245,12 @@ def _parse_param(s, ty):
 
 
 class PipelineInfo:
-    """pipeline.rs:17-25 restricted to images: [(resource_name, binding)]"""
+    """pipeline.rs:17-25: [(resource_name, binding)] for images and storage buffers"""
 
     def __init__(self, name, type_name):
         self.name, self.type = name, type_name
         self.input_images, self.output_images = [], []
+        self.input_ssbos, self.output_ssbos = [], []
         self.params = {}
 
 
@@ -258,9 +263,14 @@ def synthesize(cfg):
         if t is None:
             raise ConfigError("no node type %r" % tname)      # Shader::from_path -> None
         info = PipelineInfo(name, tname)
-        for key, dst in (("inputs", info.input_images), ("outputs", info.output_images)):
+        for key, dst, bdst in (("inputs", info.input_images, info.input_ssbos), ("outputs", info.output_images, info.output_ssbos)):
             for resource, descriptor in cfg.graph_pipelines[name][key]:
                 if descriptor not in t["images"]:
+                    # not an image variable: a storage buffer by its block type name (vkutils.rs:165-170)
+                    if descriptor in t.get("buffers", {}):
+                        if (resource, t["buffers"][descriptor][0]) not in bdst:
+                            bdst.append((resource, t["buffers"][descriptor][0]))
+                        continue
                     raise ConfigError("Shader has no binding named: %s" % descriptor)   # :179
                 # a node named in several graph expressions repeats the same (resource, binding)
                 # (config.rs:149-190 pushes per occurrence); the planner works on sets -- with the
@@ -280,7 +290,8 @@ def order_by_execution(infos):
 
     def input_nodes(info):
         ins = [r for r, _ in info.input_images]
-        return [c for c, ci in infos.items() if any(r in ins for r, _ in ci.output_images)]
+        bins = [r for r, _ in info.input_ssbos]           # storage-buffer edges order nodes like image edges (:438,:443)
+        return [c for c, ci in infos.items() if any(r in ins for r, _ in ci.output_images) or any(r in bins for r, _ in ci.output_ssbos)]
 
     layers = []
     while unexecuted:
@@ -364,6 +375,24 @@ class GraphOracle:
         self.W, self.H, self.fmt = W, H, fmt
         self.images = {}
         self.buffers = {}     # node -> conv weights override
+        # storage buffers (pipeline_graph.rs:142-175, :240-265): size = max over users of the block's bytes; an output on
+        # the binding of an input is the same buffer (point op); one zero-filled buffer per resolved name
+        self.ssbo_remap, self.ssbo_bytes, self.ssbos = {}, {}, {}
+        for layer in self.layers:
+            for node in layer:
+                info = self.infos[node]
+                size = max([b[1] for b in NODE_TYPES[info.type].get("buffers", {}).values()] or [0])
+                for r, _ in info.input_ssbos + info.output_ssbos:
+                    self.ssbo_bytes[r] = max(self.ssbo_bytes.get(r, 0), size)
+                for ro, bo in info.output_ssbos:
+                    for ri, bi in info.input_ssbos:
+                        if bo == bi:
+                            self.ssbo_remap[ro] = ri
+        for layer in self.layers:
+            for node in layer:
+                for r, _ in self.infos[node].output_ssbos:
+                    nm = _remap(r, self.ssbo_remap)
+                    self.ssbos.setdefault(nm, np.zeros(self.ssbo_bytes[nm] // 4, np.float32))
         # pipeline_graph.rs:205-224: FILE_INPUT once, outputs through the remap
         for layer in self.layers:
             for node in layer:
@@ -386,6 +415,13 @@ class GraphOracle:
     def set_param(self, node, key, value):
         self.infos[node].params[key] = value
 
+    def set_time(self, seconds):
+        """update_ubos, render.rs:212-223: every member whose name ends in `_rf_time`."""
+        for info in self.infos.values():
+            for k in info.params:
+                if k.endswith("_rf_time"):
+                    info.params[k] = float(np.float32(seconds))
+
     def set_weights(self, node, weights):
         self.buffers[node] = np.ascontiguousarray(weights, np.float32)
 
@@ -405,6 +441,9 @@ class GraphOracle:
 
         if not info.output_images:
             return                       # nothing observable
+        for r, _ in info.input_ssbos:
+            if _remap(r, self.ssbo_remap) not in self.ssbos:
+                raise ConfigError("No buffer found for input %s" % r)       # pipeline_graph.rs:269
         if not info.input_images:
             raise ConfigError("node %s has no input image" % info.name)
         t, p = info.type, info.params
@@ -416,7 +455,7 @@ class GraphOracle:
             pixel.mix(img(by_binding[0]), img(by_binding[1]), p["mix"], dst=dst)
             return
         src = img(info.input_images[0][0])
-        if src is dst and t not in ("colour_grade", "colour-grade", "grade", "colour_grade_inplace", "passthrough"):
+        if src is dst and t not in ("colour_grade", "colour-grade", "grade", "colour_grade_inplace", "passthrough", "conv2d_weights", "pulse"):
             raise ConfigError("in-place execution of a stencil node")
         if t == "passthrough":
             if src is not dst:
@@ -436,9 +475,27 @@ class GraphOracle:
             pixel.sharpen(src, p["amount"], dst=dst)
         elif t == "conv2d":
             w = self.buffers.get(info.name)
-            if w is None:
+            if info.input_ssbos:
+                # weights through a storage-buffer edge: the first K*K floats of the wired buffer, whoever wrote them
+                K = conv_ksize(p["ksize"])
+                w = self.ssbos[_remap(info.input_ssbos[0][0], self.ssbo_remap)][:K * K].reshape(K, K).copy()
+            elif w is None:
                 w = default_conv_weights(p["ksize"], p["sigma"])
             pixel.conv2d(src, w, dst=dst)
+        elif t == "conv2d_weights":
+            # writes the K x K weights (host-derived defaults, or what set_weights gave this node) and passes its image through
+            w = self.buffers.get(info.name)
+            if w is None:
+                w = default_conv_weights(p["ksize"], p["sigma"])
+            for r, _ in info.output_ssbos:
+                buf = self.ssbos[_remap(r, self.ssbo_remap)]
+                buf[:] = 0
+                buf[:w.size] = np.ascontiguousarray(w, np.float32).reshape(-1)
+            if src is not dst:
+                pixel.passthrough(src, dst)
+        elif t == "pulse":
+            # a colour grade whose slope breathes with time: slope = fmaf(amount, frac(phase_rf_time), 1), offset 0, saturation 1
+            pixel.colour_grade(src, pixel.pulse_slope(p["amount"], p["phase_rf_time"]), 0.0, 1.0, dst=dst)
         else:
             raise ConfigError("no node type %r" % t)
 

@@ -51,6 +51,8 @@ def lib():
         L.rfo_fill_structured.argtypes = [vp, sz, i32, i32, i32, i32, i32]
         L.rfo_gaussian_weights.argtypes = [f32, i32, fp]
         L.rfo_sharpen_weights.argtypes = [f32, fp, fp]
+        L.rfo_pulse_slope.restype = f32
+        L.rfo_pulse_slope.argtypes = [f32, f32]
         L.rfo_srgb_tables.argtypes = [fp, fp]
         L.rfo_passthrough.argtypes = [vp, sz, vp, sz, i32, i32, i32]
         L.rfo_gaussian.argtypes = [vp, sz, vp, sz, i32, i32, i32, i32, fp]
@@ -120,6 +122,10 @@ def sharpen_weights(amount):
     c, s = C.c_float(), C.c_float()
     lib().rfo_sharpen_weights(float(amount), C.byref(c), C.byref(s))
     return c.value, s.value
+
+
+def pulse_slope(amount, t):
+    return float(lib().rfo_pulse_slope(float(amount), float(t)))
 
 
 def srgb_tables():

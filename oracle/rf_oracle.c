@@ -154,6 +154,16 @@ void rfo_sharpen_weights(float amount, float* centre, float* side)
     *side   = -amount;
 }
 
+/* `pulse` node: a colour grade whose slope follows the frame time -- slope = fma(amount, frac(t), 1) (one rounding; the
+ * fractional part of an f32 is exact), offset 0, saturation 1.  `t` is the member `phase_rf_time`, which the host
+ * overwrites with the seconds since start every frame (src/render.rs:212-223). */
+float rfo_pulse_slope(float amount, float t)
+{
+    float f = t - floorf(t);
+    if (!(f >= 0.0f && f < 1.0f)) f = 0.0f;     /* NaN / infinite time: no pulse */
+    return fmaf(amount, f, 1.0f);
+}
+
 static double srgb_eotf_d(double cs)
 {
     return cs <= 0.04045 ? cs / 12.92 : pow((cs + 0.055) / 1.055, 2.4);

@@ -60,6 +60,7 @@ void rfo_fill_structured(void* img, size_t pitch, int W, int H, int fmt,
 /* w[0..radius]: normalised half-kernel, double math rounded once to f32 */
 void rfo_gaussian_weights(float sigma, int radius, float* w);
 /* centre and side weights of the 3x3 sharpen cross */
+float rfo_pulse_slope(float amount, float t);
 void rfo_sharpen_weights(float amount, float* centre, float* side);
 /* sRGB tables: eotf[c] = linear value of code c; thr[q] = linear value at
  * which the encoded code steps from q to q+1 (q = 0..254) */

@@ -79,6 +79,10 @@ SIGNATURES = {
     "rf_plan_num_images": (_i, [_vp]),
     "rf_plan_image_name": (_cp, [_vp, _i]),
     "rf_plan_resolve": (_cp, [_vp, _cp]),
+    "rf_plan_num_buffers": (_i, [_vp]),
+    "rf_plan_buffer_name": (_cp, [_vp, _i]),
+    "rf_plan_buffer_bytes": (_sz, [_vp, _i]),
+    "rf_plan_resolve_buffer": (_cp, [_vp, _cp]),
     "rf_plan_num_launches": (_i, [_vp]),
     "rf_plan_launch_label": (_cp, [_vp, _i]),
     "rf_plan_launch_layer": (_i, [_vp, _i]),
@@ -97,6 +101,7 @@ SIGNATURES = {
     "rf_plan_halo_schedule": (_i, [_vp, _i, _pi, _pi, _i, _pi, _pi]),
     "rf_registry_num_types": (_i, []),
     "rf_registry_type_name": (_cp, [_i]),
+    "rf_registry_buffer_binding": (_i, [_cp, _cp]),
     "rf_registry_binding": (_i, [_cp, _cp]),
     "rf_registry_radius": (_i, [_cp]),
     "rf_strip_rows": (_i, [_i, _i, _i, _pi, _pi]),

@@ -280,6 +280,28 @@ extern "C" rf_status rf_plan_halo_schedule(const rf_plan* p, int exchange, int* 
     return RF_OK;
 }
 
+// ---- storage buffers -------------------------------------------------------------------------------
+extern "C" int rf_plan_num_buffers(const rf_plan* p) { return p ? (int)p->plan.buffers.size() : -1; }
+extern "C" const char* rf_plan_buffer_name(const rf_plan* p, int i)
+{
+    return (p && i >= 0 && i < (int)p->plan.buffers.size()) ? p->plan.buffers[(size_t)i].c_str() : nullptr;
+}
+extern "C" size_t rf_plan_buffer_bytes(const rf_plan* p, int i)
+{
+    return (p && i >= 0 && i < (int)p->plan.buffers.size()) ? p->plan.buffer_bytes.at(p->plan.buffers[(size_t)i]) : 0;
+}
+extern "C" const char* rf_plan_resolve_buffer(const rf_plan* p, const char* resource)
+{
+    return (p && resource) ? p->plan.resolve_buffer(resource).c_str() : nullptr;
+}
+extern "C" int rf_registry_buffer_binding(const char* type_name, const char* block_type_name)
+{
+    if (!type_name || !block_type_name) return -1;
+    const NodeType* t = find_type(type_name);
+    const NodeType::BufferDef* b = t ? t->buffer(block_type_name) : nullptr;
+    return b ? b->binding : -1;
+}
+
 // ---- kernels compiled at graph creation (rf_jit.cpp) --------------------------------------------
 extern "C" int rf_jit_available(void) { return jit_available() ? 1 : 0; }
 extern "C" int rf_jit_compile_count(void) { return jit_compile_count(); }

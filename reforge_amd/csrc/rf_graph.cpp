@@ -274,7 +274,7 @@ rf_status issue_frame(rf_graph* g, FrameSlot& f, bool timers)
 void rebuild_ops(rf_graph* g)
 {
     for (auto& L : g->launches) {
-        L.ops = ops_of_members(g->plan.plan, L.members, L.member_slot, &g->dev_weights);
+        L.ops = ops_of_members(g->plan.plan, L.members, L.member_slot, &g->weights_of);
     }
 }
 
@@ -497,16 +497,48 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
     const int Hs = strip_rows_of(g);
     if (Hs < 1) return fail(RF_ERR_INVALID, "frame has fewer rows than ranks");
 
-    // conv2d weight buffers (default weights; rf_graph_set_weights overrides)
+    // storage buffers (PipelineGraphFrame::new, pipeline_graph.rs:142-175,:249-260): one zero-filled device buffer per
+    // allocated name, sized to the largest block any user declares
+    for (const auto& name : plan.buffers) {
+        float* d = nullptr;
+        const size_t bytes = std::max<size_t>(plan.buffer_bytes.at(name), 4);
+        HIP_TRY(hipMalloc((void**)&d, bytes));
+        g->dev_buffers[name] = d;
+        HIP_TRY(hipMemset(d, 0, bytes));
+    }
+    // conv2d: K x K weights -- through a ConvWeights buffer edge when the graph wires one, else the node's own (default
+    // weights derived from sigma on the host; rf_graph_set_weights overrides).  conv2d_weights: the node that WRITES such a
+    // buffer; its content is host-derived too, so it is written here and whenever its parameters or weights change (the
+    // reference's node would rewrite the same values every frame).
     for (const auto& kv : plan.nodes) {
-        if (kv.second.type->kind != OP_CONV2D) continue;
+        const int kind = kv.second.type->kind;
+        if (kind != OP_CONV2D && kind != OP_WEIGHTS) continue;
+        const PipelineInfo* info = nullptr;
+        for (const auto& u : plan.infos)
+            if (std::find(u.second.members.begin(), u.second.members.end(), kv.first) != u.second.members.end()) info = &u.second;
         const int K = kv.second.conv_ksize();
         std::vector<float> w((size_t)K * K);
         auto it = kv.second.values.find("sigma");
         default_conv_weights(K, it == kv.second.values.end() ? 0.f : it->second.f, w.data());
+        if (kind == OP_WEIGHTS) {
+            if (!info) continue;
+            for (const auto& out : info->output_ssbos) {
+                float* d = g->dev_buffers.at(plan.resolve_buffer(out.first));
+                g->written_by[kv.first].push_back(d);
+                HIP_TRY(hipMemcpy(d, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
+            continue;
+        }
+        if (info && !info->input_ssbos.empty()) {
+            auto bit = g->dev_buffers.find(plan.resolve_buffer(info->input_ssbos[0].first));
+            if (bit == g->dev_buffers.end()) return fail(RF_ERR_GRAPH, "No buffer found for input " + info->input_ssbos[0].first);   // pipeline_graph.rs:269
+            g->weights_of[kv.first] = bit->second;
+            continue;
+        }
         float* d = nullptr;
         HIP_TRY(hipMalloc((void**)&d, w.size() * sizeof(float)));
         g->dev_weights[kv.first] = d;
+        g->weights_of[kv.first] = d;
         HIP_TRY(hipMemcpy(d, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
     }
 
@@ -622,6 +654,7 @@ extern "C" void rf_graph_destroy(rf_graph* g)
         if (f.stream) (void)hipStreamDestroy(f.stream);
     }
     for (auto& kv : g->dev_weights) (void)hipFree(kv.second);
+    for (auto& kv : g->dev_buffers) (void)hipFree(kv.second);
     if (g->d_staging) (void)hipFree(g->d_staging);
     delete g;
 }
@@ -675,17 +708,21 @@ extern "C" rf_status rf_graph_set_param(rf_graph* g, const char* node, const cha
         return fail(RF_ERR_UNSUPPORTED, std::string("parameter '") + name + "' changes the stencil radius: destroy and re-create the graph");
     }
     invalidate_captures(g);
-    if (np.type->kind == OP_CONV2D && std::string(name) == "sigma") {
-        // the node's weights are DERIVED from sigma until rf_graph_set_weights replaces them: an edit
-        // of sigma regenerates them, as creating the graph with that sigma would
+    if ((np.type->kind == OP_CONV2D || np.type->kind == OP_WEIGHTS) && std::string(name) == "sigma") {
+        // the weights are DERIVED from sigma until rf_graph_set_weights replaces them: an edit of sigma regenerates
+        // them, as creating the graph with that sigma would (a conv2d fed through a buffer edge has none of its own)
+        std::vector<float*> targets;
         auto wit = g->dev_weights.find(node);
-        if (wit != g->dev_weights.end()) {
+        if (wit != g->dev_weights.end()) targets.push_back(wit->second);
+        auto bit = g->written_by.find(node);
+        if (bit != g->written_by.end()) targets = bit->second;
+        if (!targets.empty()) {
             const int K = np.conv_ksize();
             std::vector<float> w((size_t)K * K);
             default_conv_weights(K, nv.f, w.data());
             HIP_TRY(hipSetDevice(g->ctx->device));
             for (auto& f : g->frames) HIP_TRY(hipStreamSynchronize(f.stream));
-            HIP_TRY(hipMemcpy(wit->second, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+            for (float* d : targets) HIP_TRY(hipMemcpy(d, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
         }
     }
     rebuild_ops(g);
@@ -695,13 +732,23 @@ extern "C" rf_status rf_graph_set_param(rf_graph* g, const char* node, const cha
 extern "C" rf_status rf_graph_set_weights(rf_graph* g, const char* node, const float* weights, int count)
 {
     if (!g || !node || !weights) return fail(RF_ERR_INVALID, "rf_graph_set_weights: null argument");
+    auto nit = g->plan.plan.nodes.find(node);
+    if (nit == g->plan.plan.nodes.end()) return fail(RF_ERR_INVALID, std::string("no node named '") + node + "'");
+    std::vector<float*> targets;
     auto it = g->dev_weights.find(node);
-    if (it == g->dev_weights.end()) return fail(RF_ERR_INVALID, std::string("node '") + node + "' is not a conv2d node");
-    const int K = g->plan.plan.nodes.at(node).conv_ksize();
+    if (it != g->dev_weights.end()) targets.push_back(it->second);
+    auto bit = g->written_by.find(node);
+    if (bit != g->written_by.end()) targets = bit->second;
+    if (targets.empty()) {
+        if (nit->second.type->kind == OP_CONV2D)
+            return fail(RF_ERR_INVALID, std::string("node '") + node + "' takes its weights through a ConvWeights buffer edge: set them on the node that writes it");
+        return fail(RF_ERR_INVALID, std::string("node '") + node + "' is not a conv2d or conv2d_weights node");
+    }
+    const int K = nit->second.conv_ksize();
     if (count != K * K) return fail(RF_ERR_INVALID, "rf_graph_set_weights: expected " + std::to_string(K * K) + " weights");
     HIP_TRY(hipSetDevice(g->ctx->device));
     for (auto& f : g->frames) HIP_TRY(hipStreamSynchronize(f.stream));
-    HIP_TRY(hipMemcpy(it->second, weights, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
+    for (float* d : targets) HIP_TRY(hipMemcpy(d, weights, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
     return RF_OK;
 }
 

@@ -30,8 +30,11 @@ enum OpKind : int {
     OP_GRADE       = 2,   // colour grade point op
     OP_SHARPEN     = 3,   // 3x3 cross
     OP_CONV2D      = 4,   // dense KxK (never fused; own tile kernel)
-    OP_MIX         = 5    // two-input blend a + mix*(b-a) (the "combination" node of
+    OP_MIX         = 5,   // two-input blend a + mix*(b-a) (the "combination" node of
                           // pipeline_graph.rs:462-468's example; own kernel)
+    // registry-level kinds (NodeParams::to_op turns them into one of the device ops above)
+    OP_WEIGHTS     = 6,   // conv2d_weights: writes a ConvWeights storage buffer, passes its image through
+    OP_PULSE       = 7    // pulse: a colour grade whose slope follows `phase_rf_time`
 };
 
 struct Op {

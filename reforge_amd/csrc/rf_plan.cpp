@@ -20,6 +20,13 @@ int NodeType::binding(const std::string& descriptor) const
     return -1;
 }
 
+const NodeType::BufferDef* NodeType::buffer(const std::string& descriptor) const
+{
+    for (const auto& b : buffers)
+        if (descriptor == b.name) return &b;
+    return nullptr;
+}
+
 const ParamDef* NodeType::param(const std::string& pname) const
 {
     for (const auto& p : params)
@@ -47,17 +54,22 @@ const std::vector<NodeType>& registry()
         return v;
     };
     static const std::vector<NodeType> types = {
-        {"passthrough", OP_PASSTHROUGH, 0, io, {}},
-        {"gaussian5", OP_GAUSSIAN, 2, io, gauss_params(2, false)},
-        {"gaussian9", OP_GAUSSIAN, 4, io, gauss_params(4, false)},
-        {"gaussian", OP_GAUSSIAN, -1, io, gauss_params(kMaxRadius, true)},
-        {"colour_grade", OP_GRADE, 0, io_rw, grade},
-        {"colour_grade_inplace", OP_GRADE, 0, rw, grade},
-        {"colour-grade", OP_GRADE, 0, io_rw, grade},
-        {"grade", OP_GRADE, 0, io_rw, grade},
-        {"sharpen", OP_SHARPEN, 1, io, {{"amount", PARAM_F32}}},
-        {"conv2d", OP_CONV2D, -1, io, {{"ksize", PARAM_I32}, {"sigma", PARAM_F32}}},
-        {"combination", OP_MIX, 0, io2, {{"mix", PARAM_F32}}},
+        {"passthrough", OP_PASSTHROUGH, 0, io, {}, {}},
+        {"gaussian5", OP_GAUSSIAN, 2, io, gauss_params(2, false), {}},
+        {"gaussian9", OP_GAUSSIAN, 4, io, gauss_params(4, false), {}},
+        {"gaussian", OP_GAUSSIAN, -1, io, gauss_params(kMaxRadius, true), {}},
+        {"colour_grade", OP_GRADE, 0, io_rw, grade, {}},
+        {"colour_grade_inplace", OP_GRADE, 0, rw, grade, {}},
+        {"colour-grade", OP_GRADE, 0, io_rw, grade, {}},
+        {"grade", OP_GRADE, 0, io_rw, grade, {}},
+        {"sharpen", OP_SHARPEN, 1, io, {{"amount", PARAM_F32}}, {}},
+        // conv2d may take its K x K weights through a storage-buffer edge (`kw:ConvWeights -> conv:ConvWeights`); the block
+        // `ConvWeights { float weights[961]; }` is found by its type name (shaders/conv2d.comp, shader.rs:144-147)
+        {"conv2d", OP_CONV2D, -1, io, {{"ksize", PARAM_I32}, {"sigma", PARAM_F32}}, {{"ConvWeights", 3, 961 * sizeof(float)}}},
+        {"conv2d_weights", OP_WEIGHTS, 0, io, {{"ksize", PARAM_I32}, {"sigma", PARAM_F32}}, {{"ConvWeights", 3, 961 * sizeof(float)}}},
+        {"combination", OP_MIX, 0, io2, {{"mix", PARAM_F32}}, {}},
+        // a member ending in `_rf_time` receives the seconds since start every frame (render.rs:190,:212-223)
+        {"pulse", OP_PULSE, 0, io, {{"amount", PARAM_F32}, {"phase_rf_time", PARAM_F32}}, {}},
     };
     return types;
 }
@@ -148,11 +160,28 @@ int NodeParams::conv_ksize() const
     return k;
 }
 
+// slope of the `pulse` node: fma(amount, frac(t), 1) -- the same single rounding as oracle/rf_oracle.c rfo_pulse_slope
+static float pulse_slope(float amount, float t)
+{
+    float f = t - std::floor(t);
+    if (!(f >= 0.0f && f < 1.0f)) f = 0.0f;
+    return std::fmaf(amount, f, 1.0f);
+}
+
 Op NodeParams::to_op(const float* dev_weights) const
 {
     Op op;
     op.kind = type->kind;
     switch (type->kind) {
+        case OP_WEIGHTS:              // its device work is the copy of its image; the buffer is written by the host side (rf_graph.cpp)
+            op.kind = OP_PASSTHROUGH;
+            break;
+        case OP_PULSE:
+            op.kind = OP_GRADE;
+            op.slope = pulse_slope(pf(values, "amount"), pf(values, "phase_rf_time"));
+            op.offset = 0.0f;
+            op.saturation = 1.0f;
+            break;
         case OP_GAUSSIAN: {
             int r = type->fixed_radius;
             if (r < 0) r = std::min(std::max(pi(values, "radius"), 0), kMaxRadius);
@@ -192,6 +221,16 @@ Op NodeParams::to_op(const float* dev_weights) const
 // ---------------------------------------------------------------------------------
 // Plan
 // ---------------------------------------------------------------------------------
+const std::string& Plan::resolve_buffer(const std::string& resource) const
+{
+    const std::string* name = &resource;
+    for (;;) {
+        auto it = buffer_reuse.find(*name);
+        if (it == buffer_reuse.end()) return *name;
+        name = &it->second;
+    }
+}
+
 const std::string& Plan::resolve(const std::string& resource) const
 {
     const std::string* name = &resource;
@@ -223,6 +262,9 @@ static bool order_by_execution(const std::map<std::string, PipelineInfo>& infos,
             bool feeds = false;
             for (const auto& out : cand.second.output_images)
                 for (const auto& in : info.input_images)
+                    if (out.first == in.first) feeds = true;
+            for (const auto& out : cand.second.output_ssbos)     // storage-buffer edges order nodes too (:438,:443)
+                for (const auto& in : info.input_ssbos)
                     if (out.first == in.first) feeds = true;
             if (feeds) nodes.push_back(cand.first);
         }
@@ -323,7 +365,10 @@ static std::map<std::string, std::string> reusable_image_remapping(
     return reuse;
 }
 
-static bool is_simple(const PipelineInfo& p) { return p.input_images.size() == 1 && p.output_images.size() == 1; }
+static bool is_simple(const PipelineInfo& p)
+{
+    return p.input_images.size() == 1 && p.output_images.size() == 1 && p.input_ssbos.empty() && p.output_ssbos.empty();   // a node with a buffer edge keeps a launch of its own
+}
 
 // Fuse chains of single-input/single-output nodes whose intermediate image has exactly
 // one producer and one consumer and is not the graph output (no reference counterpart:
@@ -532,8 +577,19 @@ bool build_plan(const Config& cfg, uint32_t flags, Plan& plan, std::string& err)
         for (int side = 0; side < 2; ++side) {
             const auto& descs = side == 0 ? kv.second.inputs : kv.second.outputs;
             auto& dst = side == 0 ? info.input_images : info.output_images;
+            auto& bdst = side == 0 ? info.input_ssbos : info.output_ssbos;
             for (const auto& d : descs) {
                 int b = type->binding(d.descriptor_name);
+                if (b < 0) {
+                    // not an image variable: a storage buffer, by its block type name (vkutils.rs:165-170)
+                    if (const NodeType::BufferDef* bd = type->buffer(d.descriptor_name)) {
+                        const std::pair<std::string, int> e{d.resource_name, bd->binding};
+                        if (std::find(bdst.begin(), bdst.end(), e) == bdst.end()) bdst.push_back(e);
+                        size_t& bytes = plan.buffer_bytes[d.resource_name];
+                        bytes = std::max(bytes, bd->bytes);                  // max over users, pipeline_graph.rs:158-175
+                        continue;
+                    }
+                }
                 if (b < 0) {   // vkutils.rs:179
                     err = "Shader " + tname + " has no binding named: " + d.descriptor_name;
                     return false;
@@ -580,6 +636,26 @@ bool build_plan(const Config& cfg, uint32_t flags, Plan& plan, std::string& err)
         }
     }
     plan.images.assign(images.begin(), images.end());
+
+    // storage buffers, pipeline_graph.rs:240-260: an output on the binding of an input is that input's buffer (point op);
+    // every other output allocates; sizes of aliased names merge (the reference sizes each NAME separately and creates the
+    // buffer under the resolved one, :252-253)
+    for (const auto& layer : plan.layers)
+        for (const auto& n : layer) {
+            const PipelineInfo& info = plan.infos.at(n);
+            for (const auto& out : info.output_ssbos)
+                for (const auto& in : info.input_ssbos)
+                    if (out.second == in.second) plan.buffer_reuse[out.first] = in.first;
+        }
+    std::set<std::string> buffers;
+    for (const auto& layer : plan.layers)
+        for (const auto& n : layer)
+            for (const auto& out : plan.infos.at(n).output_ssbos) {
+                const std::string& nm = plan.resolve_buffer(out.first);
+                buffers.insert(nm);
+                plan.buffer_bytes[nm] = std::max(plan.buffer_bytes[nm], plan.buffer_bytes[out.first]);
+            }
+    plan.buffers.assign(buffers.begin(), buffers.end());
     return true;
 }
 
@@ -600,7 +676,7 @@ std::vector<Op> ops_of_members(const Plan& plan, const std::vector<std::string>&
     return ops;
 }
 
-static bool point_kind(int kind) { return kind == OP_PASSTHROUGH || kind == OP_GRADE; }
+static bool point_kind(int kind) { return kind == OP_PASSTHROUGH || kind == OP_GRADE; }    // (device kinds: conv2d_weights is a passthrough, pulse a grade)
 
 bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string& err)
 {
@@ -653,6 +729,15 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
                 return false;
             }
             L.dst = plan.resolve(info.output_images[0].first);
+            for (const auto& b : info.input_ssbos) {
+                const std::string& nm = plan.resolve_buffer(b.first);
+                if (std::find(plan.buffers.begin(), plan.buffers.end(), nm) == plan.buffers.end()) {
+                    err = "No buffer found for input " + b.first;   // pipeline_graph.rs:269
+                    return false;
+                }
+                L.in_buffers.push_back(nm);
+            }
+            for (const auto& b : info.output_ssbos) L.out_buffers.push_back(plan.resolve_buffer(b.first));
             for (const auto& s : L.src) {
                 if (std::find(plan.images.begin(), plan.images.end(), s) == plan.images.end()) {
                     err = "No image found for input " + s;   // pipeline_graph.rs:236

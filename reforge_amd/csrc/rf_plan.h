@@ -33,7 +33,11 @@ struct NodeType {
     int fixed_radius;                                     // -1: from the `radius` / `ksize` parameter
     std::vector<std::pair<const char*, int>> images;      // variable name -> binding (shader.rs:151-153)
     std::vector<ParamDef> params;                         // uniform members (pipeline_graph.rs:276-292)
-    int binding(const std::string& descriptor) const;     // -1 if absent
+    // storage buffers, found by the block TYPE name (shader.rs:144-147): (name, binding, bytes of the block's members)
+    struct BufferDef { const char* name; int binding; size_t bytes; };
+    std::vector<BufferDef> buffers;
+    int binding(const std::string& descriptor) const;     // image variable -> binding, -1 if absent
+    const BufferDef* buffer(const std::string& descriptor) const;
     const ParamDef* param(const std::string& name) const;
 };
 
@@ -56,6 +60,8 @@ struct PipelineInfo {
     std::vector<int> member_slot;                          // per member: 0, or 1 / 2 = node of the branch feeding input_image0 / 1 of a fused fork/join (empty = all 0)
     std::vector<std::pair<std::string, int>> input_images; // (resource name, binding)
     std::vector<std::pair<std::string, int>> output_images;
+    std::vector<std::pair<std::string, int>> input_ssbos;  // storage-buffer edges (pipeline.rs:23-24)
+    std::vector<std::pair<std::string, int>> output_ssbos;
 };
 
 // per-node resolved parameters -> the device op
@@ -72,6 +78,12 @@ struct Plan {
     std::vector<std::vector<std::string>> layers;          // order_by_execution, name-sorted inside a layer
     std::map<std::string, std::string> reuse;              // image_reuse_remapping
     std::vector<std::string> images;                       // allocated per frame, sorted
+    // storage buffers (pipeline_graph.rs:142-175, :240-265): size = max over users; an output on the binding of an input is
+    // the same buffer (buffer_reuse); `buffers` = the names actually allocated, sorted
+    std::map<std::string, std::string> buffer_reuse;
+    std::map<std::string, size_t> buffer_bytes;
+    std::vector<std::string> buffers;
+    const std::string& resolve_buffer(const std::string& resource) const;
     bool fused = false;
 
     const std::string& resolve(const std::string& resource) const;   // remap_resource_name, :75-79
@@ -87,6 +99,7 @@ struct LaunchDesc {
     int layer = 0;
     std::vector<std::string> src;   // allocated image names (1; 2 for OP_MIX in binding order)
     std::string dst;                // allocated image name
+    std::vector<std::string> in_buffers, out_buffers;   // allocated storage-buffer names the launch reads / writes
     int radius = 0;                 // vertical halo read beyond the rows written
     int need_src = 0;               // ghost rows of src the launch reads (multi-rank)
     int need_dst = 0;               // ghost rows of dst the launch must also produce (over-fetch mode)

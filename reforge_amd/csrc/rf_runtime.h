@@ -94,7 +94,10 @@ struct rf_graph {
     int ghost = 0;                     // ghost rows allocated above and below every image
     std::vector<rf::Launch> launches;  // execution order
     std::vector<rf::FrameSlot> frames;
-    std::map<std::string, float*> dev_weights;   // conv2d nodes
+    std::map<std::string, float*> dev_weights;   // owned: the K x K weights of conv2d nodes that take none through a buffer edge
+    std::map<std::string, float*> dev_buffers;   // owned: storage buffers by allocated name (PipelineGraphFrame buffers, pipeline_graph.rs:249-260)
+    std::map<std::string, float*> weights_of;    // conv2d node -> the weights it reads (its own, or the storage buffer wired to it)
+    std::map<std::string, std::vector<float*>> written_by;   // conv2d_weights node -> the storage buffers it writes
     std::string input_image;           // allocated name of rf:file-input ("" if the graph has none)
     std::string output_image;          // allocated name rf:final-output resolves to
     int need_input = 0;                // ghost rows of the input the frame reads

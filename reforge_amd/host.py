@@ -137,6 +137,14 @@ class Plan:
     def resolve(self, resource):
         return _s(lib().rf_plan_resolve(self._h, resource.encode()))
 
+    def buffers(self):
+        """{allocated storage-buffer name: bytes} (SSBO edges, pipeline_graph.rs:142-175)."""
+        L, h = lib(), self._h
+        return {_s(L.rf_plan_buffer_name(h, i)): L.rf_plan_buffer_bytes(h, i) for i in range(L.rf_plan_num_buffers(h))}
+
+    def resolve_buffer(self, resource):
+        return _s(lib().rf_plan_resolve_buffer(self._h, resource.encode()))
+
     def launches(self):
         L, h = lib(), self._h
         return [_s(L.rf_plan_launch_label(h, i)) for i in range(L.rf_plan_num_launches(h))]

@@ -234,6 +234,14 @@ def main():
         assert g[5:] == [("saturation", "DR", "luma"), ("saturation", "DG", "luma"), ("saturation", "DB", "luma")], g
         assert [a for a in flat_o if a[0] == "saturation"] == [("saturation", "DR", "luma"), ("saturation", "DG", "luma"), ("saturation", "DB", "luma")], flat_o
 
+    # pulse: slope = fma(amount, frac(t), 1), then the grade arithmetic with (slope, 0, 1)
+    o = ordered_args(oracle_c, "rfo_pulse_slope", [(r"\.0\b", "")])
+    g = ordered_args(sh("pulse.comp"), "main", [(r"c \. r", "IN_R"), (r"c \. g", "IN_G"), (r"c \. b", "IN_B"), (r"\bdr\b", "DR"), (r"\bdg\b", "DG"), (r"\bdb\b", "DB"), (r"\.0\b", "")])
+    assert o == [("amount", "f", "1")], o
+    assert g[0] == ("amount", "f", "1") and g[1:4] == [("IN_R", "slope", "0"), ("IN_G", "slope", "0"), ("IN_B", "slope", "0")], g
+    assert g[4:6] == [("0.7152", "tg", "luma"), ("0.0722", "tb", "luma")] and g[6:] == [("1", "DR", "luma"), ("1", "DG", "luma"), ("1", "DB", "luma")], g
+    assert re.search(r"f = t - floorf\(t\)", strip_comments(oracle_c)) and re.search(r"f = phase_rf_time - floor\(phase_rf_time\)", strip_comments(sh("pulse.comp")))
+
     # conv2d: dy outer, dx inner, both ascending -r .. r; weight [(dy+r)*K + (dx+r)]
     for text, func in ((oracle_c, "rfo_conv2d"), (sh("conv2d.comp"), "main")):
         e = [x for x in fmas(text, func)]

@@ -5,6 +5,7 @@ import pytest
 
 import reforge_amd as rf
 from oracle import graph as og
+from oracle import pixel
 from tests import util
 
 NF = rf.RF_GRAPH_NO_FUSION
@@ -492,3 +493,45 @@ def test_planner_matches_restatement_on_random_dags():
             for l in info:
                 if l["radius"] > 0 and len(l["inputs"]) == 1:
                     assert l["inputs"][0] != l["output"], text
+
+
+# ---- storage buffers (SSBO edges) and `_rf_time` ---------------------------------------------------------------
+SSBO = """input -> kw -> cv -> output
+kw:ConvWeights -> cv:ConvWeights
+kw: conv2d_weights { ksize: 5, sigma: 1.2 }
+cv: conv2d { ksize: 5, sigma: 9.0 }"""
+
+
+def test_storage_buffer_edges_follow_the_reference_rules():
+    """A descriptor that is no image variable is looked up as a storage buffer by its block TYPE name
+    (vkutils.rs:165-170, shader.rs:144-147); buffer edges order the layers like image edges
+    (pipeline_graph.rs:438,:443); a buffer is sized to the largest block among its users (:158-175); an output on the
+    binding of an input is the same buffer (:240-246).  Product plan == oracle restatement."""
+    assert rf.lib().rf_registry_buffer_binding(b"conv2d", b"ConvWeights") == 3
+    assert rf.lib().rf_registry_buffer_binding(b"conv2d_weights", b"ConvWeights") == 3
+    assert rf.lib().rf_registry_buffer_binding(b"sharpen", b"ConvWeights") == -1
+    p = rf.Plan(rf.Config(SSBO), NF)
+    o = og.GraphOracle(SSBO, 8, 8, pixel.FMT_RGBA32F)
+    assert p.layers() == o.layers == [["kw"], ["cv"]]
+    assert p.buffers() == {"kw:ConvWeights": 3844} and sorted(o.ssbos) == ["kw:ConvWeights"] and o.ssbo_bytes["kw:ConvWeights"] == 3844
+    # the buffer edge alone orders two nodes that share no image: cv2 must wait for kw although it reads only the input
+    text = "input -> kw -> mx:input_image1\ninput -> cv2 -> mx:input_image0\nkw:ConvWeights -> cv2:ConvWeights\nmx -> output\n" \
+           "kw: conv2d_weights { ksize: 3, sigma: 1.0 }\ncv2: conv2d { ksize: 3 }\nmx: combination { mix: 0.5 }"
+    p = rf.Plan(rf.Config(text), NF)
+    assert p.layers() == og.GraphOracle(text, 8, 8, pixel.FMT_RGBA32F).layers == [["kw"], ["cv2"], ["mx"]]
+    # a conv2d that names a buffer nobody writes: "No buffer found for input" (pipeline_graph.rs:269)
+    with pytest.raises(rf.RfError) as e:
+        rf.Plan(rf.Config("input -> cv -> output\ninput -> cv:ConvWeights\ncv: conv2d { ksize: 3 }"), NF).halo_schedule(True)
+    assert "No buffer found for input rf:file-input" in str(e.value)
+    # unknown descriptor: neither an image nor a buffer of the type
+    with pytest.raises(rf.RfError) as e:
+        rf.Plan(rf.Config("input -> kw -> output\nkw:Nope -> cv:Nope\ncv -> output\nkw: conv2d_weights {}\ncv: conv2d {}"), NF)
+    assert "has no binding named: Nope" in str(e.value)
+    # a node with a buffer edge is never fused into a chain
+    fused = rf.Plan(rf.Config(SSBO.replace("-> cv -> output", "-> cv -> sh -> output") + "\nsh: sharpen {}"), 0).launches()
+    assert "kw" in fused and not any("kw+" in l or "+kw" in l for l in fused)
+
+
+def test_rf_time_member_exists_and_is_a_float():
+    assert "pulse" in rf.registry_types() and "pulse" in og.NODE_TYPES
+    assert og.NODE_TYPES["pulse"]["params"] == {"amount": "f32", "phase_rf_time": "f32"}

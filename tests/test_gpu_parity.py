@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import reforge_amd as rf
+from oracle import graph as og
 from oracle import pixel
 from tests import kat, util
 
@@ -412,6 +413,72 @@ def test_chains_compiled_at_graph_creation(ctx, k):
                        dict(exec_flags=rf.RF_EXEC_NO_ALTERNATE), dict(exec_flags=rf.RF_EXEC_FORCE_SPLIT)):
                 util.assert_same(util.run_hip(ctx, text, x, **kw), want, "jit chain %d %dx%d fmt=%d %r" % (k, W, H, fmt, kw))
     assert rf.lib().rf_jit_compile_count() - before <= 4        # per format: the kernel and its two-texel variant, compiled once
+
+
+SSBO = """input -> kw -> cv -> output
+kw:ConvWeights -> cv:ConvWeights
+kw: conv2d_weights { ksize: 5, sigma: 1.2 }
+cv: conv2d { ksize: 5, sigma: 9.0 }"""
+
+
+def test_conv_weights_through_a_storage_buffer_edge(ctx):
+    """`kw:ConvWeights -> cv:ConvWeights`: the conv2d node reads its K x K weights from the storage buffer the conv2d_weights
+    node writes (found by the block type name, shader.rs:144-147), not from its own sigma.  Same bits as the oracle and as a
+    conv2d that derives those weights itself; rf_graph_set_weights / set_param on the WRITER change what the conv reads."""
+    direct = "input -> cv -> output\ncv: conv2d { ksize: 5, sigma: 1.2 }"
+    for fmt in (util.F32, util.U8):
+        x = util.synthetic(97, 61, fmt, seed=9)
+        want = util.run_oracle(SSBO, x)
+        util.assert_same(want, util.run_oracle(direct, x), "oracle: wired == direct")
+        for flags in (0, NF):
+            util.assert_same(util.run_hip(ctx, SSBO, x, flags=flags), want, "buffer edge flags=%d" % flags)
+        g = rf.Graph(ctx, rf.Config(SSBO), 97, 61, fmt)
+        o = og.GraphOracle(SSBO, 97, 61, fmt)
+        g.upload_raw(x); o.upload_raw(x)
+        w = np.random.RandomState(3).uniform(-0.05, 0.09, (5, 5)).astype(np.float32)
+        g.set_weights("kw", w); o.set_weights("kw", w)
+        g.execute(); g.wait(); o.execute()
+        util.assert_same(g.download_raw(), o.download_raw(), "weights set on the writer")
+        with pytest.raises(rf.RfError):
+            g.set_weights("cv", w)                       # a wired conv2d has no weights of its own
+        g.set_param("kw", "sigma", 0.7); o.buffers.pop("kw"); o.set_param("kw", "sigma", float(np.float32(0.7)))
+        g.execute(); g.wait(); o.execute()
+        util.assert_same(g.download_raw(), o.download_raw(), "sigma edited on the writer")
+        g.close()
+
+
+def test_rf_time_drives_the_pulse_node(ctx):
+    """update_ubos (render.rs:212-223): every uniform member whose name ends in `_rf_time` receives the frame time.  The
+    `pulse` type has one; rf_graph_set_time must change what the NEXT frame computes, fused into a chain or alone, with
+    hipGraph replay too, exactly as the oracle's set_time does."""
+    text = "input -> pp -> gg -> output\npp: pulse { amount: 0.5, phase_rf_time: 0.25 }\ngg: gaussian5 { sigma: 1.0 }"
+    for fmt in (util.F32, util.U8):
+        x = util.synthetic(131, 45, fmt, seed=4)
+        for flags in (0, NF, rf.RF_GRAPH_HIPGRAPH):
+            g = rf.Graph(ctx, rf.Config(text), 131, 45, fmt, flags=flags)
+            o = og.GraphOracle(text, 131, 45, fmt)
+            g.upload_raw(x); o.upload_raw(x)
+            outs = []
+            for t in (None, 0.0, 3.25, 7.9990234375, 1e9):
+                if t is not None:
+                    g.set_time(t); o.set_time(t)
+                g.execute(); g.wait(); o.execute()
+                util.assert_same(g.download_raw(), o.download_raw(), "pulse at t=%r flags=%d" % (t, flags))
+                outs.append(g.download_raw().tobytes())
+            assert outs[0] != outs[1] and outs[1] != outs[2]          # the config's own 0.25, then 0 (no pulse), then 3.25
+            g.close()
+    # the Render mirror: update_ubos is part of every frame (main.rs:134-182)
+    info = rf.RenderInfo(width=32, height=16, format=util.F32)      # (through rgba32f the sRGB round trip is the identity)
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".cfg", delete=False) as fh:
+        fh.write("input -> pp -> output\npp: pulse { amount: 1.0 }")
+    info.config_path = fh.name
+    r = rf.Render(info, ctx=ctx)
+    r.staging[...] = 100
+    a = r.render_frame(0.0).copy()
+    b = r.render_frame(0.5).copy()
+    assert (a[..., :3] == 100).all() and (b[..., :3] > 100).all() and (b[..., 3] == a[..., 3]).all()
+    os.unlink(fh.name)
 
 
 FORKS = [
