@@ -46,18 +46,17 @@ RF_DEV f4 fma4(float w, f4 v, f4 a)
 // ---------------------------------------------------------------------------------
 // Texel formats: what imageLoad/imageStore do (shaders/passthrough.comp:9,:12)
 // ---------------------------------------------------------------------------------
-// c / 255 correctly rounded, without the ~12-instruction IEEE division sequence: one Newton
-// step on q = c * fl(1/255) gives the correctly rounded quotient for all 256 codes
-// (tests/test_gpu_parity.py::test_unorm8_decode_all_codes checks every code against the
-// oracle's true division).
-RF_DEV float unorm8_to_f32(unsigned c)
+// c / 255 correctly rounded, without the ~12-instruction IEEE division sequence: 1/255 split into a head (the nearest
+// float) and a tail, x * tail rounded, then ONE fma x * head + that -- the correctly rounded quotient for all 256 codes
+// (tests/test_gpu_parity.py::test_unorm8_decode_all_codes checks every code against the oracle's true division; the
+// round-1 form q = x * r, e = fma(-q, 255, x), fma(e, r, q) took three operations).
+RF_DEV float unorm8_code_to_f32(float x)
 {
-    const float r = 1.0f / 255.0f;
-    const float x = (float)c;
-    const float q = x * r;
-    const float e = fmaf(-q, 255.0f, x);
-    return fmaf(e, r, q);
+    const float hi = 1.0f / 255.0f;                                        // 0x3b808081
+    const float lo = (float)(1.0 / 255.0 - (double)(1.0f / 255.0f));       // the part of 1/255 the head misses
+    return fmaf(x, hi, x * lo);
 }
+RF_DEV float unorm8_to_f32(unsigned c) { return unorm8_code_to_f32((float)c); }
 // imageStore's float -> UNORM8 as a float: clamp to [0,1] (NaN -> 0), x255, round to nearest even.
 // v_med3_f32 returns min3 when an operand is NaN, i.e. 0; the +0 addend of the fma turns a
 // clamped -0 into +0, which is what the integer code decodes to.
@@ -66,15 +65,6 @@ RF_DEV float unorm8_code(float v)
     return rintf(fmaf(__builtin_amdgcn_fmed3f(v, 0.0f, 1.0f), 255.0f, 0.0f));
 }
 RF_DEV unsigned f32_to_unorm8(float v) { return (unsigned)unorm8_code(v); }
-// code (an integer-valued float in [0,255]) -> c / 255 correctly rounded, as unorm8_to_f32
-RF_DEV float unorm8_code_to_f32(float x)
-{
-    const float r = 1.0f / 255.0f;
-    const float q = x * r;
-    const float e = fmaf(-q, 255.0f, x);
-    return fmaf(e, r, q);
-}
-
 struct PxF32 {
     typedef f4 Raw;
     static constexpr int BPP = 16;

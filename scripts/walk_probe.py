@@ -10,17 +10,20 @@ TEXTS = {"chain5": bench.CHAIN5, "chain3": bench.CHAIN3, "gauss9": bench.WORKLOA
 for sp in sys.argv[1:]:
     parts = sp.split(":")
     name, dims = parts[0], parts[1]
+    fmt = 1
+    if name.endswith("_u8"):
+        name, fmt = name[:-3], 0
     rpcs = [int(x) for x in parts[2].split(",")] if len(parts) > 2 else [0]
     W, H = map(int, dims.split("x"))
     for t in (1, 2):
         line = []
         for ex in (rf.RF_EXEC_ALTERNATE, rf.RF_EXEC_NO_ALTERNATE):
             for rpc in rpcs:
-                g = rf.Graph(ctx, rf.Config(TEXTS[name]), W, H, 1, texels_per_lane=t, rows_per_chunk=rpc, exec_flags=ex)
+                g = rf.Graph(ctx, rf.Config(TEXTS[name]), W, H, fmt, texels_per_lane=t, rows_per_chunk=rpc, exec_flags=ex)
                 g.fill_synthetic(1)
                 g.execute(); g.wait()
                 n = max(4, int(20 / max(g.time_frames(2) / 2, 0.02)))
                 ms = sorted(g.time_frames(n) / n for _ in range(5))
                 line.append("%s%d:%.4f" % ("fwd" if ex == rf.RF_EXEC_NO_ALTERNATE else "alt", rpc, ms[0]))
                 g.close()
-        print(name, dims, "T=%d" % t, " ".join(line), flush=True)
+        print(name, "u8" if fmt == 0 else "f32", dims, "T=%d" % t, " ".join(line), flush=True)
