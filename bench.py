@@ -94,7 +94,7 @@ def bpp_of(fmt):
 def kernel_sources_sha16():
     """Identity of the kernel sources the committed PMC traffic figures were measured on."""
     h = hashlib.sha256()
-    for f in ("rf_stream.hip", "rf_conv.hip", "rf_misc.hip", "rf_device.h"):
+    for f in ("rf_stream.hip", "rf_stream_dev.h", "rf_conv.hip", "rf_misc.hip", "rf_device.h"):
         with open(os.path.join(ROOT, "reforge_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -29,7 +29,10 @@ def main():
                 break
             time.sleep(0.01)
         uid = open(id_path, "rb").read()
-    ctx = rf.Context(0, rank, world, uid)
+    # RF_TEST_ONE_GPU_PER_RANK=1: rank r on device r with the REAL librccl (tests/test_gpu_rccl.py, needs world GPUs);
+    # otherwise every rank shares GPU 0 through the test double
+    device = rank if os.environ.get("RF_TEST_ONE_GPU_PER_RANK") == "1" else 0
+    ctx = rf.Context(device, rank, world, uid)
     source = sys.argv[11] if len(sys.argv) > 11 else "fill"
     g = rf.Graph(ctx, rf.Config(text), W, H, fmt, flags=flags)       # exchange mode unless the caller set RF_GRAPH_NO_HALO_XCHG
     y0, y1 = g.strip
