@@ -434,7 +434,7 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
     // ---- fork/join: a `combination` node whose two inputs descend from ONE image through chains of simple nodes is ONE
     // launch (rf_stream_dev.h "Fork / join in ONE launch"): branch results are never stored, the forked image is read once.
     // Conservative: no in-place node in a branch, every branch image has one producer and one consumer.
-    struct Diamond { std::vector<std::string> a, b; std::string mix, src; };
+    struct Diamond { std::vector<std::string> pre, a, b, post; std::string mix, src; };
     std::vector<Diamond> diamonds;
     std::set<std::string> in_diamond;
     for (const auto& kv : infos) {
@@ -480,27 +480,77 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
         for (const auto& n : d.a) clash = clash || in_diamond.count(n);
         for (const auto& n : d.b) clash = clash || in_diamond.count(n);
         if (clash || in_diamond.count(d.mix)) continue;
-        std::vector<std::string> members = d.a;
-        members.insert(members.end(), d.b.begin(), d.b.end());
-        members.push_back(d.mix);
-        std::vector<int> slots(d.a.size(), 1);
-        slots.insert(slots.end(), d.b.size(), 2);
-        slots.push_back(0);
-        if (members.size() > (size_t)kMaxFusedOps) continue;
-        std::vector<Op> ops = ops_of_members(plan, members, slots, nullptr);
-        if (!stream_supported(ops.data(), (int)ops.size(), allow_jit)) continue;
+        // nodes before the fork and after the join ride along (StSolo stages) when nobody else sees their images: upstream
+        // while the forked image has ONE simple producer and no reader outside the group; downstream while the joined image has
+        // ONE simple consumer and is not the graph output.  The longest admissible extension wins; the bare diamond is the floor.
+        std::vector<std::string> pre, post;
+        {
+            std::string res = common;
+            std::set<std::string> inside(d.a.begin(), d.a.end());
+            inside.insert(d.b.begin(), d.b.end());
+            inside.insert(d.mix);
+            for (;;) {
+                if (res == kFileInput || producers[res].size() != 1) break;
+                bool all_inside = true;
+                for (const auto& c : consumers[res]) all_inside = all_inside && inside.count(c);
+                const std::string& n = producers[res][0];
+                const PipelineInfo& pi = infos.at(n);
+                const int kind = plan.nodes.at(n).type->kind;
+                if (!all_inside || !is_simple(pi) || in_place(pi) || kind == OP_MIX || kind == OP_CONV2D || in_diamond.count(n)) break;
+                pre.insert(pre.begin(), n);
+                inside.insert(n);
+                res = pi.input_images[0].first;
+            }
+            res = m.output_images[0].first;
+            for (;;) {
+                if (res == kFinalOutput || producers[res].size() != 1 || consumers[res].size() != 1) break;
+                const std::string& n = consumers[res][0];
+                const PipelineInfo& pi = infos.at(n);
+                const int kind = plan.nodes.at(n).type->kind;
+                if (!is_simple(pi) || in_place(pi) || kind == OP_MIX || kind == OP_CONV2D || in_diamond.count(n) || inside.count(n)) break;
+                post.push_back(n);
+                inside.insert(n);
+                res = pi.output_images[0].first;
+            }
+        }
+        std::vector<std::string> members;
+        std::vector<int> slots;
+        bool ok = false;
+        for (;;) {
+            members = pre;
+            members.insert(members.end(), d.a.begin(), d.a.end());
+            members.insert(members.end(), d.b.begin(), d.b.end());
+            members.push_back(d.mix);
+            members.insert(members.end(), post.begin(), post.end());
+            slots.assign(pre.size(), 0);
+            slots.insert(slots.end(), d.a.size(), 1);
+            slots.insert(slots.end(), d.b.size(), 2);
+            slots.insert(slots.end(), 1 + post.size(), 0);
+            if (members.size() <= (size_t)kMaxFusedOps) {
+                std::vector<Op> ops = ops_of_members(plan, members, slots, nullptr);
+                if (stream_supported(ops.data(), (int)ops.size(), allow_jit)) { ok = true; break; }
+            }
+            if (!post.empty()) post.pop_back();                 // shrink: nodes after the join first, then those before the fork
+            else if (!pre.empty()) pre.erase(pre.begin());
+            else break;
+        }
+        if (!ok) continue;
+        d.pre = pre;
+        d.post = post;
         for (const auto& n : members) in_diamond.insert(n);
         diamonds.push_back(d);
     }
     for (const auto& d : diamonds) {
         PipelineInfo f;
+        for (const auto& n : d.pre) { f.members.push_back(n); f.member_slot.push_back(0); }
         for (const auto& n : d.a) { f.members.push_back(n); f.member_slot.push_back(1); }
         for (const auto& n : d.b) { f.members.push_back(n); f.member_slot.push_back(2); }
         f.members.push_back(d.mix);
         f.member_slot.push_back(0);
+        for (const auto& n : d.post) { f.members.push_back(n); f.member_slot.push_back(0); }
         for (size_t k = 0; k < f.members.size(); ++k) f.name += (k ? "+" : "") + f.members[k];
-        f.input_images = {{d.src, 1000}};
-        f.output_images = {{infos.at(d.mix).output_images[0].first, 1001}};
+        f.input_images = {{d.pre.empty() ? d.src : infos.at(d.pre.front()).input_images[0].first, 1000}};
+        f.output_images = {{infos.at(d.post.empty() ? d.mix : d.post.back()).output_images[0].first, 1001}};
         for (const auto& n : f.members) infos.erase(n);
         infos[f.name] = f;
     }

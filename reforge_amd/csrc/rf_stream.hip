@@ -359,6 +359,9 @@ template <int K, class S> struct StageKey<StOn<K, S>> { static std::string get()
 #define RF_PF_DEFAULT 4
 #endif
 constexpr int PF_DEFAULT = RF_PF_DEFAULT;   // rows in flight per wave (8 was measured slower, 3/5/6 see DESIGN.md)
+#ifndef RF_PF_T2
+#define RF_PF_T2 4
+#endif
 
 template <class... S> struct TL {};
 template <class A, class B> struct Concat;
@@ -381,7 +384,7 @@ template <int PF, class... S> static void add_to_catalogue(TL<S...>)
     e.fn[kFmtRGBA32F][1] = &launch_aot<PxF32, PF, 1, S...>;
     // two texels per lane: only where the doubled state still fits 256 VGPRs
     if constexpr (SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4 && MaxSlots<S...>::value == 1) e.fn[kFmtRGBA8][2] = &launch_aot<PxU8, (PF > 4 ? 4 : PF), 2, S...>;
-    if constexpr (SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4 && MaxSlots<S...>::value == 1) e.fn[kFmtRGBA32F][2] = &launch_aot<PxF32, (PF > 4 ? 4 : PF), 2, S...>;
+    if constexpr (SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4 && MaxSlots<S...>::value == 1) e.fn[kFmtRGBA32F][2] = &launch_aot<PxF32, (PF > RF_PF_T2 ? RF_PF_T2 : (PF == PF_DEFAULT ? RF_PF_T2 : PF)), 2, S...>;
 }
 
 // The ahead-of-time catalogue: every node alone (gaussian radius 0..15), every ordered pair of

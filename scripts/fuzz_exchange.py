@@ -11,7 +11,7 @@ from tests.test_gpu_exchange import run_ranks, ROOT, HIPCC
 first, count = int(sys.argv[1]), int(sys.argv[2])
 fake = tempfile.mkdtemp()
 subprocess.check_call([HIPCC, "-O2", "-std=c++17", "-shared", "-fPIC", "-x", "c++", os.path.join(ROOT, "tests", "native", "fake_rccl.cpp"),
-                       "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-o", os.path.join(fake, "librccl.so.1")],
+                       "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "reforge_amd", "csrc"), "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-o", os.path.join(fake, "librccl.so.1")],
                       stderr=subprocess.DEVNULL)
 pixel.set_threads(8)
 bad = skipped = 0

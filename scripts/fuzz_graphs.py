@@ -26,11 +26,13 @@ for seed in range(first, first + count):
             print("seed", seed, "oracle failed:", e, "\n" + text, flush=True)
             bad += 1
             break
-        for flags in (0, rf.RF_GRAPH_NO_FUSION, rf.RF_GRAPH_HIPGRAPH):
+        for flags in (0, rf.RF_GRAPH_NO_FUSION, rf.RF_GRAPH_HIPGRAPH, rf.RF_GRAPH_NO_JIT):
             try:
                 got = util.run_hip(ctx, text, x, flags=flags)
                 util.assert_same(got, want, "")
             except Exception as e:
                 bad += 1
                 print("seed", seed, "fmt", fmt, "flags", flags, "%dx%d" % (w, h), str(e)[:300], "\n" + text, flush=True)
+    if (seed - first) % 20 == 19:
+        print("progress", seed - first + 1, "graphs,", bad, "failures, %.0f s, %d kernels compiled" % (time.time() - t0, rf.lib().rf_jit_compile_count()), flush=True)
 print("done", count, "graphs,", bad, "failures, %.0f s" % (time.time() - t0), flush=True)

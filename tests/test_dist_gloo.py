@@ -34,11 +34,16 @@ def _free_port():
 
 def _member_chain_text(cfg, members, slots=None):
     slots = slots or [0] * len(members)
-    if any(slots):          # a fused fork/join launch: two branches from the launch's input, joined by the last member
-        a = [m for m, s in zip(members, slots) if s == 1]
-        b = [m for m, s in zip(members, slots) if s == 2]
-        mx = members[-1]
-        lines = ["input -> " + " -> ".join(a + [mx + ":input_image0"]), "input -> " + " -> ".join(b + [mx + ":input_image1"]), mx + " -> output"]
+    if any(slots):          # a fused fork/join launch: [nodes before the fork] [branch 0] [branch 1] [the join] [nodes after it]
+        first = min(i for i, s in enumerate(slots) if s)
+        last = max(i for i, s in enumerate(slots) if s)
+        pre, a = members[:first], [m for m, s in zip(members, slots) if s == 1]
+        b, mx, post = [m for m, s in zip(members, slots) if s == 2], members[last + 1], members[last + 2:]
+        src = pre[-1] if pre else "input"
+        lines = []
+        if pre:
+            lines.append("input -> " + " -> ".join(pre))
+        lines += [" -> ".join([src] + a + [mx + ":input_image0"]), " -> ".join([src] + b + [mx + ":input_image1"]), " -> ".join([mx] + post + ["output"])]
     else:
         lines = ["input -> " + " -> ".join(members) + " -> output"]
     for m in members:
