@@ -504,7 +504,7 @@ def main():
             for i in range(3):
                 g16.execute(0)
             g16.wait(0)
-            n16 = 20
+            n16 = 100 if not args.rehearse else 20
             barrier_sync()
             t0 = time.perf_counter()
             for i in range(n16):
