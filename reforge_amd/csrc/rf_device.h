@@ -92,6 +92,15 @@ struct PxF32 {
         // no gain, and split into four stores it would break the count)
         *reinterpret_cast<f4*>(row + xoff) = v;
     }
+    // The same store with a WAVE-UNIFORM row address, written as the scalar-base form (row address in SGPRs, the
+    // lane's column offset in one VGPR): the stream kernel's row pointer then advances on the scalar unit, not with a
+    // 64-bit vector add per row.
+    RF_DEV static void store_row(char* row, unsigned xoff, f4 v)
+    {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f d = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(xoff), "v"(d), "s"(row) : "memory");
+    }
     RF_DEV static f4 requant(f4 v) { return v; }
 };
 
@@ -115,6 +124,11 @@ struct PxU8 {
         return __builtin_amdgcn_cvt_pk_u8_f32(unorm8_code(v.w), 3u, o);
     }
     RF_DEV static void store(char* row, unsigned xoff, f4 v) { *reinterpret_cast<unsigned*>(row + xoff) = pack(v); }
+    RF_DEV static void store_row(char* row, unsigned xoff, f4 v)       // wave-uniform row address: see PxF32::store_row
+    {
+        const unsigned d = pack(v);
+        asm volatile("global_store_dword %0, %1, %2" ::"v"(xoff), "v"(d), "s"(row) : "memory");
+    }
     // what a store followed by a load of the next node does to a value: decode(pack(v)) without
     // the trip through the integer byte (the code is the same number either way)
     RF_DEV static f4 requant(f4 v)

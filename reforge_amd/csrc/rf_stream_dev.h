@@ -65,7 +65,7 @@ RF_DEV void wave_sync()
 template <int N> RF_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int T> struct Sink {
-    char* dst;          // address of local row 0
+    char* dst;          // address of the next output row (wave-uniform: advances on the scalar unit)
     ptrdiff_t pitch;    // negative when the wave walks bottom-up
     unsigned xoff[T];   // byte offset of the lane's texel j in a row
     bool lane_ok[T];    // the lane owns an output texel at j
@@ -77,7 +77,9 @@ template <class Px, int PF, int T> struct Source {
     static_assert(PF >= 2, "the ring needs at least two slots");
     static constexpr int SLOTS = PF;
     static constexpr int SLOT_BYTES = 64 * T * Px::BPP;
-    const char* src[T];   // address of local row 0, already offset by the column of the lane's texel j
+    const char* src;      // address of local row 0 (wave-uniform)
+    unsigned xoff[T];     // byte offset of the column of the lane's texel j (clamped to the frame)
+    mutable const char* cur;   // address of the next row to issue: rows are issued in order, the pointer advances on the scalar unit
     ptrdiff_t pitch;
     int a0, n0;           // first source row, number of source rows
     unsigned lds_base;    // LDS byte address of slot 0 (wave-uniform)
@@ -99,21 +101,23 @@ template <class Px, int PF, int T> struct Source {
     RF_DEV void issue(int r) const
     {
         const unsigned dst0 = lds_base + (unsigned)(r % SLOTS) * (unsigned)SLOT_BYTES;
+        const char* g = cur;
+        cur = g + pitch;
 #pragma unroll
         for (int j = 0; j < T; ++j) {
-            const char* g = src[j] + (ptrdiff_t)(a0 + r) * pitch;
             const unsigned dst = dst0 + (unsigned)(j * 64 * Px::BPP);
             unsigned keep;
             if constexpr (Px::BPP == 16)
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(xoff[j]), "s"(dst), "s"(g) : "memory");
             else
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(xoff[j]), "s"(dst), "s"(g) : "memory");
         }
     }
     RF_DEV void prologue() const
     {
+        cur = src + (ptrdiff_t)a0 * pitch;
         for (int r = 0; r < PF && r < n0; ++r) issue(r);
     }
     // Wait until row r has landed, leaving younger operations in flight.  Younger than
@@ -135,10 +139,11 @@ template <class Px, int PF, int T> struct Source {
 // ahead so the LDS latency hides behind the previous row's arithmetic
 template <class Px, int T> struct OwnFeed {      // the lane's own texels
     typename Px::Raw nxt[T];
-    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane<T>& L)
+    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane<T>& L) { fetch_at(s.slot(r), L); }
+    RF_DEV void fetch_at(const char* slot, const Lane<T>& L)
     {
 #pragma unroll
-        for (int j = 0; j < T; ++j) nxt[j] = *reinterpret_cast<const typename Px::Raw*>(s.slot(r) + (size_t)L.pos(j) * Px::BPP);
+        for (int j = 0; j < T; ++j) nxt[j] = *reinterpret_cast<const typename Px::Raw*>(slot + (size_t)L.pos(j) * Px::BPP);
     }
     RF_DEV Tex<T> own() const
     {
@@ -150,13 +155,18 @@ template <class Px, int T> struct OwnFeed {      // the lane's own texels
 };
 template <int R, int T> struct TapFeed {         // rgba32f: the 2R+1 horizontal taps, straight from the DMA ring
     f4 t[T][2 * R + 1];
-    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane<T>& L)
+    // The ring row already holds clamp-to-edge columns (the DMA reads column clamp(x)), so tap i of position p is
+    // simply slot p + i: ONE address per texel (position p - R; the taps are instruction offsets) instead of 2R+1.
+    // Positions within R of the strip's ends -- halo lanes, results discarded -- are pulled inside the row.
+    template <class Src> RF_DEV void fetch(const Src& s, int r, const Lane<T>& L) { fetch_at(s.slot(r), L); }
+    RF_DEV void fetch_at(const char* slot, const Lane<T>& L)
     {
-        const f4* row = reinterpret_cast<const f4*>(s.slot(r));
+        const f4* row = reinterpret_cast<const f4*>(slot);
 #pragma unroll
         for (int j = 0; j < T; ++j) {
+            const f4* base = row + min(max(L.pos(j) - R, 0), 64 * T - 1 - 2 * R);
 #pragma unroll
-            for (int i = -R; i <= R; ++i) t[j][i + R] = row[L.nbr(j, i)];
+            for (int i = 0; i <= 2 * R; ++i) t[j][i] = base[i];
         }
     }
     RF_DEV Tex<T> own() const
@@ -337,7 +347,11 @@ struct StGrade {
 struct StCross3 {
     static constexpr int RV = 1, RH = 1, LDS_ROWS = 1;
     struct Params { float wc, ws; };
-    template <class Px, int T> struct State { Tex<T> n, c, cw, ce; };   // rows y-1, y and y's left/right neighbours
+    // bottom-up walks keep a window: n, c = rows y-1, y (in walk order), cw, ce = y's left/right neighbours.
+    // Top-down walks keep RUNNING SUMS instead (as StVTap does): n = the sum of output row y so far (its N, W, C, E
+    // taps), c = the N tap of output row y+1, cw = the newest real row (bottom-edge flush; KEEP phases only) -- the same
+    // five fmas in the same order, and no register moves per row.
+    template <class Px, int T> struct State { Tex<T> n, c, cw, ce; };
     template <class Px, int T> using Feed = OwnFeed<Px, T>;
     template <int T> RF_DEV static void exchange(const Lane<T>& L, f4* lds, const Tex<T>& v, Tex<T>& w, Tex<T>& e)
     {
@@ -350,8 +364,41 @@ struct StCross3 {
             e.v[j] = lds[L.nbr(j, +1)];
         }
     }
+    // row v becomes the centre row: its W, C, E taps go on top of the N tap already summed in `north`
+    template <int T> RF_DEV static void centre_row(const Params& p, const Lane<T>& L, f4* lds, const Tex<T>& v, const Tex<T>& north, Tex<T>& sum, Tex<T>& next_north)
+    {
+        Tex<T> w, e;
+        exchange(L, lds, v, w, e);
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            f4 acc = fma4(p.ws, w.v[j], north.v[j]);
+            acc = fma4(p.wc, v.v[j], acc);
+            sum.v[j] = fma4(p.ws, e.v[j], acc);
+            next_north.v[j] = fma4(p.ws, v.v[j], f4_zero());
+        }
+    }
     template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, State<Px, T>& s, const Lane<T>& L, f4* lds, const Tex<T>& v, bool real, bool first, bool emit, Tex<T>& out)
     {
+        if constexpr (!REV) {
+            if (first) {                 // clamp-to-edge above the stage's first row: it is its own northern neighbour
+                Tex<T> north;
+#pragma unroll
+                for (int j = 0; j < T; ++j) north.v[j] = fma4(p.ws, v.v[j], f4_zero());
+                centre_row<T>(p, L, lds, v, north, s.n, s.c);
+                if constexpr (KEEP) s.cw = v;
+                return;
+            }
+            if (emit) {
+#pragma unroll
+                for (int j = 0; j < T; ++j) out.v[j] = fma4(p.ws, real ? v.v[j] : s.cw.v[j], s.n.v[j]);     // the S tap closes the sum
+            }
+            if (real) {
+                const Tex<T> north = s.c;
+                centre_row<T>(p, L, lds, v, north, s.n, s.c);
+                if constexpr (KEEP) s.cw = v;
+            }
+            return;
+        }
         if (first) {                     // window = [v, v, (next row)]
             s.n = v;
             s.c = v;
@@ -364,11 +411,11 @@ struct StCross3 {
             for (int j = 0; j < T; ++j) {
                 f4 acc = f4_zero();
                 // frame order N, W, C, E, S: walking bottom-up the older row is the one BELOW
-                acc = fma4(p.ws, REV ? below.v[j] : s.n.v[j], acc);
+                acc = fma4(p.ws, below.v[j], acc);
                 acc = fma4(p.ws, s.cw.v[j], acc);
                 acc = fma4(p.wc, s.c.v[j], acc);
                 acc = fma4(p.ws, s.ce.v[j], acc);
-                acc = fma4(p.ws, REV ? s.n.v[j] : below.v[j], acc);
+                acc = fma4(p.ws, s.n.v[j], acc);
                 out.v[j] = acc;
             }
         }
@@ -544,7 +591,8 @@ template <class Px, bool REV, int T, int NS, int LdsIdx> struct Chain<Px, REV, T
             // (every one of them has at least one active lane: see the strip placement in stream_kernel)
 #pragma unroll
             for (int j = 0; j < T; ++j)
-                if (k.lane_ok[j]) Px::store(k.dst + (ptrdiff_t)k.row * k.pitch, k.xoff[j], v.v[j]);
+                if (k.lane_ok[j]) Px::store_row(k.dst, k.xoff[j], v.v[j]);
+            k.dst += k.pitch;
             k.row += 1;
             if (!STEADY && k.first_store < 0) k.first_store = it;
         }
@@ -721,6 +769,7 @@ RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane<T>& L, int wave, c
         k.lane_ok[j] = (L.pos(j) >= RH) && (L.pos(j) < 64 * T - RH) && (L.col(j) < A.W);
     }
     k.row = v0;
+    k.dst = A.dst + (ptrdiff_t)v0 * k.pitch;
     k.first_store = -1;
 
     Chain<Px, REV, T, MaxSlots<S...>::value, 0, S...> chain;
@@ -731,8 +780,9 @@ RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane<T>& L, int wave, c
     const int total = chain.plan_forward(src.n0 - 1) + 1;
 
     // source: rows a0..b0, column clamp(x)
+    src.src = A.src;
 #pragma unroll
-    for (int j = 0; j < T; ++j) src.src[j] = A.src + k.xoff[j];
+    for (int j = 0; j < T; ++j) src.xoff[j] = k.xoff[j];
     src.pitch = REV ? -(ptrdiff_t)A.src_pitch : (ptrdiff_t)A.src_pitch;
     src.ring = ring_wave;
     src.lds_base = ring_lds;

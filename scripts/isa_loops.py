@@ -4,7 +4,11 @@ usage: isa_loops.py <file.s> <substring of the demangled kernel name> [--dump]""
 import collections
 import re
 import subprocess
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from isa_util import innermost_loops  # noqa: E402
 
 
 def main():
@@ -28,16 +32,7 @@ def main():
         if want not in d:
             continue
         print("==", d)
-        spans = []
-        for h, l in enumerate(body):
-            if not re.match(r"^\.LBB\d+_\d+:.*Loop Header", l):
-                continue
-            label = l.split(":")[0]
-            back = [k for k in range(h, len(body)) if re.search(r"s_c?branch\w*\s+" + re.escape(label) + r"\b", body[k])]
-            if back:
-                spans.append((h, back[-1]))
-        for h, e in spans:
-            ins = [x.strip() for x in body[h + 1:e + 1] if x.strip() and not x.strip().startswith((";", "."))]
+        for label, ins in innermost_loops(body):
             text = "\n".join(ins)
             waits = re.findall(r"vmcnt\((\d+)\)", text)
             if not waits or "global_store" not in text:
@@ -48,7 +43,7 @@ def main():
                 cls = ("pk_fma" if op == "v_pk_fma_f32" else "v_mov" if op.startswith("v_mov") or op.startswith("v_accvgpr") else "valu" if op.startswith("v_") else
                        "ds_read" if op.startswith("ds_read") else "ds_write" if op.startswith("ds_write") else "salu" if op.startswith("s_") else op)
                 ops[cls] += 1
-            print("  loop @%d: %d instrs, vmcnt waits %s: %s" % (h, len(ins), sorted(set(waits)), dict(ops)))
+            print("  loop %s: %d instrs, vmcnt waits %s: %s" % (label, len(ins), sorted(set(waits)), dict(ops)))
             if dump:
                 print("\n".join("      " + i for i in ins))
 

@@ -1,0 +1,35 @@
+"""Loops of a hipcc -S listing by BASIC BLOCK membership (not by layout): hipcc marks every block of a loop with the
+comment `in Loop: Header=BB<f>_<n>` and is free to place a loop's latch in front of its header, so "from the header
+label to the last branch back" misses rotated loops.  Shared by scripts/isa_loops.py and tests/test_isa_invariants.py."""
+import re
+
+
+def innermost_loops(body):
+    """[(header label, instruction lines in EXECUTION order of one iteration: header block first, then the blocks
+    laid out after it, then the ones laid out before it)] for every innermost loop of one function body."""
+    blocks = []                       # (label or None, comment, [lines])
+    cur = (None, "", [])
+    for l in body:
+        m = re.match(r"^(\.LBB\d+_\d+):(.*)$", l)
+        m2 = re.match(r"^; %bb\.\d+:(.*)$", l)
+        if m:
+            blocks.append(cur)
+            cur = (m.group(1), m.group(2), [])
+        elif m2:
+            blocks.append(cur)
+            cur = (None, m2.group(1), [])
+        else:
+            cur[2].append(l)
+    blocks.append(cur)
+    out = []
+    for i, (label, comment, lines) in enumerate(blocks):
+        if label is None or "Inner Loop Header" not in comment:
+            continue
+        tag = "Header=BB" + label[len(".LBB"):] + " "
+        after = [b for b in blocks[i + 1:] if tag in b[1] + " "]
+        before = [b for b in blocks[:i] if tag in b[1] + " "]
+        seq = list(lines)
+        for b in after + before:
+            seq += b[2]
+        out.append((label, [x.strip() for x in seq if x.strip() and not x.strip().startswith((";", "."))]))
+    return out

@@ -10,9 +10,13 @@ import os
 import re
 import subprocess
 
+import sys
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+from isa_util import innermost_loops  # noqa: E402
 CSRC = os.path.join(ROOT, "reforge_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 
@@ -52,26 +56,14 @@ def prefetch_depth(name):
 def steady_loops(body, pf=4, t=1):
     """instruction lists of the loops whose wait is the steady counted form vmcnt((2*PF-2)*T)"""
     steady, warm = "vmcnt(%d)" % ((2 * pf - 2) * t), "vmcnt(%d)" % ((pf - 1) * t)
-    spans = []                                # (header line, last back-branch line) of every loop
-    for h, l in enumerate(body):
-        if not re.match(r"^\.LBB\d+_\d+:.*Loop Header", l):
-            continue
-        label = l.split(":")[0]
-        back = [k for k in range(h, len(body)) if re.search(r"s_c?branch\w*\s+" + re.escape(label) + r"\b", body[k])]
-        if back:
-            spans.append((h, back[-1]))
     loops = []
-    for i, l in enumerate(body):
-        if "s_waitcnt " + steady not in l:
+    for _, ins in innermost_loops(body):      # by basic-block membership: hipcc may lay a loop's latch out before its header
+        text = "\n".join(ins)
+        if "s_waitcnt " + steady not in text:
             continue
-        inside = [(h, e) for h, e in spans if h < i <= e]
-        if not inside:
-            continue
-        h, e = max(inside)                    # innermost enclosing loop
-        text = "\n".join(body[h:e + 1])
         if warm in text or "vmcnt(0)" in text:
             continue                          # the generic (priming / tail) loop carries all three waits
-        loops.append([x.strip() for x in body[h + 1:e + 1] if x.strip() and not x.strip().startswith((";", "."))])
+        loops.append(ins)
     return loops
 
 
