@@ -85,6 +85,7 @@ WORKLOADS = {
 SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "diamond_4k"]
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec)
+PACKAGE_POWER_CAP_W = 1400.0   # MI355X board power limit (rocm-smi reports 1395-1400 W on every capped kernel)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 MFMA peak (= f32 vector peak)
 MALL_BYTES = 256 << 20         # MI355X_MICROARCH.md: Infinity Cache
 CONV_PATHS = (("valu", 3), ("mfma", 2))
@@ -192,6 +193,65 @@ def cpu_baseline(wl, budget_s=12.0):
 
 
 # ---- measurement ------------------------------------------------------------------------------
+class PowerSampler:
+    """Package power and shader clock WHILE frames run (rocm-smi polled from a thread; never inside a timed region).
+    MI355X caps the package at 1400 W: a kernel that sits on the cap runs at a lowered clock and its time is set by
+    the energy of a frame, not by any single unit's peak rate -- the roofline fraction cannot say that, these two
+    numbers can (profiles/r02_clock_power_probe.txt)."""
+
+    def __init__(self, period=0.2):
+        self.period, self.samples, self._stop, self._th = period, [], None, None
+
+    @staticmethod
+    def _read():
+        import subprocess
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=10).stdout
+        card = json.loads(out)
+        card = card[sorted(card)[0]]
+        power = [float(v) for k, v in card.items() if "ower" in k and "(W)" in k]
+        sclk = [int("".join(c for c in v if c.isdigit())) for k, v in card.items() if k.startswith("sclk clock speed")]
+        return (power[0] if power else None, sclk[0] if sclk else None)
+
+    def __enter__(self):
+        import threading
+        self._stop = threading.Event()
+
+        def poll():
+            while not self._stop.is_set():
+                try:
+                    self.samples.append(self._read())
+                except Exception:          # noqa: BLE001 -- no rocm-smi, no numbers
+                    return
+                self._stop.wait(self.period)
+        self._th = threading.Thread(target=poll, daemon=True)
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._th.join(timeout=15)
+
+    def summary(self):
+        good = [s for s in self.samples[1:] if s[0] is not None and s[1] is not None]      # the first sample predates the load
+        if not good:
+            return None
+        power = sorted(s[0] for s in good)
+        sclk = sorted(s[1] for s in good)
+        return {"package_w": power[len(power) // 2], "sclk_mhz": sclk[len(sclk) // 2], "samples": len(good),
+                "cap_w": PACKAGE_POWER_CAP_W, "at_cap": bool(power[len(power) // 2] >= 0.985 * PACKAGE_POWER_CAP_W)}
+
+
+def power_under_load(g, frame_ms, seconds=1.2):
+    """~1.2 s of back-to-back frames with the sampler running (outside every timed region)."""
+    n = int(max(3, seconds * 1e3 / max(frame_ms, 1e-3)))
+    try:
+        with PowerSampler() as ps:
+            g.time_frames(n)
+        return ps.summary()
+    except Exception:                      # noqa: BLE001
+        return None
+
+
 def launch_roofline(g, wl, launches, rows, n_ev, traffic_key=None):
     """HIP events on the launch's own stream -> (per_launch [(label, ms)], roofline of the dominant launch)."""
     W, bpp = wl["W"], bpp_of(wl["fmt"])
@@ -237,9 +297,9 @@ def side_workload(rf, ctx, name, verify=True):
         launches = g.plan.launch_info()
         g.execute(); g.wait()
         t1 = max(g.time_frames(2) / 2, 1e-3)                      # ms per frame, to size the timed run
-        n = int(max(5, min(300, 250.0 / t1)))                      # ~0.25 s of frames
+        n = int(max(5, min(20000, 300.0 / t1)))                    # ~0.3 s of frames (a 12 ms window read the 4K rgba8 chain 20 % slow: clock ramp)
         frame_ms = g.time_frames(n) / n
-        per_launch, roof = launch_roofline(g, wl, launches, g.rows, max(5, min(n, 100)), traffic_key=name if not vname else name + "_" + vname)
+        per_launch, roof = launch_roofline(g, wl, launches, g.rows, int(max(5, min(n, 150.0 / t1))), traffic_key=name if not vname else name + "_" + vname)
         res = {"ms_per_frame": round(frame_ms, 5), "mpx_per_s": round(wl["W"] * wl["H"] / frame_ms / 1e3, 1), "frames_timed": n,
                "launches": [l["label"] for l in launches], "launch_ms": {k: round(v, 5) for k, v in per_launch}, "roofline": roof}
         if roof["bound"] == "hbm":
@@ -247,6 +307,7 @@ def side_workload(rf, ctx, name, verify=True):
             alg = sum((len(l["inputs"]) + 1) * wl["W"] * g.rows * bpp_of(wl["fmt"]) for l in launches)
             res["frame_hbm_frac"] = round(alg / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             res["frame_algorithmic_bytes"] = alg
+        res["power"] = power_under_load(g, frame_ms)
         if verify:
             g.execute(); g.wait()
             t0 = time.perf_counter()
@@ -431,6 +492,7 @@ def main():
     each = sorted(g.time_each_frame(max(20, min(args.steps * fps, 200))))     # median and min per frame
     frame_events = {"median_ms": round(each[len(each) // 2], 5), "min_ms": round(each[0], 5), "frames": len(each),
                     "note": "hipEvent pair per frame on the frame's stream (adds a marker packet per frame)"}
+    power = power_under_load(g, ms_per_step / fps) if (rank == 0 and world == 1) else None
     working_set = len(g.plan.images()) * W * rows * bpp
     roofline["mall_resident"] = bool(working_set <= MALL_BYTES)
     roofline["working_set_bytes"] = working_set
@@ -475,6 +537,7 @@ def main():
             "parallelism": "1 GPU" if world == 1 else "row strips x%d, halo=%s" % (world, head_mode),
         },
         "roofline": roofline,
+        "power": power,
         "verified": verified,
         "chain_hbm_frac": round(chain_frac, 4),
         "chain_algorithmic_bytes_per_px": n_nodes * 2 * bpp,

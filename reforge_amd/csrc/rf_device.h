@@ -65,6 +65,20 @@ RF_DEV float unorm8_code(float v)
     return rintf(fmaf(__builtin_amdgcn_fmed3f(v, 0.0f, 1.0f), 255.0f, 0.0f));
 }
 RF_DEV unsigned f32_to_unorm8(float v) { return (unsigned)unorm8_code(v); }
+// The same two conversions on a PAIR of channels: the x255 and the /255 run as packed operations (v_pk_fma_f32 /
+// v_pk_mul_f32: one instruction for two channels; the same IEEE operation per channel, so the same bits).
+RF_DEV v2f unorm8_code2(v2f v)
+{
+    const v2f c = {__builtin_amdgcn_fmed3f(v.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(v.y, 0.0f, 1.0f)};
+    const v2f s = __builtin_elementwise_fma(c, v2f{255.0f, 255.0f}, v2f{0.0f, 0.0f});
+    return v2f{rintf(s.x), rintf(s.y)};
+}
+RF_DEV v2f unorm8_code_to_f32_2(v2f x)
+{
+    const float hi = 1.0f / 255.0f;
+    const float lo = (float)(1.0 / 255.0 - (double)(1.0f / 255.0f));
+    return __builtin_elementwise_fma(x, v2f{hi, hi}, x * v2f{lo, lo});
+}
 struct PxF32 {
     typedef f4 Raw;
     static constexpr int BPP = 16;
@@ -111,17 +125,22 @@ struct PxU8 {
     RF_DEV static Raw load(const char* row, unsigned xoff) { return *reinterpret_cast<const unsigned*>(row + xoff); }
     RF_DEV static f4 decode(Raw r)
     {
-        return make_float4(unorm8_to_f32(r & 255u), unorm8_to_f32((r >> 8) & 255u),
-                           unorm8_to_f32((r >> 16) & 255u), unorm8_to_f32(r >> 24));
+        const v2f lo = unorm8_code_to_f32_2(v2f{(float)(r & 255u), (float)((r >> 8) & 255u)});
+        const v2f hi = unorm8_code_to_f32_2(v2f{(float)((r >> 16) & 255u), (float)(r >> 24)});
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
     }
     RF_DEV static f4 take(Raw r) { return decode(r); }   // the conversion already leaves the ring slot dead
     RF_DEV static unsigned pack(f4 v)
     {
-        // v_cvt_pk_u8_f32 converts an (already integer-valued) float and inserts it as one byte
-        unsigned o = __builtin_amdgcn_cvt_pk_u8_f32(unorm8_code(v.x), 0u, 0u);
-        o = __builtin_amdgcn_cvt_pk_u8_f32(unorm8_code(v.y), 1u, o);
-        o = __builtin_amdgcn_cvt_pk_u8_f32(unorm8_code(v.z), 2u, o);
-        return __builtin_amdgcn_cvt_pk_u8_f32(unorm8_code(v.w), 3u, o);
+        // v_cvt_pk_u8_f32 IS imageStore's conversion once the value is scaled: it saturates to [0, 255], rounds to
+        // nearest even and turns NaN into 0 (scripts/cvt_probe.hip: 1573 values incl. every tie, the neighbours of every
+        // tie, infinities and NaN against clamp + rint) -- no clamp and no v_rndne in front of it.
+        const v2f lo = __builtin_elementwise_fma(v2f{v.x, v.y}, v2f{255.0f, 255.0f}, v2f{0.0f, 0.0f});
+        const v2f hi = __builtin_elementwise_fma(v2f{v.z, v.w}, v2f{255.0f, 255.0f}, v2f{0.0f, 0.0f});
+        unsigned o = __builtin_amdgcn_cvt_pk_u8_f32(lo.x, 0u, 0u);
+        o = __builtin_amdgcn_cvt_pk_u8_f32(lo.y, 1u, o);
+        o = __builtin_amdgcn_cvt_pk_u8_f32(hi.x, 2u, o);
+        return __builtin_amdgcn_cvt_pk_u8_f32(hi.y, 3u, o);
     }
     RF_DEV static void store(char* row, unsigned xoff, f4 v) { *reinterpret_cast<unsigned*>(row + xoff) = pack(v); }
     RF_DEV static void store_row(char* row, unsigned xoff, f4 v)       // wave-uniform row address: see PxF32::store_row
@@ -133,8 +152,9 @@ struct PxU8 {
     // the trip through the integer byte (the code is the same number either way)
     RF_DEV static f4 requant(f4 v)
     {
-        return make_float4(unorm8_code_to_f32(unorm8_code(v.x)), unorm8_code_to_f32(unorm8_code(v.y)),
-                           unorm8_code_to_f32(unorm8_code(v.z)), unorm8_code_to_f32(unorm8_code(v.w)));
+        const v2f lo = unorm8_code_to_f32_2(unorm8_code2(v2f{v.x, v.y}));
+        const v2f hi = unorm8_code_to_f32_2(unorm8_code2(v2f{v.z, v.w}));
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
     }
 };
 

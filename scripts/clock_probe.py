@@ -29,8 +29,9 @@ def poll():
 ctx = rf.Context(0)
 names = sys.argv[1:] or ["chain5_16k", "gauss9_8k", "chain3_4k", "conv31_8k"]
 for name in names:
+    name, _, texels = name.partition(":")             # workload[:texels per lane]
     wl = bench.WORKLOADS[name]
-    g = rf.Graph(ctx, rf.Config(wl["text"]), wl["W"], wl["H"], wl["fmt"])
+    g = rf.Graph(ctx, rf.Config(wl["text"]), wl["W"], wl["H"], wl["fmt"], texels_per_lane=int(texels or 0))
     g.fill_synthetic(wl["seed"])
     g.execute(); g.wait()
     per = g.time_frames(3) / 3
@@ -42,9 +43,9 @@ for name in names:
     ms = g.time_frames(n) / n
     stop.set()
     th.join()
-    print(name, "ms/frame %.4f over %d frames" % (ms, n))
+    print(name, "texels_per_lane", texels or "auto", "ms/frame %.4f over %d frames" % (ms, n))
     for s in samples[1:-1][:12]:
-        print("   ", s)
+        print("   ", {k.replace(" clock speed:", "").replace("Current Socket Graphics Package ", ""): v for k, v in s.items() if "level" not in k})
     g.close()
 time.sleep(1.0)
 print("idle:", subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True).stdout[:600])

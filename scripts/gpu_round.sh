@@ -17,13 +17,13 @@ timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_defa
 python3 - <<'PY'
 import json
 d = json.load(open("gpurun_out/bench_default.json"))
-print("value", d["value"], "frac", d["roofline"]["frac"], "launch_ms", d["roofline"]["launch_ms"], "verified", d["verified"], "region_s", d["config"]["timed_region_s"])
+print("power", d.get("power")); print("value", d["value"], "frac", d["roofline"]["frac"], "launch_ms", d["roofline"]["launch_ms"], "verified", d["verified"], "region_s", d["config"]["timed_region_s"])
 for k, v in d.get("workloads", {}).items():
     if "error" in v:
         print(k, "ERROR", v["error"]); continue
     if k == "conv31_8k":
         for p in ("valu", "mfma"):
-            print(k, p, v[p]["ms_per_frame"], v[p]["roofline"]["frac"], v[p].get("verified"))
+            print(k, p, v[p]["ms_per_frame"], v[p]["roofline"]["frac"], v[p].get("verified"), v[p].get("power"))
     else:
-        print(k, v["ms_per_frame"], v["roofline"]["frac"], v.get("frame_hbm_frac"), v.get("verified"))
+        print(k, v["ms_per_frame"], v["roofline"]["frac"], v.get("frame_hbm_frac"), v.get("verified"), v.get("power"))
 PY
