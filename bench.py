@@ -85,6 +85,7 @@ WORKLOADS = {
 SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "diamond_4k"]
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec)
+NO_POWER = False               # --no-power
 PACKAGE_POWER_CAP_W = 1400.0   # MI355X board power limit (rocm-smi reports 1395-1400 W on every capped kernel)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 MFMA peak (= f32 vector peak)
 MALL_BYTES = 256 << 20         # MI355X_MICROARCH.md: Infinity Cache
@@ -203,9 +204,20 @@ class PowerSampler:
         self.period, self.samples, self._stop, self._th = period, [], None, None
 
     @staticmethod
+    def _profiler_env(k, v):
+        return k.startswith(("ROCPROF", "ROCP_", "HSA_TOOLS_LIB", "ROCTX")) or (k == "LD_PRELOAD" and "rocprof" in v.lower())
+
+    @staticmethod
+    def usable():
+        """Never under a profiler: rocm-smi would start with the tool's library in it (a second GPU-initialising program
+        launched from this one), and the numbers would describe the profiling clock anyway."""
+        return not any(PowerSampler._profiler_env(k, v) for k, v in os.environ.items())
+
+    @staticmethod
     def _read():
         import subprocess
-        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=10).stdout
+        env = {k: v for k, v in os.environ.items() if not PowerSampler._profiler_env(k, v)}
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=10, env=env).stdout
         card = json.loads(out)
         card = card[sorted(card)[0]]
         power = [float(v) for k, v in card.items() if "ower" in k and "(W)" in k]
@@ -243,6 +255,8 @@ class PowerSampler:
 
 def power_under_load(g, frame_ms, seconds=1.2):
     """~1.2 s of back-to-back frames with the sampler running (outside every timed region)."""
+    if NO_POWER or not PowerSampler.usable():
+        return None
     n = int(max(3, seconds * 1e3 / max(frame_ms, 1e-3)))
     try:
         with PowerSampler() as ps:
@@ -359,11 +373,14 @@ def main():
                     help="frame slots the batch alternates over (reforge's --num-frames; each slot has its own stream and images)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-workloads", action="store_true", help="N = 1: only the headline workload")
+    ap.add_argument("--no-power", action="store_true", help="do not poll rocm-smi for package power / clock (it is never polled under a profiler)")
     ap.add_argument("--skip-strong", action="store_true", help="N > 1: skip the 16384^2 strong-scaling run")
     ap.add_argument("--conv-path", type=int, default=0, help="conv2d kernel for --workload conv31_8k (rf_graph_options.conv_path)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 plumbing check on a one-GPU box: all ranks on device 0, gloo barrier, over-fetch only; numbers are meaningless")
     args = ap.parse_args()
+    global NO_POWER
+    NO_POWER = bool(args.no_power)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

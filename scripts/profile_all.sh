@@ -16,7 +16,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$ROOT"
 for wl in $WORKLOADS; do
   name="${wl%_unfused}"
-  extra="--skip-workloads"; [ "$wl" != "$name" ] && extra="$extra --no-fusion"
+  extra="--skip-workloads --no-power"; [ "$wl" != "$name" ] && extra="$extra --no-fusion"
   case "$name" in
     conv31_8k_valu)   name=conv31_8k; extra="$extra --conv-path 3" ;;
     conv31_8k_mfma)   name=conv31_8k; extra="$extra --conv-path 2" ;;
