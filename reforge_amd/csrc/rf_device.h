@@ -113,7 +113,11 @@ struct PxF32 {
     {
         typedef float v4f __attribute__((ext_vector_type(4)));
         const v4f d = {v.x, v.y, v.z, v.w};
-        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(xoff), "v"(d), "s"(row) : "memory");
+        // The s_nop is part of the store: on gfx940+ a vector-memory store of more than 8 bytes reads its data registers up to
+        // two wait states after it issues, and hipcc's hazard recogniser, which would keep a VALU write to them away, cannot
+        // see into an asm statement (scripts/fuzz_graphs.py seeds 7054 / 7063 / 7113: a run-time compiled fork/join kernel
+        // scheduled such a write right behind the store -- a few thousand wrong texels per frame, different ones each run).
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(xoff), "v"(d), "s"(row) : "memory");
     }
     RF_DEV static f4 requant(f4 v) { return v; }
 };

@@ -126,6 +126,35 @@ def test_random_graphs_1080p_whole_frame(ctx, seed):
         pixel.set_threads(1)
 
 
+STORE_HAZARD_GRAPHS = [
+    # scripts/fuzz_graphs.py seeds 7054 / 7063 / 7113: fork/join pipelines compiled at graph creation whose schedule put a
+    # VALU write to the store's data registers one wait state behind the (inline-asm) global_store_dwordx4 -- gfx940+ needs
+    # two for a store of more than 8 bytes, and the hazard recogniser does not look into asm (PxF32::store_row)
+    "input -> n00 -> n01 -> mx:input_image0\nn00 -> n02 -> mx:input_image1\nmx -> output\nn00: colour_grade { slope: 1.20, offset: 0.065, saturation: 0.46 }\n"
+    "n01: colour_grade { slope: 1.17, offset: 0.086, saturation: 0.22 }\nn02: sharpen { amount: 1.35 }\nmx: combination { mix: 0.60 }",
+    "input -> n00 -> n01 -> mx:input_image0\nn00 -> n02 -> mx:input_image1\nmx -> output\nn00: colour_grade { slope: 0.63, offset: -0.030, saturation: 0.93 }\n"
+    "n01: gaussian5 { sigma: 2.74 }\nn02: gaussian5 { sigma: 1.48 }\nmx: combination { mix: 0.99 }",
+    "input -> n00 -> n01 -> mx:input_image0\nn00 -> n02 -> mx:input_image1\nmx -> output\nn00: conv2d { ksize: 3, sigma: 1.51 }\n"
+    "n01: colour_grade { slope: 0.98, offset: -0.080, saturation: 1.29 }\nn02: gaussian { sigma: 1.73, radius: 3 }\nmx: combination { mix: 0.31 }",
+]
+
+
+@pytest.mark.parametrize("k", range(len(STORE_HAZARD_GRAPHS)))
+def test_store_data_hazard_graphs_1080p(ctx, k):
+    """The graphs that exposed the store-data hazard of the asm store (a few thousand wrong texels per 1080p frame, different
+    ones each run), whole frame against the oracle, three runs each."""
+    text = STORE_HAZARD_GRAPHS[k]
+    pixel.set_threads(min(16, os.cpu_count() or 1))
+    try:
+        x = pixel.fill_synthetic(1920, 1080, util.F32, 7054 + k)
+        want = util.run_oracle(text, x)
+        for rep in range(3):
+            util.assert_same(util.run_hip(ctx, text, x), want, "store hazard graph %d run %d" % (k, rep))
+        util.assert_same(util.run_hip(ctx, text, x, flags=rf.RF_GRAPH_HIPGRAPH), want, "store hazard graph %d replayed" % k)
+    finally:
+        pixel.set_threads(1)
+
+
 def test_config4_chain5_whole_16k_frame_one_gpu(ctx):
     """BASELINE config 4's whole 16384 x 16384 rgba32f frame on ONE GPU (what bench.py --workload
     chain5_16k times at N=1): 4 GiB per image, byte offsets beyond 2^31 and 2^32.  Fused (one

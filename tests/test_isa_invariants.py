@@ -83,6 +83,11 @@ def test_stream_kernels_keep_the_counted_wait_contract(stream_asm):
         for i, ins in enumerate(instrs):
             if ins.startswith("global_load_lds"):
                 assert any(p.startswith("s_waitcnt") and "lgkmcnt(0)" in p for p in instrs[max(0, i - 5):i]), name
+        # the rgba32f store is inline asm, so hipcc's hazard recogniser cannot keep a VALU write to its data registers two
+        # wait states away (gfx940+: stores of more than 8 bytes): the asm carries its own s_nop 1
+        for i, ins in enumerate(instrs):
+            if ins.startswith("global_store_dwordx4"):
+                assert instrs[i + 1].split()[:2] == ["s_nop", "1"], (name, instrs[i:i + 3])
         pf, t = prefetch_depth(name)
         for loop in steady_loops(body, pf, t):
             ops = [x.split()[0] for x in loop]
