@@ -362,7 +362,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="chain3_4k", choices=sorted(WORKLOADS))
-    ap.add_argument("--halo", default="both", choices=["both", "overfetch", "exchange"],
+    ap.add_argument("--halo", default=None, choices=["both", "overfetch", "exchange"],
                     help="N > 1: which ghost-row schedule(s) to time; `value` is the faster one, both are reported under `halo`")
     ap.add_argument("--no-fusion", action="store_true", help="one launch per node, as the reference dispatches")
     ap.add_argument("--hipgraph", action="store_true")
@@ -421,10 +421,10 @@ def main():
     modes = []
     if world == 1:
         modes = ["single"]
-    elif args.rehearse:
-        modes = ["overfetch"]
     else:
-        modes = {"both": ["overfetch", "exchange"], "overfetch": ["overfetch"], "exchange": ["exchange"]}[args.halo]
+        # a rehearsal (all ranks on one GPU) can only exchange through the RCCL test double (RF_RCCL_LIBRARY): over-fetch unless asked
+        halo = args.halo or ("overfetch" if args.rehearse else "both")
+        modes = {"both": ["overfetch", "exchange"], "overfetch": ["overfetch"], "exchange": ["exchange"]}[halo]
     comm_info = None
     ctx_plain = rf.Context(local_rank, rank, world, None) if world > 1 else rf.Context(local_rank)
     ctx_rccl, rccl_error = None, None
@@ -465,8 +465,28 @@ def main():
     # ---- the headline: K timed steps per halo schedule -------------------------------------------
     legs = {}
     fps = args.frames_per_step
-    for mode in modes:
-        ctx, g = make_graph(mode, wl, H)
+    poisoned = False                                   # an exchange that failed may have left a collective stuck on its stream
+    for mode in list(modes):
+        if mode == "exchange":
+            # Real RCCL between GPUs first runs on the driver's node: probe ONE frame (the first exchange of a context is
+            # waited for with a bound, RF_XCHG_TIMEOUT_S), then let every rank agree before the leg's collectives start --
+            # a failure here costs the exchange row of the JSON line, not the run.
+            err = None
+            try:
+                ctx, g = make_graph(mode, wl, H)
+                g.execute(0)
+                g.wait(0)
+            except rf.RfError as e:
+                err = str(e)
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                rccl_error = err or "another rank failed its first halo exchange"
+                modes.remove("exchange")
+                poisoned = True
+                continue
+        else:
+            ctx, g = make_graph(mode, wl, H)
         launches = g.plan.launch_info()
         if fps <= 0:
             # size the batch in the warm-up: K steps of `fps` frames should last ~0.6 s
@@ -579,11 +599,21 @@ def main():
         if args.rehearse:
             wl16 = dict(wl16, W=2048, H=2048)          # plumbing only: every rank shares one GPU
         strong_out = {"workload": wl16["desc"], "frame": "%dx%d" % (wl16["W"], wl16["H"])}
-        for mode in modes:
-            c16, g16 = make_graph(mode, wl16, wl16["H"])
-            for i in range(3):
-                g16.execute(0)
-            g16.wait(0)
+        for mode in list(modes):
+            err = None
+            try:
+                c16, g16 = make_graph(mode, wl16, wl16["H"])
+                for i in range(3):
+                    g16.execute(0)
+                g16.wait(0)
+            except rf.RfError as e:
+                err = str(e)
+            okt = torch.tensor([0 if err else 1], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if int(okt.item()) == 0:               # every rank skips the leg together (see the headline's probe)
+                strong_out[mode] = {"error": err or "another rank failed"}
+                poisoned = poisoned or mode == "exchange"
+                continue
             n16 = 100 if not args.rehearse else 20
             barrier_sync()
             t0 = time.perf_counter()
@@ -624,6 +654,15 @@ def main():
                     out["workloads"][name] = {"error": str(e)}
         if not args.skip_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
+    if poisoned:
+        # do not tear down a communicator with a collective possibly stuck on it: print the line and leave at once
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if ctx_rccl is not None:
         ctx_rccl.close()
     ctx_plain.close()

@@ -38,10 +38,14 @@ RcclLib* rccl_lib(std::string& err)
     if (lib.handle) return &lib;
     if (tried) { err = "librccl.so could not be loaded"; return nullptr; }
     tried = true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // RF_RCCL_LIBRARY = path of the library to bind instead (a specific RCCL build; the test double under a host that has
+    // already mapped its own librccl.so.1, e.g. PyTorch: a dlopen by SONAME would return that copy)
+    const char* forced = std::getenv("RF_RCCL_LIBRARY");
+    const char* names[] = {forced && *forced ? forced : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         lib.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (lib.handle) break;
+        if (forced && *forced && n == names[0]) { err = std::string("dlopen(RF_RCCL_LIBRARY): ") + dlerror(); return nullptr; }
     }
     if (!lib.handle) { err = std::string("dlopen(librccl): ") + dlerror(); return nullptr; }
     bool ok = true;

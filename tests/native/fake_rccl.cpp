@@ -143,6 +143,13 @@ int ncclGroupStart()
 int ncclGroupEnd()
 {
     if (--g_depth > 0) return 0;
+    // FAKE_RCCL_FAIL=1: every exchange fails (bench.py's probe-and-agree path, tests/test_gpu_exchange.py)
+    if (const char* e = std::getenv("FAKE_RCCL_FAIL")) {
+        if (*e == '1') {
+            g_ops.clear();
+            return 5;
+        }
+    }
     return run_ops();
 }
 

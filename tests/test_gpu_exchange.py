@@ -4,6 +4,7 @@ RCCL refuses two ranks on one device, so the processes load tests/native/fake_rc
 points librfhip dlopens, with the real signatures, over shared memory -- in its place.  Everything
 else is the product.  (The real library's ABI is covered by rf_comm_selftest; the schedule by
 tests/test_dist_gloo.py; real multi-GPU runs are the driver's.)"""
+import json
 import os
 import subprocess
 import sys
@@ -121,3 +122,35 @@ def test_srgb_strips(fake_rccl_dir, tmp_path):
         ref.upload_srgb8(rgba)
         ref.execute()
         assert got.tobytes() == ref.download_srgb8().tobytes()
+
+
+def _bench_rehearsal(fake_dir, port, fail):
+    """bench.py as the driver launches it for N = 2, rehearsed on one GPU: both ranks on device 0, gloo for the bench's own
+    collectives, the halo exchange through the RCCL test double (RF_RCCL_LIBRARY: torch has mapped its own librccl.so.1)."""
+    env = dict(os.environ, RF_RCCL_LIBRARY=os.path.join(fake_dir, "librccl.so.1"), MASTER_ADDR="127.0.0.1")
+    if fail:
+        env["FAKE_RCCL_FAIL"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse", "--halo", "both", "--skip-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_times_both_halo_schedules(fake_rccl_dir):
+    out = _bench_rehearsal(fake_rccl_dir, 29541, fail=False)
+    assert out["n_gpus"] == 2 and set(out["halo"]) >= {"overfetch", "exchange", "value_is"}, out.get("halo")
+    assert "rccl_error" not in out
+    assert "fake" in out["rccl_library"] or "librccl.so.1" in out["rccl_library"]
+    assert set(out["strong_16k"]) >= {"overfetch", "exchange"} and "error" not in out["strong_16k"]["exchange"]
+
+
+def test_bench_survives_a_failing_exchange(fake_rccl_dir):
+    """The first real RCCL exchange between GPUs happens on the driver's node: if it fails, every rank must drop the exchange
+    leg together and the run must still print its line (the over-fetch number) and exit 0."""
+    out = _bench_rehearsal(fake_rccl_dir, 29542, fail=True)
+    assert out["n_gpus"] == 2 and out["halo"]["value_is"] == "overfetch" and "exchange" not in out["halo"]
+    assert out["rccl_error"], out
+    assert out["value"] > 0 and "overfetch" in out["strong_16k"]
