@@ -47,3 +47,24 @@ def test_exchange_rows_closes_its_group_on_every_path():
     between = body[body.index("GroupStart());") + len("GroupStart());"):body.index("GroupEnd()")]
     assert "return" not in between, "a return between ncclGroupStart and ncclGroupEnd leaves the group open"
     assert "NCCL_TRY" not in between, "NCCL_TRY returns early inside the open group"
+
+
+def _unique_id_in_a_child(env_extra):
+    """rf_comm_unique_id in a fresh process (the library binds RCCL once per process)"""
+    code = ("import sys; sys.path.insert(0, %r)\nimport reforge_amd as rf\n"
+            "try:\n    uid = rf.Context.unique_id(); print('OK', len(uid), rf.lib().rf_comm_library().decode())\n"
+            "except rf.RfError as e:\n    print('ERR', e)\n" % ROOT)
+    import sys
+    return subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=120).stdout
+
+
+def test_rf_rccl_library_binds_the_named_build(tmp_path):
+    """RF_RCCL_LIBRARY names the RCCL build to bind (a host that has mapped its own librccl.so.1 -- PyTorch -- would otherwise win
+    the dlopen by SONAME); a path that cannot be loaded is an error, never a silent fall-back to some other copy."""
+    out = _unique_id_in_a_child({"RF_RCCL_LIBRARY": str(tmp_path / "no_such_librccl.so")})
+    assert out.startswith("ERR") and "RF_RCCL_LIBRARY" in out, out
+    so = str(tmp_path / "libfake_rccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-shared", "-fPIC", "-x", "c++", os.path.join(ROOT, "tests", "native", "fake_rccl.cpp")]
+                          + INC + ["-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-o", so], stderr=subprocess.DEVNULL)
+    out = _unique_id_in_a_child({"RF_RCCL_LIBRARY": so})
+    assert out.startswith("OK 128") and "libfake_rccl.so" in out, out
