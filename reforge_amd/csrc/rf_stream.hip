@@ -65,11 +65,13 @@ static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo
     // 36-row chunks = 1020 workgroups on 1024 slots, 194.6k Mpx/s; 24-row 191k; 44-row 180k)
     int rpc = (int)(fit < lo ? lo : (fit > 2 * hi ? hi : fit));
     rpc = (rpc + 3) & ~3;
-    // a few rounds: use the rounds in full -- as many chunks as that number of rounds holds
+    // a few rounds: use the rounds in full -- as many chunks as that number of rounds holds.  (16384^2 5-stage chain, two
+    // texels per lane, 512 slots, 36 strip groups: 256-row chunks = 2304 workgroups = 4.5 rounds, 1.85-1.90 ms; 71 chunks of
+    // 231 rows = 4.99 rounds, 1.79 ms; 72 chunks = 5.06 rounds, 1.90 ms -- scripts/walk_probe.py, the cliff is that sharp)
     {
         const int chunks0 = (rows + rpc - 1) / rpc;
         const long rounds = ((long)chunks0 * strip_groups + slots - 1) / slots;
-        if (rounds >= 2 && rounds <= 4) {
+        if (rounds >= 2 && rounds <= 8) {
             const long chunks = rounds * slots / strip_groups;
             if (chunks > chunks0) {
                 int r2 = (int)((rows + chunks - 1) / chunks);
@@ -478,6 +480,8 @@ int ops_radius(const Op* ops, int n)
 // Two texels per lane are never used in place (the last strip overlaps its neighbour: see
 // stream_kernel), for rgba8 (its lanes would issue four 256-B DMAs per row) or for narrow frames.
 constexpr int kHeavyTaps = 24;
+constexpr long kTopDownMinPixels = 48L << 20;       // light rgba32f pipelines walk top-down from here up
+constexpr long kTwoTexelLightMinPixels = 200L << 20;   // ... and take two texels per lane from here up
 constexpr long kTwoTexelMinPixels = 24L << 20;   // two texels per lane from 8K frames up (5-stage chain at 4K: 64.4 us with one, 68.3 with two)
 
 static int choose_texels(int fmt, const StageList& sl, Image src, Image dst, const Geom& g, StreamTuning& t)
@@ -486,10 +490,15 @@ static int choose_texels(int fmt, const StageList& sl, Image src, Image dst, con
     const bool heavy = sl.taps() >= kHeavyTaps;
     // rgba8 pipelines are bound by vector issue whatever their length (conversion arithmetic): top-down as well
     // (4K 3-stage chain 40.1 -> 39.2 us, 8K gaussian9 117.7 -> 114.3 us)
-    if (t.walk == 0) t.walk = (heavy || fmt == kFmtRGBA8) ? 2 : 1;
+    // ... and so do the light pipelines once the frame is far beyond the Infinity Cache (gaussian9: 7680x4320 alternating 184 us,
+    // top-down 189-197; 8192^2 413 -> 397; 16384x4096 416 -> 387; 12288^2 868 -> 847.  3-stage chain 12288^2 915 -> 869)
+    if (t.walk == 0) t.walk = (heavy || fmt == kFmtRGBA8 || px >= kTopDownMinPixels) ? 2 : 1;
     if (sl.sum_rh() > 7 || sl.max_rv() > 4 || sl.pair()) return 1;
     const bool can2 = src.base != dst.base && g.W >= 256;
-    const bool two = t.texels_per_lane == 2 || (t.texels_per_lane == 0 && fmt == kFmtRGBA32F && heavy && px >= kTwoTexelMinPixels);
+    // two texels per lane: heavy pipelines from 8K frames up, every rgba32f pipeline on the very largest frames (16384^2:
+    // gaussian9 1.76 -> 1.53 ms, 3-stage chain 1.72 -> 1.61, passthrough 1.52 -> 1.46; 12288^2: no gain yet)
+    const bool two = t.texels_per_lane == 2 ||
+                     (t.texels_per_lane == 0 && fmt == kFmtRGBA32F && t.walk == 2 && px >= (heavy ? kTwoTexelMinPixels : kTwoTexelLightMinPixels));
     return (two && can2) ? 2 : 1;
 }
 
