@@ -38,6 +38,19 @@ namespace rf {
 // ---------------------------------------------------------------------------------
 // Host side: op list -> stage list -> kernel instantiation
 // ---------------------------------------------------------------------------------
+static int device_cus()
+{
+    static int cus_of[64] = {};                      // per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus_of[dev] == 0) {
+        int cus = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cus_of[dev] = cus > 0 ? cus : 256;
+    }
+    return cus_of[dev];
+}
+
 static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo_rows, int bpp, const StreamTuning& tune, bool top_down)
 {
     if (tune.rows_per_chunk > 0) return tune.rows_per_chunk;
@@ -77,6 +90,29 @@ static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo
                 int r2 = (int)((rows + chunks - 1) / chunks);
                 if (r2 >= lo) rpc = r2;
             }
+        }
+    }
+    // ONE round: what counts then is the busiest CU.  The dispatcher deals workgroups evenly, so a launch of k x CUs workgroups
+    // (just below) finishes together, while k.5 x CUs leaves half the CUs a workgroup longer than the rest.  Among the chunk
+    // heights around the one chosen above take the one with the least rows on the busiest CU (4K 3-stage rgba32f chain, 17 strip
+    // groups, 5 workgroups per CU: 32-row chunks = 1156 workgroups = 4.5 per CU, 42.5 us; 29 rows = 1275 = 4.98, 41.7; 36 rows =
+    // 1020 = 3.98, 41.7; 34 rows = 4.25 per CU, 43.4; 44 rows = 3.3, 44.6 -- scripts/walk_probe.py, repeatable to 0.1 us)
+    {
+        const int cus = device_cus();
+        const long wgs0 = (long)((rows + rpc - 1) / rpc) * strip_groups;
+        if (wgs0 <= slots && wgs0 > cus && rpc < rows) {
+            auto busiest = [&](int r) {
+                const long wgs = (long)((rows + r - 1) / r) * strip_groups;
+                return wgs > slots ? 1L << 40 : ((wgs + cus - 1) / cus) * (long)(r + 2 * h);
+            };
+            int best = rpc;
+            long best_cost = busiest(rpc);
+            const int from = rpc - rpc / 6 > lo ? rpc - rpc / 6 : lo, to = rpc + rpc / 4;
+            for (int r = from; r <= to && r <= rows; ++r) {
+                const long c = busiest(r);
+                if (c < best_cost) { best_cost = c; best = r; }
+            }
+            rpc = best;
         }
     }
     if (rpc > rows) rpc = rows;
