@@ -26,6 +26,7 @@
 // time, each half still a single-rounding fma); this file is compiled with -ffp-contract=off,
 // so results are bit-identical to oracle/rf_oracle.c for finite inputs.
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <string>
@@ -64,7 +65,8 @@ static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo
     // size for rgba32f; 3-stage chain 12/16/24/24/24; gaussian9 12/24/24/32/32; 5-stage chain
     // 12/24/32/64/96 -- e.g. the 5-stage chain at 1080p 34 us with 24-row chunks, 66 us with 112):
     const int h = halo_rows;
-    const bool narrow = bpp == 4;                    // rgba8: bound by VALU issue, halo recompute costs more
+    const bool narrow = bpp == 4;                    // rgba8: bound by its arithmetic, every halo row a chunk recomputes costs in full (7680x4320:
+                                                     // gaussian9 40-row chunks 101 us, 85-row 95, 128-row 96; 3-stage chain 28-row 121, 96-row 113)
     // shortest chunks with every workgroup resident: at most slots / strip_groups chunks (a
     // 31-tap gaussian at 4K, one workgroup per CU: 9 chunks x 29 groups = 261 workgroups on 256
     // slots ran two rounds, 457 us; 8 chunks = 232 workgroups, 271 us)
@@ -73,7 +75,7 @@ static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo
     const int lo = h > 4 ? 2 * h : 8;
     // all-top-down walks share no halo rows through L2: each chunk fetches its own, so they are taller (16384^2 5-stage chain,
     // two texels per lane: 112-row chunks 1.87 ms, 256-row 1.81, 384-row 2.01)
-    const int hi = narrow ? (12 * h > 16 ? 12 * h : 16) : (h <= 4 ? (8 * h > 8 ? 8 * h : 8) : (top_down ? 36 * h : 16 * h));   // 5-stage chain (h = 7) at 16384^2: 128-row 2.03 ms, 96-row 2.08, 84-row 2.12
+    const int hi = narrow ? (h == 0 ? 16 : (24 * h > 32 ? 24 * h : 32)) : (h <= 4 ? (8 * h > 8 ? 8 * h : 8) : (top_down ? 36 * h : 16 * h));   // 5-stage chain (h = 7) at 16384^2: 128-row 2.03 ms, 96-row 2.08, 84-row 2.12
     // a frame that fits ONE round at up to twice the cap keeps the single round (4K 3-stage chain:
     // 36-row chunks = 1020 workgroups on 1024 slots, 194.6k Mpx/s; 24-row 191k; 44-row 180k)
     int rpc = (int)(fit < lo ? lo : (fit > 2 * hi ? hi : fit));
@@ -340,6 +342,10 @@ static bool launch_shape(Image src, Image dst, const Geom& g, const StreamTuning
     A.n_work = groups * ((rows + A.rows_per_chunk - 1) / A.rows_per_chunk);
     A.alternate = tune.walk == 2 ? 0 : 1;
     out.grid = (unsigned)((A.n_work + 7) / 8 * 8);   // 1-D, a multiple of the 8 XCDs (see the kernel's block order)
+    static const bool trace = std::getenv("RF_TRACE_SHAPE") != nullptr;      // diagnostics: the launch geometry, to stderr
+    if (trace)
+        std::fprintf(stderr, "rf shape: %dx%d rows, bpp %d, texels %d, walk %d: %d strips in %d groups, %d-row chunks, %d workgroups on %d resident (%d CUs)\n",
+                     g.W, rows, bpp, texels, tune.walk, A.n_strips, groups, A.rows_per_chunk, A.n_work, resident, device_cus());
     return true;
 }
 
