@@ -86,6 +86,7 @@ SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "diamo
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec)
 NO_POWER = False               # --no-power
+SHADER_CLOCK_MAX_MHZ = 2400.0  # what rocm-smi shows on an idle or lightly loaded MI355X
 PACKAGE_POWER_CAP_W = 1400.0   # MI355X board power limit (rocm-smi reports 1395-1400 W on every capped kernel)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 MFMA peak (= f32 vector peak)
 MALL_BYTES = 256 << 20         # MI355X_MICROARCH.md: Infinity Cache
@@ -250,7 +251,8 @@ class PowerSampler:
         power = sorted(s[0] for s in good)
         sclk = sorted(s[1] for s in good)
         return {"package_w": power[len(power) // 2], "sclk_mhz": sclk[len(sclk) // 2], "samples": len(good),
-                "cap_w": PACKAGE_POWER_CAP_W, "at_cap": bool(power[len(power) // 2] >= 0.985 * PACKAGE_POWER_CAP_W)}
+                "cap_w": PACKAGE_POWER_CAP_W, "at_cap": bool(power[len(power) // 2] >= 0.985 * PACKAGE_POWER_CAP_W),
+                "clock_pulled_down": bool(sclk[len(sclk) // 2] < 0.97 * SHADER_CLOCK_MAX_MHZ)}
 
 
 def power_under_load(g, frame_ms, seconds=1.2):
