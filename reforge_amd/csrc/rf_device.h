@@ -29,6 +29,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // the weight already as a pair {w, w}: stage parameters are stored that way, so that a weight is ONE aligned 8-byte
 // scalar load (hipcc otherwise widens neighbouring float loads into overlapping vector loads, which can pin the whole
 // parameter block to scratch: it did for the grade -> gaussian chains)
+#ifdef RF_EXPERIMENT_NO_FMA      // timing-only build (scripts/mk_variant.sh): the taps are fetched but not summed -- WRONG results
+RF_DEV f4 fma4(v2f, f4 v, f4) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); return v; }
+RF_DEV f4 fma4(float, f4 v, f4) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); return v; }
+#else
 RF_DEV f4 fma4(v2f ww, f4 v, f4 a)
 {
     const v2f lo = __builtin_elementwise_fma(ww, v2f{v.x, v.y}, v2f{a.x, a.y});
@@ -42,6 +46,7 @@ RF_DEV f4 fma4(float w, f4 v, f4 a)
     const v2f hi = __builtin_elementwise_fma(ww, v2f{v.z, v.w}, v2f{a.z, a.w});
     return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
+#endif
 
 // ---------------------------------------------------------------------------------
 // Texel formats: what imageLoad/imageStore do (shaders/passthrough.comp:9,:12)

@@ -166,7 +166,11 @@ template <int R, int T> struct TapFeed {         // rgba32f: the 2R+1 horizontal
         for (int j = 0; j < T; ++j) {
             const f4* base = row + min(max(L.pos(j) - R, 0), 64 * T - 1 - 2 * R);
 #pragma unroll
+#ifdef RF_EXPERIMENT_NO_EXCHANGE     // timing-only build (scripts/mk_variant.sh): every tap reads the centre texel -- WRONG results
+            for (int i = 0; i <= 2 * R; ++i) t[j][i] = base[R];
+#else
             for (int i = 0; i <= 2 * R; ++i) t[j][i] = base[i];
+#endif
         }
     }
     RF_DEV Tex<T> own() const
@@ -211,17 +215,23 @@ template <int R> struct StHTap {
     }
     template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, NoState&, const Lane<T>& L, f4* lds, const Tex<T>& v, bool, bool, bool, Tex<T>& out)
     {
+#ifndef RF_EXPERIMENT_NO_EXCHANGE
         if constexpr (R > 0) {
 #pragma unroll
             for (int j = 0; j < T; ++j) lds[L.pos(j)] = v.v[j];
             wave_sync();
         }
+#endif
 #pragma unroll
         for (int j = 0; j < T; ++j) {
             f4 acc = f4_zero();
 #pragma unroll
             for (int i = -R; i <= R; ++i) {
+#ifdef RF_EXPERIMENT_NO_EXCHANGE
+                f4 t = v.v[j];
+#else
                 f4 t = (i == 0) ? v.v[j] : lds[L.nbr(j, i)];
+#endif
                 acc = fma4(p.w[i < 0 ? -i : i], t, acc);
             }
             out.v[j] = acc;
@@ -355,6 +365,11 @@ struct StCross3 {
     template <class Px, int T> using Feed = OwnFeed<Px, T>;
     template <int T> RF_DEV static void exchange(const Lane<T>& L, f4* lds, const Tex<T>& v, Tex<T>& w, Tex<T>& e)
     {
+#ifdef RF_EXPERIMENT_NO_EXCHANGE
+        w = v;
+        e = v;
+        return;
+#endif
 #pragma unroll
         for (int j = 0; j < T; ++j) lds[L.pos(j)] = v.v[j];
         wave_sync();

@@ -7,9 +7,13 @@ reference's to import.  The vectors are of two kinds:
   (A) KNOWN ANSWERS derived here INDEPENDENTLY of oracle/ (pure Python / numpy float64
       restatements of the published formulas): the hash, the sRGB tables, the rgba8
       round-trip LUT, gaussian weights.  They pin the oracle.
-  (B) REGRESSION PINS produced by the oracle itself on small seeded frames: they pin
-      nothing about the reference (parity is unpinned for the authored nodes), they
-      only freeze the authored specification so later rounds cannot drift silently.
+  (B) the authored node SPECIFICATION evaluated on small seeded frames by
+      tests/golden/exact_eval.py: exact rational arithmetic, one round-to-nearest-even to
+      binary32 per operation, pure Python, no code shared with oracle/ or the kernels.  The
+      oracle AND the HIP kernels are then both checked against it (tests/test_oracle.py,
+      tests/test_gpu_parity.py::test_golden_vectors).  It pins nothing about the reference
+      (parity is unpinned for the authored nodes); it removes the risk of the oracle
+      grading itself.  This script imports nothing from oracle/.
 
 Run from the repo root:  python tests/golden/make_golden.py
 """
@@ -22,8 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-from oracle import pixel  # noqa: E402
-from tests import util  # noqa: E402
+from tests.golden import exact_eval as ex  # noqa: E402
 
 
 def hash32_py(seed, idx, c):
@@ -66,16 +69,13 @@ def main():
         tot = e[0] + sum(2.0 * v for v in e[1:])
         out[name] = np.array([v / tot for v in e], dtype=np.float64).astype(np.float32)
 
-    # ---- (B) regression pins of the authored specification -------------------------
+    # ---- (B) the specification, evaluated exactly (NOT by the oracle) ---------------
     W, H = 40, 24
-    for tag, fmt in (("f32", util.F32), ("u8", util.U8)):
-        x = pixel.fill_synthetic(W, H, fmt, 0x5EED0002)
-        out["in_" + tag] = x
-        out["chain3_" + tag] = util.run_oracle(util.CHAIN3, x)
-        out["chain5_" + tag] = util.run_oracle(util.CHAIN5, x)
-        out["diamond_" + tag] = util.run_oracle(util.DIAMOND, x)
-        out["gauss9_" + tag] = util.run_oracle("input -> gaussian9 -> output\ngaussian9: gaussian9 { sigma: 2.0 }", x)
-        out["conv7_" + tag] = util.run_oracle("input -> conv2d -> output\nconv2d: conv2d { ksize: 7, sigma: 1.5 }", x)
+    for tag, dt in (("f32", np.float32), ("u8", np.uint8)):
+        x = ex.synthetic(W, H, tag, 0x5EED0002)
+        out["in_" + tag] = np.frombuffer(ex.to_bytes(x, tag), dtype=dt).reshape(H, W, 4).copy()
+        for name, fn in ex.GRAPHS.items():
+            out["%s_%s" % (name, tag)] = np.frombuffer(ex.to_bytes(fn(x, tag), tag), dtype=dt).reshape(H, W, 4).copy()
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.npz"), **out)
     print("wrote golden.npz with", len(out), "arrays")
 

@@ -110,7 +110,9 @@ def test_separable_gaussian_equals_dense_conv_on_interior_within_rounding():
 
 
 @pytest.mark.parametrize("tag,fmt", [("f32", util.F32), ("u8", util.U8)])
-def test_regression_pins(tag, fmt):
+def test_golden_part_b_from_the_exact_evaluator(tag, fmt):
+    """golden.npz part B is produced by tests/golden/exact_eval.py (exact rationals, one rounding per operation, no code
+    shared with oracle/): the oracle is checked against it here, the kernels in test_gpu_parity.py::test_golden_vectors."""
     x = GOLDEN["in_" + tag]
     assert x.tobytes() == pixel.fill_synthetic(40, 24, fmt, 0x5EED0002).tobytes()
     util.assert_same(run(util.CHAIN3, x), GOLDEN["chain3_" + tag], "chain3")
