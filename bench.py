@@ -468,7 +468,9 @@ def main():
     legs = {}
     fps = args.frames_per_step
     poisoned = False                                   # an exchange that failed may have left a collective stuck on its stream
-    for mode in list(modes):
+    queue = list(modes)
+    while queue:
+        mode = queue.pop(0)
         if mode == "exchange":
             # Real RCCL between GPUs first runs on the driver's node: probe ONE frame (the first exchange of a context is
             # waited for with a bound, RF_XCHG_TIMEOUT_S), then let every rank agree before the leg's collectives start --
@@ -476,16 +478,32 @@ def main():
             err = None
             try:
                 ctx, g = make_graph(mode, wl, H)
-                g.execute(0)
-                g.wait(0)
             except rf.RfError as e:
                 err = str(e)
+            # the launch list fixes the rows every send/recv carries: all ranks must hold the same one BEFORE the first exchange
+            sig = 0 if err else (g.plan.signature() & 0x7FFFFFFFFFFFFFFF)
+            lo_hi = torch.tensor([sig, -sig], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(lo_hi, op=dist.ReduceOp.MIN)
+            if not err and (int(lo_hi[0].item()) != sig or int(lo_hi[1].item()) != -sig):
+                err = "the ranks disagree about the launch list (plan signature %x here)" % sig
+            agreed = int(lo_hi[0].item()) == -int(lo_hi[1].item()) and int(lo_hi[0].item()) != 0
+            if agreed and not err:
+                try:
+                    g.execute(0)
+                    g.wait(0)
+                except rf.RfError as e:
+                    err = str(e)
+            elif not err:
+                err = "another rank holds a different launch list"
             ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=red_dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
                 rccl_error = err or "another rank failed its first halo exchange"
                 modes.remove("exchange")
-                poisoned = True
+                poisoned = poisoned or agreed          # an exchange was started somewhere: a collective may be stuck on its stream
+                if not legs and not modes and not queue:
+                    modes.append("overfetch")          # `--halo exchange` alone: still produce a (communication-free) headline
+                    queue.append("overfetch")
                 continue
         else:
             ctx, g = make_graph(mode, wl, H)

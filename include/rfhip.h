@@ -176,6 +176,12 @@ int         rf_plan_launch_radius(const rf_plan* plan, int i);
  * another launch of the layer reads or writes (an in-place point op beside a second consumer).
  * The reference runs such a layer concurrently (command.rs:194-240), a data race. */
 int         rf_plan_launch_serial(const rf_plan* plan, int i);
+/* [host] a 64-bit digest of the launch list (labels, radii, layers, outputs; never 0 for a valid plan).  Row-strip ranks
+ * in exchange mode must run the SAME list -- it fixes how many rows every neighbour send/recv carries -- so a caller
+ * compares rf_plan_signature(rf_graph_plan(g)) across ranks before the first frame (bench.py does, with an all-reduce).
+ * rf_graph_create never lets a rank change its list on its own there: if a fused launch cannot be compiled in exchange
+ * mode it fails with RF_ERR_UNSUPPORTED instead of falling back to catalogue-only fusion. */
+uint64_t    rf_plan_signature(const rf_plan* plan);
 /* Kernels compiled at graph creation.  A fused launch whose stage list the ahead-of-time kernel catalogue lacks is
  * compiled by rf_graph_create with hiprtc from the library's own device source -- the counterpart of
  * Shader::from_path + Pipeline::new_compute (src/vulkan/shader.rs:29-93, pipeline.rs:73-88), which run at the same
@@ -190,6 +196,8 @@ int         rf_plan_launch_needs_jit(const rf_plan* plan, int i);
 /* [host] compiles every such kernel of the plan for gfx950 WITHOUT a device (nothing is loaded): proves on a
  * GPU-less machine that the generated instantiations build; *code_bytes = total code object size */
 rf_status   rf_plan_jit_compile(const rf_plan* plan, int format, size_t* code_bytes);
+/* [host] the same for the variant with `texels_per_lane` (1 or 2) texels per lane; launches that have no two-texel variant are skipped */
+rf_status   rf_plan_jit_compile_texels(const rf_plan* plan, int format, int texels_per_lane, size_t* code_bytes);
 /* [host] ghost-row schedule of a row-strip partition (new: SURVEY.md 8e).
  *   exchange != 0: before launch i its input's need_src[i] = radius edge rows are
  *                  exchanged with the neighbour ranks; need_dst[i] = 0.

@@ -94,10 +94,12 @@ SIGNATURES = {
     "rf_plan_launch_output": (_cp, [_vp, _i]),
     "rf_plan_launch_radius": (_i, [_vp, _i]),
     "rf_plan_launch_serial": (_i, [_vp, _i]),
+    "rf_plan_signature": (C.c_uint64, [_vp]),
     "rf_jit_available": (_i, []),
     "rf_jit_compile_count": (_i, []),
     "rf_plan_launch_needs_jit": (_i, [_vp, _i]),
     "rf_plan_jit_compile": (_i, [_vp, _i, C.POINTER(C.c_size_t)]),
+    "rf_plan_jit_compile_texels": (_i, [_vp, _i, _i, C.POINTER(C.c_size_t)]),
     "rf_plan_halo_schedule": (_i, [_vp, _i, _pi, _pi, _i, _pi, _pi]),
     "rf_registry_num_types": (_i, []),
     "rf_registry_type_name": (_cp, [_i]),

@@ -265,6 +265,21 @@ extern "C" int rf_plan_launch_serial(const rf_plan* p, int i)
     const LaunchDesc* l = launch_at(p, i);
     return l ? (l->serial ? 1 : 0) : -1;
 }
+extern "C" uint64_t rf_plan_signature(const rf_plan* p)
+{
+    if (!p) return 0;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const std::string& t) {
+        for (unsigned char c : t) { h ^= c; h *= 1099511628211ull; }
+        h ^= 0xff; h *= 1099511628211ull;
+    };
+    mix(p->launch_error);
+    for (const auto& l : p->launches) {
+        mix(l.label);
+        mix(std::to_string(l.radius) + "/" + std::to_string(l.layer) + "/" + l.dst);
+    }
+    return h ? h : 1;
+}
 extern "C" rf_status rf_plan_halo_schedule(const rf_plan* p, int exchange, int* need_src, int* need_dst, int n,
                                            int* need_input, int* ghost)
 {
@@ -323,9 +338,12 @@ extern "C" int rf_plan_launch_needs_jit(const rf_plan* p, int i)
     return stream_in_catalogue(sl) ? 0 : 1;
 }
 
-extern "C" rf_status rf_plan_jit_compile(const rf_plan* p, int format, size_t* code_bytes)
+extern "C" rf_status rf_plan_jit_compile(const rf_plan* p, int format, size_t* code_bytes) { return rf_plan_jit_compile_texels(p, format, 1, code_bytes); }
+
+extern "C" rf_status rf_plan_jit_compile_texels(const rf_plan* p, int format, int texels_per_lane, size_t* code_bytes)
 {
     if (!p) return fail(RF_ERR_INVALID, "rf_plan_jit_compile: null plan");
+    if (texels_per_lane != 1 && texels_per_lane != 2) return fail(RF_ERR_INVALID, "rf_plan_jit_compile: texels_per_lane must be 1 or 2");
     if (!p->launch_error.empty()) return fail(RF_ERR_GRAPH, p->launch_error);
     if (format != RF_FORMAT_RGBA8 && format != RF_FORMAT_RGBA32F) return fail(RF_ERR_INVALID, "rf_plan_jit_compile: unknown format");
     size_t total = 0;
@@ -334,7 +352,8 @@ extern "C" rf_status rf_plan_jit_compile(const rf_plan* p, int format, size_t* c
         StageList sl;
         if (ops.size() < 2 || !ops_to_stages(ops.data(), (int)ops.size(), sl) || stream_in_catalogue(sl)) continue;
         std::string err;
-        const size_t n = jit_compile_only(format, 4, 1, sl, 4, err);
+        if (texels_per_lane == 2 && (sl.sum_rh() > 7 || sl.max_rv() > 4 || sl.pair())) continue;      // no two-texel variant of such a list (choose_texels)
+        const size_t n = jit_compile_only(format, 4, texels_per_lane, sl, 4, err);
         if (n == 0) return fail(RF_ERR_UNSUPPORTED, err);
         total += n;
     }

@@ -102,6 +102,15 @@ rf_status fail(rf_status st, const std::string& msg)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Row pitch of a device image.  EXPERIMENT (RF_PITCH_PAD = bytes added to every row): how the pitch maps rows onto the HBM
+// channels decides how well a column-strip walk streams (scripts/walk_probe.py, profiles/r03_pitch_*).
+size_t image_pitch(size_t row_bytes)
+{
+    size_t pitch = align_up(row_bytes, 256);
+    if (const char* e = std::getenv("RF_PITCH_PAD")) pitch += align_up((size_t)std::atol(e), 256);
+    return pitch;
+}
+
 RcclLib* ctx_rccl(const rf_ctx* ctx) { return (RcclLib*)ctx->rccl; }
 
 int strip_rows_of(const rf_graph* g) { return g->strip_y1 - g->strip_y0; }
@@ -150,10 +159,10 @@ rf_status exchange_rows(rf_graph* g, const DeviceImage& img, int r, hipStream_t 
     const int rc_end = lib->GroupEnd();
     if (rc != 0) return fail(RF_ERR_DEVICE, std::string(what) + ": " + lib->GetErrorString(rc));
     if (rc_end != 0) return fail(RF_ERR_DEVICE, std::string("ncclGroupEnd: ") + lib->GetErrorString(rc_end));
-    // The first exchange of a context is where a mis-paired send/recv (ranks that disagree about the
-    // plan) would hang forever.  Wait for it with a deadline instead: poll the stream, give up after
-    // RF_XCHG_TIMEOUT_S seconds (default 60) with RF_ERR_DEVICE, never block without bound.
-    if (!ctx->exchanged_once) {
+    // The first exchange of a GRAPH is where a mis-paired send/recv (ranks that disagree about the
+    // plan: every graph has a plan of its own) would hang forever.  Wait for it with a deadline instead: poll the
+    // stream, give up after RF_XCHG_TIMEOUT_S seconds (default 60) with RF_ERR_DEVICE, never block without bound.
+    if (!g->exchanged_once) {
         double limit_s = 60.0;
         if (const char* e = std::getenv("RF_XCHG_TIMEOUT_S")) limit_s = std::atof(e) > 0 ? std::atof(e) : limit_s;
         const auto t0 = std::chrono::steady_clock::now();
@@ -167,7 +176,7 @@ rf_status exchange_rows(rf_graph* g, const DeviceImage& img, int r, hipStream_t 
                                                " s (ranks disagree about the graph, or a rank is missing)");
             std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
-        ctx->exchanged_once = true;
+        g->exchanged_once = true;
     }
     return RF_OK;
 }
@@ -484,6 +493,13 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
             if (ops.size() < 2) continue;
             std::string jerr;
             if (!stream_prepare(opt.format, ops.data(), (int)ops.size(), opt.width, Hs1 - Hs0, g->tune, jerr)) {
+                // With neighbour exchanges the launch list fixes how many rows every ncclSend/Recv carries and how many
+                // exchanges a frame has: a rank that fell back on its own would mis-pair them with its neighbours'.  The
+                // fallback is a LOCAL decision, so it is not taken there: the graph is refused and the caller decides for
+                // all ranks (RF_GRAPH_NO_JIT on every rank, or RF_GRAPH_NO_HALO_XCHG).
+                if (ctx->world > 1 && !(opt.flags & RF_GRAPH_NO_HALO_XCHG))
+                    return fail(RF_ERR_UNSUPPORTED, "a fused launch of this graph could not be compiled on rank " + std::to_string(ctx->rank) + " (" + jerr +
+                                                        "); in exchange mode the ranks must agree on the launch list: create the graph with RF_GRAPH_NO_JIT on every rank");
                 g->jit_note = "catalogue-only fusion: " + jerr;
                 ok = false;
             }
@@ -570,7 +586,7 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
                                             " is smaller than the halo " + std::to_string(g->ghost));
 
     // per-frame images, streams, events (PipelineGraphFrame::new, Frame::new)
-    const size_t pitch = align_up((size_t)opt.width * bytes_per_pixel(opt.format), 256);
+    const size_t pitch = image_pitch((size_t)opt.width * bytes_per_pixel(opt.format));
     size_t max_layer = 1;
     {
         std::map<int, size_t> per_layer;

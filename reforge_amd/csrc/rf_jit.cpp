@@ -35,6 +35,7 @@ struct Rtc {
     int (*GetLoweredName)(RtcProgram, const char*, const char**) = nullptr;
     int (*DestroyProgram)(RtcProgram*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*Version)(int*, int*) = nullptr;      // optional: part of the disk-cache key
 };
 
 Rtc* rtc()
@@ -64,6 +65,7 @@ Rtc* rtc()
     lib.GetLoweredName = (decltype(lib.GetLoweredName))sym("hiprtcGetLoweredName");
     lib.DestroyProgram = (decltype(lib.DestroyProgram))sym("hiprtcDestroyProgram");
     lib.GetErrorString = (decltype(lib.GetErrorString))sym("hiprtcGetErrorString");
+    lib.Version = (decltype(lib.Version))dlsym(lib.handle, "hiprtcVersion");
     if (!ok) {
         dlclose(lib.handle);
         lib.handle = nullptr;
@@ -75,7 +77,10 @@ Rtc* rtc()
 struct Compiled {
     std::vector<char> code;
     std::string lowered;     // mangled kernel name
+    std::string disk;        // path stem of the disk-cache entry this came from ("" = compiled by this process)
 };
+
+const char kArch[] = "gfx950";
 
 std::mutex g_mu;
 std::map<std::string, Compiled> g_code;                       // name expression -> code object (process cache)
@@ -97,13 +102,23 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull)
     return h;
 }
 
-// optional disk cache (RF_JIT_CACHE_DIR): <dir>/<hash of source + name + options>.{hsaco,name}
+// Optional disk cache (RF_JIT_CACHE_DIR), shared by concurrent processes (the ranks of one job, pytest workers):
+//   <dir>/rfjit_<key>.hsaco   the code object, a plain ELF (llvm-objdump reads it: tests/test_jit_isa.py)
+//   <dir>/rfjit_<key>.name    "<mangled kernel name>\n<code bytes> <fnv1a of the code>\n"
+// key = hash of device source + name expression + waves per block + target + hiprtc version.  Both files are written to
+// a temporary name and renamed; an entry whose .name does not match its .hsaco (torn, stale, truncated) is deleted
+// and treated as a miss, and so is one the driver refuses to load (jit_compile): a bad entry costs a recompile on the
+// process that finds it, never a silent fallback on ONE rank.
 std::string cache_path(const std::string& expr, int waves_per_block)
 {
     const char* dir = std::getenv("RF_JIT_CACHE_DIR");
     if (!dir || !*dir) return "";
+    int major = 0, minor = 0;
+    if (Rtc* r = rtc())
+        if (r->Version) (void)r->Version(&major, &minor);
+    const std::string salt = expr + "|w" + std::to_string(waves_per_block) + "|" + kArch + "|rtc" + std::to_string(major) + "." + std::to_string(minor);
     char buf[64];
-    std::snprintf(buf, sizeof(buf), "%016llx", (unsigned long long)fnv1a(expr + "|w" + std::to_string(waves_per_block), fnv1a(kSource)));
+    std::snprintf(buf, sizeof(buf), "%016llx", (unsigned long long)fnv1a(salt, fnv1a(kSource)));
     return std::string(dir) + "/rfjit_" + buf;
 }
 
@@ -115,6 +130,52 @@ bool read_file(const std::string& p, std::vector<char>& out)
     return !out.empty();
 }
 
+bool write_file_atomically(const std::string& path, const char* data, size_t n)
+{
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    {
+        std::ofstream f(tmp, std::ios::binary);
+        f.write(data, (std::streamsize)n);
+        if (!f) { (void)std::remove(tmp.c_str()); return false; }
+    }
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) { (void)std::remove(tmp.c_str()); return false; }
+    return true;
+}
+
+void cache_drop(const std::string& stem)
+{
+    (void)std::remove((stem + ".name").c_str());
+    (void)std::remove((stem + ".hsaco").c_str());
+}
+
+bool cache_load(const std::string& stem, Compiled& c)
+{
+    std::vector<char> nm;
+    if (!read_file(stem + ".name", nm) || !read_file(stem + ".hsaco", c.code)) return false;
+    const std::string text(nm.begin(), nm.end());
+    const size_t nl = text.find('\n');
+    unsigned long long size = 0, hash = 0;
+    if (nl == std::string::npos || std::sscanf(text.c_str() + nl + 1, "%llu %llx", &size, &hash) != 2 || size != c.code.size() ||
+        hash != (unsigned long long)fnv1a(std::string(c.code.begin(), c.code.end()))) {
+        cache_drop(stem);
+        return false;
+    }
+    c.lowered = text.substr(0, nl);
+    c.disk = stem;
+    return !c.lowered.empty();
+}
+
+void cache_store(const std::string& stem, const Compiled& c)
+{
+    const char* dir = std::getenv("RF_JIT_CACHE_DIR");
+    (void)mkdir(dir, 0755);
+    char tail[64];
+    std::snprintf(tail, sizeof(tail), "\n%llu %llx\n", (unsigned long long)c.code.size(),
+                  (unsigned long long)fnv1a(std::string(c.code.begin(), c.code.end())));
+    const std::string name = c.lowered + tail;
+    if (write_file_atomically(stem + ".hsaco", c.code.data(), c.code.size())) (void)write_file_atomically(stem + ".name", name.data(), name.size());
+}
+
 const Compiled* compile(int fmt, int pf, int texels, const StageList& sl, int waves_per_block, std::string& err)
 {
     const std::string expr = name_expression(fmt, pf, texels, sl);
@@ -123,11 +184,7 @@ const Compiled* compile(int fmt, int pf, int texels, const StageList& sl, int wa
     const std::string cpath = cache_path(expr, waves_per_block);
     if (!cpath.empty()) {
         Compiled c;
-        std::vector<char> nm;
-        if (read_file(cpath + ".hsaco", c.code) && read_file(cpath + ".name", nm)) {
-            c.lowered.assign(nm.begin(), nm.end());
-            return &(g_code[expr] = std::move(c));
-        }
+        if (cache_load(cpath, c)) return &(g_code[expr] = std::move(c));
     }
     Rtc* r = rtc();
     if (!r) { err = "libhiprtc.so could not be loaded"; return nullptr; }
@@ -159,18 +216,7 @@ const Compiled* compile(int fmt, int pf, int texels, const StageList& sl, int wa
     r->DestroyProgram(&prog);
     if (c.lowered.empty() || c.code.empty()) { err = "hiprtc produced no code for " + expr; return nullptr; }
     ++g_compiled;
-    if (!cpath.empty()) {
-        const char* dir = std::getenv("RF_JIT_CACHE_DIR");
-        (void)mkdir(dir, 0755);
-        const std::string tmp = cpath + ".tmp" + std::to_string((long)getpid());
-        {
-            std::ofstream f(tmp, std::ios::binary);
-            f.write(c.code.data(), (std::streamsize)c.code.size());
-        }
-        (void)std::rename(tmp.c_str(), (cpath + ".hsaco").c_str());
-        std::ofstream f(cpath + ".name", std::ios::binary);
-        f << c.lowered;
-    }
+    if (!cpath.empty()) cache_store(cpath, c);
     return &(g_code[expr] = std::move(c));
 }
 
@@ -210,14 +256,32 @@ bool jit_compile(int fmt, int pf, int texels, const StageList& sl, int waves_per
     const std::string expr = name_expression(fmt, pf, texels, sl);
     const std::string lk = loaded_key(expr);
     if (g_loaded.count(lk)) return true;
-    const Compiled* c = compile(fmt, pf, texels, sl, waves_per_block, err);
-    if (!c) return false;
-    hipModule_t mod = nullptr;
-    hipError_t e = hipModuleLoadData(&mod, c->code.data());
-    if (e != hipSuccess) { err = std::string("hipModuleLoadData: ") + hipGetErrorString(e); return false; }
     JitKernel k;
-    e = hipModuleGetFunction(&k.fn, mod, c->lowered.c_str());
-    if (e != hipSuccess) { err = std::string("hipModuleGetFunction(") + c->lowered + "): " + hipGetErrorString(e); return false; }
+    for (int attempt = 0;; ++attempt) {
+        const Compiled* c = compile(fmt, pf, texels, sl, waves_per_block, err);
+        if (!c) return false;
+        hipModule_t mod = nullptr;
+        hipError_t e = hipModuleLoadData(&mod, c->code.data());
+        std::string what;
+        if (e != hipSuccess) what = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
+        if (e == hipSuccess) {
+            e = hipModuleGetFunction(&k.fn, mod, c->lowered.c_str());
+            if (e != hipSuccess) {
+                what = std::string("hipModuleGetFunction(") + c->lowered + "): " + hipGetErrorString(e);
+                (void)hipModuleUnload(mod);
+            }
+        }
+        if (e == hipSuccess) break;
+        // an entry of the disk cache the driver refuses (stale, damaged in a way the checksum of its own bytes cannot
+        // show): delete it and compile here, once -- never fall back on this process alone
+        if (attempt == 0 && !c->disk.empty()) {
+            cache_drop(c->disk);
+            g_code.erase(expr);
+            continue;
+        }
+        err = what;
+        return false;
+    }
     k.texels = texels;
     (void)hipFuncGetAttribute(&k.vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k.fn);
     (void)hipFuncGetAttribute(&k.scratch_bytes, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k.fn);
@@ -235,6 +299,12 @@ const JitKernel* jit_lookup(int fmt, int pf, int texels, const StageList& sl)
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_loaded.find(loaded_key(name_expression(fmt, pf, texels, sl)));
     return it == g_loaded.end() ? nullptr : &it->second;
+}
+
+void jit_forget(int fmt, int pf, int texels, const StageList& sl)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_loaded.erase(loaded_key(name_expression(fmt, pf, texels, sl)));      // the module stays loaded; the kernel is simply never looked up again
 }
 
 hipError_t jit_launch(const JitKernel& k, unsigned grid, unsigned block, void* args, size_t size, hipStream_t stream)

@@ -27,6 +27,8 @@ bool jit_available();
 bool jit_compile(int fmt, int pf, int texels, const StageList& sl, int waves_per_block, std::string& err);
 // the loaded kernel, nullptr if jit_compile has not produced it on the current device
 const JitKernel* jit_lookup(int fmt, int pf, int texels, const StageList& sl);
+// unregister a loaded kernel (an optional variant that turned out to spill): jit_lookup no longer returns it
+void jit_forget(int fmt, int pf, int texels, const StageList& sl);
 hipError_t jit_launch(const JitKernel& k, unsigned grid, unsigned block, void* args, size_t size, hipStream_t stream);
 // number of kernels compiled by this process (not served from a cache): measurement / tests
 int jit_compile_count();

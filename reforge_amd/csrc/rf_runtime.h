@@ -51,7 +51,6 @@ struct rf_ctx {
     float* d_tables = nullptr;             // sRGB eotf[256] ++ thr[255]
     void* comm = nullptr;                  // ncclComm_t
     const rf::RcclApi* rccl = nullptr;
-    bool exchanged_once = false;           // the first halo exchange is waited for with a deadline
 };
 
 namespace rf {
@@ -109,4 +108,5 @@ struct rf_graph {
     size_t staging_bytes = 0;
     std::vector<std::string> time_names;   // scratch for rf_graph_node_times
     std::string jit_note;                  // why the graph fell back to catalogue-only fusion ("" if it did not)
+    bool exchanged_once = false;           // the first halo exchange of THIS graph is waited for with a deadline
 };

@@ -600,7 +600,12 @@ bool stream_prepare(int fmt, const Op* ops, int n, int W, int rows, const Stream
     }
     if (stream_texels_for(fmt, ops, n, W, rows, tune) == 2) {
         std::string e2;
-        (void)jit_compile(fmt, PF_DEFAULT, 2, sl, kWavesPerBlock, e2);      // optional variant: the one-texel kernel serves if it fails
+        // optional variant: the one-texel kernel serves if it fails to compile -- or if it spills (its state is twice the
+        // one-texel kernel's under the same 256-VGPR bound), which the ahead-of-time kernels are checked for by the ISA test
+        if (jit_compile(fmt, PF_DEFAULT, 2, sl, kWavesPerBlock, e2)) {
+            const JitKernel* k2 = jit_lookup(fmt, PF_DEFAULT, 2, sl);
+            if (k2 && k2->scratch_bytes > 0) jit_forget(fmt, PF_DEFAULT, 2, sl);
+        }
     }
     return true;
 }

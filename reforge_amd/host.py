@@ -161,15 +161,19 @@ class Plan:
                  "radius": L.rf_plan_launch_radius(h, i),
                  "serial": bool(L.rf_plan_launch_serial(h, i))} for i in range(L.rf_plan_num_launches(h))]
 
+    def signature(self):
+        """64-bit digest of the launch list: row-strip ranks in exchange mode must agree on it."""
+        return int(lib().rf_plan_signature(self._h))
+
     def needs_jit(self):
         """Per launch: True if its kernel is not in the ahead-of-time catalogue (compiled at graph creation)."""
         L, h = lib(), self._h
         return [bool(L.rf_plan_launch_needs_jit(h, i)) for i in range(L.rf_plan_num_launches(h))]
 
-    def jit_compile(self, fmt=_lib.RF_FORMAT_RGBA32F):
+    def jit_compile(self, fmt=_lib.RF_FORMAT_RGBA32F, texels_per_lane=1):
         """Compile every such kernel for gfx950 without a device; returns the total code size in bytes."""
         n = C.c_size_t()
-        _check(lib().rf_plan_jit_compile(self._h, fmt, C.byref(n)), "rf_plan_jit_compile")
+        _check(lib().rf_plan_jit_compile_texels(self._h, fmt, texels_per_lane, C.byref(n)), "rf_plan_jit_compile")
         return n.value
 
     def halo_schedule(self, exchange=True):
