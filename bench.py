@@ -301,6 +301,54 @@ def launch_roofline(g, wl, launches, rows, n_ev, traffic_key=None):
     return per_launch, roof
 
 
+COLD_SLOTS = 5
+
+
+def cold_leg(rf, ctx, wl, launches, flags, verify=True):
+    """The headline workload with NO help from the 256 MiB Infinity Cache: frames rotate over COLD_SLOTS frame slots, each
+    with its own input and output image, on one queue -- the way the reference runs its frames in flight (--num-frames slots,
+    a new frame per slot, one queue: src/main.rs:164-170, src/vulkan/core.rs:123).  Between two touches of a line lie the
+    other slots' images (4 x 265 MB for the 4K chain), so every read comes from HBM and every write goes there."""
+    W, H, bpp = wl["W"], wl["H"], bpp_of(wl["fmt"])
+    g = rf.Graph(ctx, rf.Config(wl["text"]), W, H, wl["fmt"], num_frames=COLD_SLOTS, flags=flags)
+    try:
+        g.fill_synthetic(wl["seed"])                          # every slot's input, resident in HBM
+        per_slot = len(g.plan.images()) * W * g.rows * bpp
+        g.time_frames_rotating(2 * COLD_SLOTS)
+        t1 = max(g.time_frames_rotating(2 * COLD_SLOTS) / (2 * COLD_SLOTS), 1e-3)
+        n = int(max(4 * COLD_SLOTS, min(20000, 300.0 / t1)))   # ~0.3 s
+        ms = min(g.time_frames_rotating(n) / n for _ in range(3))
+        dom = max(range(len(launches)), key=lambda i: len(launches[i]["inputs"]))
+        alg = sum((len(l["inputs"]) + 1) * W * g.rows * bpp for l in launches)
+        out = {"slots": COLD_SLOTS, "bytes_per_slot": per_slot, "working_set_bytes": per_slot * COLD_SLOTS,
+               "ms_per_frame": round(ms, 5), "frames_timed": n, "mpx_per_s": round(W * H / ms / 1e3, 1),
+               "frame_algorithmic_bytes": alg, "achieved_gbs": round(alg / (ms * 1e-3) / 1e9, 1),
+               "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "note": "frame i on slot i % slots, all slots on one queue; time = hipEvents around the whole run / frames"}
+        del dom
+        if verify:
+            # the LAST slot written is checked against the oracle like the resident leg
+            last = (n - 1) % COLD_SLOTS
+            want_ok = True
+            for sl in (0, last):
+                gg = _SlotView(g, sl)
+                want_ok = want_ok and bool(verify_bands(gg, wl, 0, H, default_bands(g.rows)))
+            out["verified"] = want_ok
+        return out
+    finally:
+        g.close()
+
+
+class _SlotView:
+    """verify_bands reads through g.download_rows(y0, y1): the same for one frame slot of a multi-slot graph"""
+
+    def __init__(self, g, slot):
+        self._g, self._slot = g, slot
+
+    def download_rows(self, y0, y1):
+        return self._g.download_rows(y0, y1, slot=self._slot)
+
+
 def side_workload(rf, ctx, name, verify=True):
     """One BASELINE config beside the headline (N = 1): frames timed with HIP events on the frame's
     stream, the dominant launch priced against its roofline, the result band-checked."""
@@ -339,6 +387,38 @@ def side_workload(rf, ctx, name, verify=True):
         out["best"] = best
         out["roofline"] = dict(out[best]["roofline"], kernel_path=best)
         out["verified"] = all(out[v].get("verified", True) for v, _ in CONV_PATHS)
+    return out
+
+
+def strip8_bound(rf, full_ms, verify=True):
+    """What ONE GPU can say about BASELINE configs[3] on eight: the MIDDLE rank's 16384 x 2048 strip of a
+    world of 8, timed here on its own -- (a) over-fetch (the input carries the chain's 7-row halo, one launch), (b) the
+    exchange schedule's launch geometry (interior rows first, then the boundary rows that wait for the neighbours' ghost
+    rows; RF_EXEC_FORCE_SPLIT, no communicator: the ghost rows are generated).  max_speedup_8 = t(whole frame on one GPU) /
+    t(strip): the ceiling of the 8-GPU strong-scaling figure, reached only if the RCCL exchange hides completely."""
+    wl = WORKLOADS["chain5_16k"]
+    out = {"workload": "rank 3 of 8 of " + wl["desc"], "strip_rows": None, "full_frame_ms": round(full_ms, 5)}
+    ctx8 = rf.Context(0, 3, 8, None)
+    try:
+        for key, ex in (("overfetch", 0), ("split", rf.RF_EXEC_FORCE_SPLIT)):
+            g = rf.Graph(ctx8, rf.Config(wl["text"]), wl["W"], wl["H"], wl["fmt"], flags=rf.RF_GRAPH_NO_HALO_XCHG, exec_flags=ex)
+            try:
+                g.fill_synthetic(wl["seed"])
+                out["strip_rows"] = g.rows
+                g.execute(); g.wait()
+                t1 = max(g.time_frames(3) / 3, 1e-3)
+                n = int(max(10, min(5000, 300.0 / t1)))
+                ms = min(g.time_frames(n) / n for _ in range(3))
+                res = {"ms_per_frame": round(ms, 5), "frames_timed": n, "max_speedup_8": round(full_ms / ms, 3),
+                       "hbm_frac": round(2 * wl["W"] * g.rows * 16 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                if verify:
+                    g.execute(); g.wait()
+                    res["verified"] = bool(verify_bands(g, wl, g.strip[0], wl["H"], default_bands(g.rows)))
+                out[key] = res
+            finally:
+                g.close()
+    finally:
+        ctx8.close()
     return out
 
 
@@ -553,6 +633,15 @@ def main():
     working_set = len(g.plan.images()) * W * rows * bpp
     roofline["mall_resident"] = bool(working_set <= MALL_BYTES)
     roofline["working_set_bytes"] = working_set
+    # the same launch with every byte coming from / going to HBM (the resident figure is cache-assisted)
+    if rank == 0 and world == 1 and not args.no_fusion and not args.hipgraph:
+        try:
+            cold = cold_leg(rf, ctx, wl, launches, flags0, verify=not args.skip_cpu_baseline)
+            roofline["cold"] = cold
+            roofline["frac_cold"] = cold["frac"] if len(launches) == 1 else None
+            roofline["launch_ms_cold"] = cold["ms_per_frame"] if len(launches) == 1 else None
+        except rf.RfError as e:
+            roofline["cold"] = {"error": str(e)}
 
     # the headline result is checked too: bands at the strip seams / frame edges against the oracle
     verified = None
@@ -672,6 +761,12 @@ def main():
                     out["workloads"][name] = side_workload(rf, ctx, name, verify=not args.skip_cpu_baseline)
                 except rf.RfError as e:
                     out["workloads"][name] = {"error": str(e)}
+            full = out["workloads"].get("chain5_16k", {}).get("ms_per_frame")
+            if full:
+                try:
+                    out["workloads"]["chain5_16k_strip8"] = strip8_bound(rf, full, verify=not args.skip_cpu_baseline)
+                except rf.RfError as e:
+                    out["workloads"]["chain5_16k_strip8"] = {"error": str(e)}
         if not args.skip_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
     if poisoned:

@@ -182,6 +182,20 @@ int         rf_plan_launch_serial(const rf_plan* plan, int i);
  * rf_graph_create never lets a rank change its list on its own there: if a fused launch cannot be compiled in exchange
  * mode it fails with RF_ERR_UNSUPPORTED instead of falling back to catalogue-only fusion. */
 uint64_t    rf_plan_signature(const rf_plan* plan);
+/* Filter types that are FILES.  In the reference a type T is {shader_path}/T.comp (src/config/config.rs:59-75), compiled
+ * and reflected when the graph is built (src/vulkan/shader.rs:29-59,:106-160).  Here a type the built-in registry lacks is
+ * looked for as {shader_path}/T.stage.hip: `struct Params { float|int|bool members = the config's parameter names };
+ * static constexpr int RADIUS = 0|1; RF_STAGE f4 apply(const Params&, f4)` (point op) or `apply(const Params&, const f4
+ * (&n)[3][3])` (3x3 neighbourhood, clamp-to-edge), image bindings input_image / output_image as passthrough.comp:4-5.
+ * It becomes a row stage of the stream kernel -- user nodes fuse with the built-in ones -- compiled by hiprtc in
+ * rf_graph_create; a file that does not parse or compile fails rf_plan_create / rf_graph_create with RF_ERR_GRAPH and the
+ * compiler's message (the caller keeps the graph it has: render.rs:121-136).  shaders/edge_detect.stage.hip and
+ * shaders/invert.stage.hip are the first two.  [host] process-wide, like Render's shader path (render.rs:537-588). */
+rf_status   rf_set_shader_path(const char* dir);
+const char* rf_shader_path(void);
+/* [host] modification time (ns) of {shader_path}/{type}.stage.hip as last loaded, -1 if there is no such file: what a
+ * live-reload loop polls (reload_changed_pipelines, render.rs:225-249) */
+long long   rf_user_stage_mtime(const char* type_name);
 /* Kernels compiled at graph creation.  A fused launch whose stage list the ahead-of-time kernel catalogue lacks is
  * compiled by rf_graph_create with hiprtc from the library's own device source -- the counterpart of
  * Shader::from_path + Pipeline::new_compute (src/vulkan/shader.rs:29-93, pipeline.rs:73-88), which run at the same
@@ -317,6 +331,10 @@ rf_status rf_graph_times_string(rf_graph* g, int frame_slot, char* buf, size_t c
 /* runs `iters` frames back to back on slot 0 and returns the total elapsed GPU
  * milliseconds between a hipEvent recorded before the first and after the last */
 rf_status rf_graph_time_frames(rf_graph* g, int iters, float* total_ms);
+/* the same with frame i on frame slot i % num_frames (its own input/output images), all slots submitted to slot 0's
+ * queue -- the reference's frames in flight: images per frame, ONE queue (src/main.rs:164-170, src/vulkan/core.rs:123).
+ * With num_frames x (images of a slot) beyond the 256 MiB Infinity Cache this is the cache-cold rate. */
+rf_status rf_graph_time_frames_rotating(rf_graph* g, int iters, float* total_ms);
 /* same, but one launch only (index into rf_plan_launch_label): average ms */
 rf_status rf_graph_time_launch(rf_graph* g, int launch, int iters, float* avg_ms);
 /* `iters` whole frames on slot 0 with a hipEvent pair around every launch, recorded on

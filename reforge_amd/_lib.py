@@ -95,6 +95,9 @@ SIGNATURES = {
     "rf_plan_launch_radius": (_i, [_vp, _i]),
     "rf_plan_launch_serial": (_i, [_vp, _i]),
     "rf_plan_signature": (C.c_uint64, [_vp]),
+    "rf_set_shader_path": (_i, [_cp]),
+    "rf_shader_path": (_cp, []),
+    "rf_user_stage_mtime": (C.c_longlong, [_cp]),
     "rf_jit_available": (_i, []),
     "rf_jit_compile_count": (_i, []),
     "rf_plan_launch_needs_jit": (_i, [_vp, _i]),
@@ -136,6 +139,7 @@ SIGNATURES = {
     "rf_graph_node_times": (_i, [_vp, _i, C.POINTER(_cp), _pf, _pi]),
     "rf_graph_times_string": (_i, [_vp, _i, _cp, _sz]),
     "rf_graph_time_frames": (_i, [_vp, _i, _pf]),
+    "rf_graph_time_frames_rotating": (_i, [_vp, _i, _pf]),
     "rf_graph_time_each_frame": (_i, [_vp, _i, _pf]),
     "rf_graph_time_launch": (_i, [_vp, _i, _i, _pf]),
     "rf_graph_time_launches": (_i, [_vp, _i, _pf, _i]),

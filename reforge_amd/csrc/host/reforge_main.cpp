@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -59,7 +60,7 @@ void usage()
         "      --height <HEIGHT>\n"
         "      --shader-format <rgba8|rgba32f>  Shader image format [default: rgba32f]\n"
         "      --config <config>              Path to the pipeline configuration file\n"
-        "      --shader-path <shader-path>    Kept for compatibility; filter types are compiled in [default: shaders]\n"
+        "      --shader-path <shader-path>    Where {type}.stage.hip is looked for when a node type is not built in [default: shaders]\n"
         "      --num-frames <NUM_FRAMES>      Frames in flight in the --watch loop (one headless frame forces 1) [default: 2]\n"
         "      --synthetic <SEED>             Generate the input on the GPU instead of reading a file\n"
         "      --frames <N>                   Execute the graph N times and report the mean frame time\n"
@@ -270,6 +271,7 @@ static int run(int argc, char** argv)
     }
 
     // create_config, render.rs:100-119 (nullptr + warning on a user error)
+    (void)rf_set_shader_path(args.shader_path.c_str());       // Config::new(path, shader_path), config.rs:59-75
     auto create_config = [&]() -> rf_config* {
         rf_config* c = nullptr;
         if (!args.config.empty()) {
@@ -316,16 +318,38 @@ static int run(int argc, char** argv)
     // config_changed + recreate_graph (render.rs:121-165): mtime in whole seconds as
     // utils.rs:33-42; a config that does not parse or plan keeps the old graph running
     uint64_t last_mtime = args.config.empty() ? 0 : modified_time(args.config);
-    auto trigger_reloads = [&]() -> bool {
-        if (args.config.empty()) return false;
-        const uint64_t m = modified_time(args.config);
-        if (m == 0) {
-            if (last_mtime != 0) warnln("Unable to access config file: " + args.config);
-            last_mtime = 0;
-            return false;
+    // the stage files of user types the running graph names (reload_changed_pipelines, render.rs:225-249): type -> mtime (ns)
+    std::map<std::string, long long> stage_mtimes;
+    auto stage_file_ns = [&](const std::string& type) -> long long {
+        struct stat st;
+        if (::stat((args.shader_path + "/" + type + ".stage.hip").c_str(), &st) != 0) return -1;
+        return (long long)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+    };
+    auto note_stage_files = [&]() {
+        stage_mtimes.clear();
+        for (int n = 0; n < rf_config_num_nodes(cfg); ++n) {
+            const char* t = rf_config_node_type(cfg, n);
+            if (t && rf_user_stage_mtime(t) >= 0) stage_mtimes[t] = stage_file_ns(t);
         }
-        if (m == last_mtime) return false;
-        last_mtime = m;
+    };
+    note_stage_files();
+    auto trigger_reloads = [&]() -> bool {
+        bool changed = false;
+        if (!args.config.empty()) {
+            const uint64_t m = modified_time(args.config);
+            if (m == 0) {
+                if (last_mtime != 0) warnln("Unable to access config file: " + args.config);
+                last_mtime = 0;
+            } else if (m != last_mtime) {
+                last_mtime = m;
+                changed = true;
+            }
+        }
+        for (auto& kv : stage_mtimes) {
+            const long long now = stage_file_ns(kv.first);
+            if (now != kv.second) { kv.second = now; changed = true; }   // a file that fails to build is not retried until it changes again
+        }
+        if (!changed) return false;
         rf_config* c2 = create_config();
         if (!c2) return false;
         for (int k = 0; k < num_frames; ++k) (void)rf_graph_wait(graph, k);   // device_wait_idle, render.rs:126
@@ -339,6 +363,7 @@ static int run(int argc, char** argv)
         rf_config_destroy(cfg);
         graph = g2;
         cfg = c2;
+        note_stage_files();
         return true;
     };
 

@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "rf_jit.h"
+#include "rf_user.h"
 #include "rf_runtime.h"
 
 namespace rf {
@@ -317,6 +318,26 @@ extern "C" int rf_registry_buffer_binding(const char* type_name, const char* blo
     return b ? b->binding : -1;
 }
 
+// ---- filter types that are files (rf_user.h) -----------------------------------------------------
+extern "C" rf_status rf_set_shader_path(const char* dir)
+{
+    set_shader_path(dir ? dir : "");
+    return RF_OK;
+}
+extern "C" const char* rf_shader_path(void)
+{
+    static thread_local std::string s;
+    s = shader_path();
+    return s.c_str();
+}
+extern "C" long long rf_user_stage_mtime(const char* type_name)
+{
+    if (!type_name) return -1;
+    std::string err;
+    const UserStage* u = user_stage_for_type(type_name, err);
+    return u ? u->mtime_ns : -1;
+}
+
 // ---- kernels compiled at graph creation (rf_jit.cpp) --------------------------------------------
 extern "C" int rf_jit_available(void) { return jit_available() ? 1 : 0; }
 extern "C" int rf_jit_compile_count(void) { return jit_compile_count(); }
@@ -334,7 +355,7 @@ extern "C" int rf_plan_launch_needs_jit(const rf_plan* p, int i)
     if (!l) return -1;
     std::vector<Op> ops = ops_of_members(p->plan, l->members, l->member_slot, nullptr);
     StageList sl;
-    if (ops.size() < 2 || !ops_to_stages(ops.data(), (int)ops.size(), sl)) return 0;
+    if ((ops.size() < 2 && !(ops.size() == 1 && ops[0].kind == OP_USER)) || !ops_to_stages(ops.data(), (int)ops.size(), sl)) return 0;
     return stream_in_catalogue(sl) ? 0 : 1;
 }
 
@@ -350,7 +371,7 @@ extern "C" rf_status rf_plan_jit_compile_texels(const rf_plan* p, int format, in
     for (const auto& l : p->launches) {
         std::vector<Op> ops = ops_of_members(p->plan, l.members, l.member_slot, nullptr);
         StageList sl;
-        if (ops.size() < 2 || !ops_to_stages(ops.data(), (int)ops.size(), sl) || stream_in_catalogue(sl)) continue;
+        if ((ops.size() < 2 && !(ops.size() == 1 && ops[0].kind == OP_USER)) || !ops_to_stages(ops.data(), (int)ops.size(), sl) || stream_in_catalogue(sl)) continue;
         std::string err;
         if (texels_per_lane == 2 && (sl.sum_rh() > 7 || sl.max_rv() > 4 || sl.pair())) continue;      // no two-texel variant of such a list (choose_texels)
         const size_t n = jit_compile_only(format, 4, texels_per_lane, sl, 4, err);

@@ -236,9 +236,19 @@ rf_status run_launch(rf_graph* g, FrameSlot& f, size_t li, hipStream_t stream, b
         rf_status st = launch_rows(g, f, L, geo, geo.y0 + r, geo.y1 - r, stream);   // reads rows [y0, y1): no ghost row
         if (st != RF_OK) return st;
         if (xchg) HIP_TRY(hipStreamWaitEvent(stream, f.halo_ready, 0));
-        st = launch_rows(g, f, L, geo, geo.y0, geo.y0 + r, stream);
-        if (st != RF_OK) return st;
-        st = launch_rows(g, f, L, geo, geo.y1 - r, geo.y1, stream);
+        // the r top and r bottom rows: ONE launch over two row ranges for the stream kernels (two slivers of r rows leave
+        // most of the chip idle, and each launch costs its start-up and its drain), two launches for the kernels of their own
+        const bool own_kernel = L.ops.size() == 1 && (L.ops[0].kind == OP_MIX || L.ops[0].kind == OP_CONV2D);
+        if (own_kernel) {
+            st = launch_rows(g, f, L, geo, geo.y0, geo.y0 + r, stream);
+            if (st != RF_OK) return st;
+            st = launch_rows(g, f, L, geo, geo.y1 - r, geo.y1, stream);
+        } else {
+            Geom two = geo;
+            two.yb0 = geo.y1 - r;
+            two.yb1 = geo.y1;
+            st = launch_rows(g, f, L, two, geo.y0, geo.y0 + r, stream);
+        }
         if (st != RF_OK) return st;
     }
     if (timers) HIP_TRY(hipEventRecord(f.t1[li], stream));
@@ -483,33 +493,42 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
     // shaders (PipelineGraph::new -> Pipeline::new_compute, pipeline_graph.rs:509-545), never on the frame path.  If a
     // chain cannot be compiled (no libhiprtc, or the compiler rejects it) the graph is planned again with
     // catalogue-only fusion: same results, more launches.
-    if (!(plan_flags & (kPlanNoJit | kPlanNoFusion))) {
-        int Hs0, Hs1;
-        strip_rows(opt.height, ctx->world, ctx->rank, Hs0, Hs1);
-        bool ok = g->plan.launch_error.empty();
+    int Hs0, Hs1;
+    strip_rows(opt.height, ctx->world, ctx->rank, Hs0, Hs1);
+    // prepare the kernels of the plan's launches; user_only: just the launches that hold a user stage
+    auto prepare = [&](bool user_only, std::string& jerr) {
         for (const auto& d : g->plan.launches) {
-            if (!ok) break;
             std::vector<Op> ops = ops_of_members(g->plan.plan, d.members, d.member_slot, nullptr);
-            if (ops.size() < 2) continue;
-            std::string jerr;
-            if (!stream_prepare(opt.format, ops.data(), (int)ops.size(), opt.width, Hs1 - Hs0, g->tune, jerr)) {
-                // With neighbour exchanges the launch list fixes how many rows every ncclSend/Recv carries and how many
-                // exchanges a frame has: a rank that fell back on its own would mis-pair them with its neighbours'.  The
-                // fallback is a LOCAL decision, so it is not taken there: the graph is refused and the caller decides for
-                // all ranks (RF_GRAPH_NO_JIT on every rank, or RF_GRAPH_NO_HALO_XCHG).
-                if (ctx->world > 1 && !(opt.flags & RF_GRAPH_NO_HALO_XCHG))
-                    return fail(RF_ERR_UNSUPPORTED, "a fused launch of this graph could not be compiled on rank " + std::to_string(ctx->rank) + " (" + jerr +
-                                                        "); in exchange mode the ranks must agree on the launch list: create the graph with RF_GRAPH_NO_JIT on every rank");
-                g->jit_note = "catalogue-only fusion: " + jerr;
-                ok = false;
-            }
+            bool has_user = false;
+            for (const auto& o : ops) has_user = has_user || o.kind == OP_USER;
+            if (user_only ? !has_user : (ops.size() < 2 && !has_user)) continue;      // single built-in nodes are in the catalogue
+            if (!stream_prepare(opt.format, ops.data(), (int)ops.size(), opt.width, Hs1 - Hs0, g->tune, jerr)) return false;
         }
-        if (!ok && g->plan.launch_error.empty()) {
+        return true;
+    };
+    if (!(plan_flags & (kPlanNoJit | kPlanNoFusion)) && g->plan.launch_error.empty()) {
+        std::string jerr;
+        if (!prepare(false, jerr)) {
+            // With neighbour exchanges the launch list fixes how many rows every ncclSend/Recv carries and how many
+            // exchanges a frame has: a rank that fell back on its own would mis-pair them with its neighbours'.  The
+            // fallback is a LOCAL decision, so it is not taken there: the graph is refused and the caller decides for
+            // all ranks (RF_GRAPH_NO_JIT on every rank, or RF_GRAPH_NO_HALO_XCHG).
+            if (ctx->world > 1 && !(opt.flags & RF_GRAPH_NO_HALO_XCHG))
+                return fail(RF_ERR_UNSUPPORTED, "a fused launch of this graph could not be compiled on rank " + std::to_string(ctx->rank) + " (" + jerr +
+                                                    "); in exchange mode the ranks must agree on the launch list: create the graph with RF_GRAPH_NO_JIT on every rank");
+            g->jit_note = "catalogue-only fusion: " + jerr;
             plan_flags |= kPlanNoJit;
             g->plan = rf_plan();
             if (!build_plan(cfg->cfg, plan_flags, g->plan.plan, err)) return fail(RF_ERR_GRAPH, err);
             g->plan.index();
         }
+    }
+    // A node whose type is a FILE ({shader_path}/{type}.stage.hip, rf_user.h) is compiled here whatever the fusion flags say --
+    // this IS the reference's shader compile (Shader::from_path, shader.rs:29-59): a file that does not compile refuses the
+    // graph with the compiler's message, and the caller keeps the graph it has (render.rs:121-136).
+    if (g->plan.launch_error.empty()) {
+        std::string jerr;
+        if (!prepare(true, jerr)) return fail(RF_ERR_GRAPH, jerr);
     }
     const Plan& plan = g->plan.plan;
 
@@ -1071,6 +1090,43 @@ extern "C" rf_status rf_graph_time_frames(rf_graph* g, int iters, float* total_m
             if (s2 != RF_OK) return s2;
         }
         HIP_TRY(hipEventRecord(e1, f->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(total_ms, e0, e1));
+        return RF_OK;
+    };
+    st = body();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return st;
+}
+
+// Frames that rotate over ALL frame slots -- frame i reads and writes slot i % num_frames's images -- submitted to ONE
+// queue (slot 0's stream), which is how the reference runs its frames in flight: a command buffer and images per frame,
+// one queue (src/main.rs:164-170, src/vulkan/core.rs:123).  With enough slots no cache line is touched twice within the
+// Infinity Cache's 256 MiB: the cache-cold figure of bench.py.
+extern "C" rf_status rf_graph_time_frames_rotating(rf_graph* g, int iters, float* total_ms)
+{
+    FrameSlot* f0;
+    rf_status st = slot_of(g, 0, &f0, "rf_graph_time_frames_rotating");
+    if (st != RF_OK) return st;
+    if (iters < 1 || !total_ms) return fail(RF_ERR_INVALID, "rf_graph_time_frames_rotating: bad argument");
+    if (use_hipgraph(g) || exchange_mode(g)) return fail(RF_ERR_UNSUPPORTED, "rf_graph_time_frames_rotating: not with RF_GRAPH_HIPGRAPH or a halo exchange (their streams belong to a slot)");
+    for (auto& f : g->frames) HIP_TRY(hipStreamSynchronize(f.stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t q = f0->stream;
+    auto body = [&]() -> rf_status {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, q));
+        for (int i = 0; i < iters; ++i) {
+            FrameSlot& f = g->frames[(size_t)i % g->frames.size()];
+            hipStream_t own = f.stream;
+            f.stream = q;                                  // this slot's images, the shared queue
+            rf_status s2 = submit_frame(g, f);
+            f.stream = own;
+            if (s2 != RF_OK) return s2;
+        }
+        HIP_TRY(hipEventRecord(e1, q));
         HIP_TRY(hipEventSynchronize(e1));
         HIP_TRY(hipEventElapsedTime(total_ms, e0, e1));
         return RF_OK;

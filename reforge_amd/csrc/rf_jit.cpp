@@ -1,5 +1,6 @@
 // rf_jit.cpp -- see rf_jit.h.
 #include "rf_jit.h"
+#include "rf_user.h"
 
 #include <dlfcn.h>
 #include <sys/stat.h>
@@ -190,7 +191,20 @@ const Compiled* compile(int fmt, int pf, int texels, const StageList& sl, int wa
     if (!r) { err = "libhiprtc.so could not be loaded"; return nullptr; }
     RtcProgram prog = nullptr;
     const std::string wpb = "-DRF_WAVES_PER_BLOCK=" + std::to_string(waves_per_block);
-    int rc = r->CreateProgram(&prog, kSource, "rf_stream_jit.hip", 0, nullptr, nullptr);
+    // the stages of user types ({shader_path}/{type}.stage.hip) this list names, wrapped into their namespaces (rf_user.cpp)
+    std::string source_with_users;
+    const char* source = kSource;
+    if (sl.has_user()) {
+        source_with_users = kSource;
+        for (int i = 0; i < sl.n; ++i) {
+            if (sl.st[i].kind != ST_USER) continue;
+            const UserStage* u = user_stage_by_id(sl.st[i].user);
+            if (!u) { err = "a user stage of this launch is no longer registered"; return nullptr; }
+            if (source_with_users.find("namespace " + u->ident + " {") == std::string::npos) source_with_users += u->wrapper();
+        }
+        source = source_with_users.c_str();
+    }
+    int rc = r->CreateProgram(&prog, source, "rf_stream_jit.hip", 0, nullptr, nullptr);
     if (rc != 0) { err = std::string("hiprtcCreateProgram: ") + r->GetErrorString(rc); return nullptr; }
     // the flags of the ahead-of-time build (Makefile): explicit fmaf only, no contraction -- bit-identical to the oracle
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", wpb.c_str()};

@@ -34,7 +34,8 @@ enum OpKind : int {
                           // pipeline_graph.rs:462-468's example; own kernel)
     // registry-level kinds (NodeParams::to_op turns them into one of the device ops above)
     OP_WEIGHTS     = 6,   // conv2d_weights: writes a ConvWeights storage buffer, passes its image through
-    OP_PULSE       = 7    // pulse: a colour grade whose slope follows `phase_rf_time`
+    OP_PULSE       = 7,   // pulse: a colour grade whose slope follows `phase_rf_time`
+    OP_USER        = 8    // a type that is a file, {shader_path}/{type}.stage.hip (rf_user.h): point op or 3x3 neighbourhood
 };
 
 struct Op {
@@ -44,6 +45,8 @@ struct Op {
     float slope = 0, offset = 0, saturation = 0;   // grade (slope doubles as the mix factor of OP_MIX)
     float wc = 1, ws = 0;            // sharpen centre / side weight
     const float* dev_weights = nullptr;   // conv2d: device pointer, [K][K]
+    int   user_id = -1;              // OP_USER: the stage (rf_user.h) ...
+    unsigned char user_params[56] = {};   // ... and its Params block, laid out as the device compiler does
     int   slot = 0;                  // inside a fused fork/join launch: 1 = node of the branch feeding input_image0, 2 = of the branch
                                      // feeding input_image1; 0 = before the fork, the join itself, after the join, or a plain chain
 };
@@ -61,6 +64,8 @@ struct Geom {
     int row_lo = 0;     // lowest readable row (clamp-to-edge bound), may be negative (ghost rows)
     int row_hi = 0;     // highest readable row, inclusive
     int y0 = 0, y1 = 0; // output rows [y0, y1)
+    int yb0 = 0, yb1 = 0;   // a SECOND range of output rows in the same launch (stream launches only; empty by default): the two
+                            // boundary slivers of a row strip in exchange mode run as ONE launch (run_launch, rf_graph.cpp)
 };
 
 // Tuning knobs (0 = heuristic).  Read once from the environment by rf_graph.
@@ -73,13 +78,14 @@ struct StreamTuning {
 
 // Row stages of a streaming launch (rf_stream_dev.h): the run-time description that selects -- or, for a list the
 // ahead-of-time catalogue lacks, GENERATES -- the kernel, and lays out its parameter block.
-enum StageKind : int { ST_NODE_END = 0, ST_HTAP = 1, ST_VTAP = 2, ST_GRADE = 3, ST_CROSS3 = 4, ST_DUP = 5, ST_MIX = 6 };
+enum StageKind : int { ST_NODE_END = 0, ST_HTAP = 1, ST_VTAP = 2, ST_GRADE = 3, ST_CROSS3 = 4, ST_DUP = 5, ST_MIX = 6, ST_USER = 7 };
 enum StageSlot : int { SLOT_PLAIN = 0, SLOT_SOLO = 1, SLOT_ON0 = 2, SLOT_ON1 = 3 };   // wrapper of a stage in a fork/join (pair) pipeline
 struct StageList {
     static constexpr int kMax = 3 * kMaxFusedOps + 4;
     int n = 0;
-    struct { int kind, r, slot, op; } st[kMax];   // op: index of the node (in the launch's op list) whose parameters the stage takes, -1 none
+    struct { int kind, r, slot, op, user; } st[kMax];   // op: index of the node (in the launch's op list) whose parameters the stage takes, -1 none; user: ST_USER's stage id
     bool pair() const { return n > 0 && st[0].slot != SLOT_PLAIN; }
+    bool has_user() const { for (int i = 0; i < n; ++i) if (st[i].kind == ST_USER) return true; return false; }
     std::string key() const;          // "H2 V2 E G E C ": catalogue / cache key
     std::string type_list() const;    // "rf::StHTap<2>, rf::StVTap<2>, ...": the template arguments of stream_kernel
     int sum_rh() const, sum_rv() const, max_rv() const, taps() const;

@@ -1,11 +1,13 @@
 // rf_plan.cpp -- see rf_plan.h.  Host only; no GPU involved.
 #include "rf_plan.h"
+#include "rf_user.h"
 
 #include <algorithm>
 #include <functional>
 #include <cerrno>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <set>
 
 namespace rf {
@@ -74,11 +76,15 @@ const std::vector<NodeType>& registry()
     return types;
 }
 
-const NodeType* find_type(const std::string& name)
+const NodeType* find_type(const std::string& name, std::string* why)
 {
     for (const auto& t : registry())
         if (name == t.name) return &t;
-    return nullptr;
+    // not built in: a type that is a file, {shader_path}/{name}.stage.hip (config.rs:59-75; rf_user.h)
+    std::string err;
+    const UserStage* u = user_stage_for_type(name, err);
+    if (why) *why = err;
+    return u ? &u->node_type : nullptr;
 }
 
 // ---------------------------------------------------------------------------------
@@ -211,6 +217,20 @@ Op NodeParams::to_op(const float* dev_weights) const
             break;
         case OP_MIX:
             op.slope = pf(values, "mix");
+            break;
+        case OP_USER:
+            if (const UserStage* u = user_stage_of(type)) {
+                op.user_id = u->id;
+                op.radius = u->radius;
+                for (const auto& p : u->params) {
+                    auto it = values.find(p.name);
+                    ParamValue v;
+                    v.i = 0;
+                    if (it != values.end()) v = it->second;
+                    if (p.type == PARAM_BOOL) op.user_params[p.offset] = v.b ? 1 : 0;
+                    else std::memcpy(op.user_params + p.offset, &v, 4);
+                }
+            }
             break;
         default:
             break;
@@ -616,9 +636,10 @@ bool build_plan(const Config& cfg, uint32_t flags, Plan& plan, std::string& err)
     for (const auto& kv : cfg.graph_pipelines) {
         const std::string& name = kv.first;
         const std::string& tname = cfg.type_of(name);
-        const NodeType* type = find_type(tname);
+        std::string why;
+        const NodeType* type = find_type(tname, &why);
         if (!type) {   // Shader::from_path -> None (utils.rs:23)
-            err = "Error reading node type '" + tname + "' for node '" + name + "': no such filter";
+            err = "Error reading node type '" + tname + "' for node '" + name + "': " + (why.empty() ? std::string("no such filter") : why);
             return false;
         }
         PipelineInfo info;

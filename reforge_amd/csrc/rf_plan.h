@@ -42,7 +42,8 @@ struct NodeType {
 };
 
 const std::vector<NodeType>& registry();
-const NodeType* find_type(const std::string& name);
+// built-in types first, then {shader_path}/{name}.stage.hip (rf_user.h); *why = what is wrong with such a file, if it exists
+const NodeType* find_type(const std::string& name, std::string* why = nullptr);
 
 // one uniform member's value (the UBO bytes of render.rs:167-210)
 union ParamValue {

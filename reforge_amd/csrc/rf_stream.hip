@@ -33,6 +33,7 @@
 
 #include "rf_stream_dev.h"
 #include "rf_jit.h"
+#include "rf_user.h"
 
 namespace rf {
 
@@ -128,8 +129,9 @@ static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo
 // the instantiation, otherwise compiled at graph creation (rf_jit.cpp) -- and lays out the
 // parameter block, which the host assembles as bytes (ParamPack in rf_stream_dev.h).
 // ---------------------------------------------------------------------------------
-static std::string stage_letter(int kind, int r)
+static std::string stage_letter(int kind, int r, int user = -1)
 {
+    if (kind == ST_USER) { const UserStage* u = user_stage_by_id(user); return "U" + (u ? u->ident : std::string("?")); }
     switch (kind) {
         case ST_HTAP: return "H" + std::to_string(r);
         case ST_VTAP: return "V" + std::to_string(r);
@@ -140,8 +142,9 @@ static std::string stage_letter(int kind, int r)
         default: return "E";
     }
 }
-static std::string stage_type(int kind, int r)
+static std::string stage_type(int kind, int r, int user = -1)
 {
+    if (kind == ST_USER) { const UserStage* u = user_stage_by_id(user); return "rf::StUser<rfuser::" + (u ? u->ident : std::string("missing")) + "::Stage>"; }
     switch (kind) {
         case ST_HTAP: return "rf::StHTap<" + std::to_string(r) + ">";
         case ST_VTAP: return "rf::StVTap<" + std::to_string(r) + ">";
@@ -157,7 +160,7 @@ std::string StageList::key() const
 {
     static const char* pre[] = {"", "s", "a", "b"};
     std::string k;
-    for (int i = 0; i < n; ++i) k += pre[st[i].slot] + stage_letter(st[i].kind, st[i].r) + ' ';
+    for (int i = 0; i < n; ++i) k += pre[st[i].slot] + stage_letter(st[i].kind, st[i].r, st[i].user) + ' ';
     return k;
 }
 
@@ -165,7 +168,7 @@ std::string StageList::type_list() const
 {
     std::string t;
     for (int i = 0; i < n; ++i) {
-        const std::string base = stage_type(st[i].kind, st[i].r);
+        const std::string base = stage_type(st[i].kind, st[i].r, st[i].user);
         if (st[i].kind == ST_DUP || st[i].kind == ST_MIX || st[i].slot == SLOT_PLAIN) t += base;
         else if (st[i].slot == SLOT_SOLO) t += "rf::StSolo<" + base + ">";
         else t += std::string("rf::StOn<") + (st[i].slot == SLOT_ON0 ? "0" : "1") + ", " + base + ">";
@@ -174,14 +177,14 @@ std::string StageList::type_list() const
     return t;
 }
 
-static int stage_rv(int kind, int r) { return kind == ST_VTAP ? r : (kind == ST_CROSS3 ? 1 : 0); }
-int StageList::sum_rh() const { int v = 0; for (int i = 0; i < n; ++i) v += (st[i].kind == ST_HTAP) ? st[i].r : (st[i].kind == ST_CROSS3 ? 1 : 0); return v; }
+static int stage_rv(int kind, int r) { return kind == ST_VTAP || kind == ST_USER ? r : (kind == ST_CROSS3 ? 1 : 0); }
+int StageList::sum_rh() const { int v = 0; for (int i = 0; i < n; ++i) v += (st[i].kind == ST_HTAP || st[i].kind == ST_USER) ? st[i].r : (st[i].kind == ST_CROSS3 ? 1 : 0); return v; }
 int StageList::sum_rv() const { int v = 0; for (int i = 0; i < n; ++i) v += stage_rv(st[i].kind, st[i].r); return v; }
 int StageList::max_rv() const { int v = 0; for (int i = 0; i < n; ++i) v = std::max(v, stage_rv(st[i].kind, st[i].r)); return v; }
 int StageList::taps() const
 {
     int v = 0;
-    for (int i = 0; i < n; ++i) v += (st[i].kind == ST_HTAP || st[i].kind == ST_VTAP) ? 2 * st[i].r + 1 : (st[i].kind == ST_CROSS3 ? 5 : (st[i].kind == ST_GRADE ? 3 : 0));
+    for (int i = 0; i < n; ++i) v += (st[i].kind == ST_HTAP || st[i].kind == ST_VTAP) ? 2 * st[i].r + 1 : (st[i].kind == ST_CROSS3 ? 5 : (st[i].kind == ST_GRADE ? 3 : (st[i].kind == ST_USER ? (st[i].r ? 9 : 2) : 0)));
     return v;
 }
 // registers the pipeline's loop-carried state takes (vertical windows / running sums, the sharpen rows, the first
@@ -192,6 +195,7 @@ int StageList::vgpr_estimate(int texels) const
     for (int i = 0; i < n; ++i) {
         if (st[i].kind == ST_VTAP) v += 4 * texels * (2 * st[i].r + 1);
         if (st[i].kind == ST_CROSS3) v += 16 * texels;
+        if (st[i].kind == ST_USER && st[i].r > 0) v += 24 * texels + 12;      // two rows of (west, centre, east) + the neighbourhood handed to apply()
         if (st[i].kind == ST_HTAP) v += (i == 0 && texels == 1 && st[i].r <= 7 && !pair()) ? 4 * (2 * st[i].r + 1) : 0;
         if (st[i].slot == SLOT_ON0 || st[i].slot == SLOT_ON1) v += 4 * texels * stage_rv(st[i].kind, st[i].r);     // the other slot's delay line
     }
@@ -218,6 +222,7 @@ bool ops_to_stages(const Op* ops, int n, StageList& out)
         out.st[out.n].r = r;
         out.st[out.n].slot = slot;
         out.st[out.n].op = op;
+        out.st[out.n].user = (kind == ST_USER && op >= 0) ? ops[op].user_id : -1;
         ++out.n;
         return true;
     };
@@ -239,6 +244,7 @@ bool ops_to_stages(const Op* ops, int n, StageList& out)
                     break;
                 case OP_GRADE: if (!push(ST_GRADE, 0, slot, i)) return false; started = true; break;
                 case OP_SHARPEN: if (!push(ST_CROSS3, 0, slot, i)) return false; started = true; break;
+                case OP_USER: if (ops[i].user_id < 0 || !push(ST_USER, ops[i].radius, slot, i)) return false; started = true; break;
                 default: return false;     // conv2d: a kernel of its own
             }
         }
@@ -290,6 +296,7 @@ static size_t param_bytes(const StageList& sl, const Op* ops, int n_ops, unsigne
         size_t size = 8;
         if (kind == ST_HTAP || kind == ST_VTAP) size = 8 * (size_t)(r + 1);
         else if (kind == ST_GRADE) size = 16;
+        else if (kind == ST_USER) { const UserStage* u = user_stage_by_id(sl.st[i].user); if (!u) return 0; size = (size_t)((u->params_size + 7) / 8 * 8); }
         if (off + size + 8 > cap) return 0;
         unsigned char* p = buf + off;
         const Op* op = (sl.st[i].op >= 0 && sl.st[i].op < n_ops) ? &ops[sl.st[i].op] : nullptr;
@@ -304,6 +311,8 @@ static size_t param_bytes(const StageList& sl, const Op* ops, int n_ops, unsigne
         } else if (kind == ST_CROSS3 && op) {
             const float c[2] = {op->wc, op->ws};
             std::memcpy(p, c, 8);
+        } else if (kind == ST_USER && op) {
+            std::memcpy(p, op->user_params, std::min(size, sizeof(op->user_params)));
         } else if (kind == ST_MIX && op) {
             std::memcpy(p, &op->slope, 4);       // OP_MIX keeps its factor in `slope`
         }
@@ -335,12 +344,18 @@ static bool launch_shape(Image src, Image dst, const Geom& g, const StreamTuning
     A.y0 = g.y0;
     A.y1 = g.y1;
     A.n_strips = (g.W + VALID - 1) / VALID;
-    const int rows = g.y1 - g.y0;
+    const int rows_a = g.y1 - g.y0 > 0 ? g.y1 - g.y0 : 0, rows_b = g.yb1 - g.yb0 > 0 ? g.yb1 - g.yb0 : 0;
+    const int rows = rows_a + rows_b;
     if (rows <= 0 || g.W <= 0) return false;
     const int groups = (A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock;
-    A.rows_per_chunk = choose_rows_per_chunk(rows, groups, resident, halo_rows, bpp, tune, tune.walk == 2);
-    A.n_work = groups * ((rows + A.rows_per_chunk - 1) / A.rows_per_chunk);
+    A.rows_per_chunk = choose_rows_per_chunk(rows_b > 0 ? std::max(rows_a, rows_b) : rows, groups, resident, halo_rows, bpp, tune, tune.walk == 2);
+    A.chunks_a = (rows_a + A.rows_per_chunk - 1) / A.rows_per_chunk;
+    A.yb0 = g.yb0;
+    A.yb1 = g.yb0 + rows_b;
+    const int chunks = A.chunks_a + (rows_b + A.rows_per_chunk - 1) / A.rows_per_chunk;
     A.alternate = tune.walk == 2 ? 0 : 1;
+    A.reserved = 0;
+    A.n_work = groups * chunks;
     out.grid = (unsigned)((A.n_work + 7) / 8 * 8);   // 1-D, a multiple of the 8 XCDs (see the kernel's block order)
     static const bool trace = std::getenv("RF_TRACE_SHAPE") != nullptr;      // diagnostics: the launch geometry, to stderr
     if (trace)
@@ -358,7 +373,8 @@ template <class Px, int PF, int T, class... S> static int resident_workgroups()
     int& slots = slots_of[dev];
     if (slots == 0) {
         int per_cu = 0, cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_kernel<Px, PF, T, S...>, 64 * kWavesPerBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        const size_t dyn = std::getenv("RF_EXPERIMENT_DYN_LDS") ? (size_t)std::atoi(std::getenv("RF_EXPERIMENT_DYN_LDS")) : 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stream_kernel<Px, PF, T, S...>, 64 * kWavesPerBlock, dyn) != hipSuccess || per_cu < 1) per_cu = 2;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         slots = per_cu * (cus > 0 ? cus : 256);
     }
@@ -379,7 +395,10 @@ static hipError_t launch_aot(Image src, Image dst, const Geom& g, const StreamTu
     StreamArgs<S...> A;
     static_cast<StreamHdr&>(A) = sh.hdr;
     std::memcpy(&A.params, pbytes, psize);
-    hipLaunchKernelGGL((stream_kernel<Px, PF, T, S...>), dim3(sh.grid), dim3(64 * kWavesPerBlock), 0, stream, A);
+    // EXPERIMENT (RF_EXPERIMENT_DYN_LDS = bytes of unused dynamic LDS per workgroup): lowers the occupancy of a launch without
+    // touching its code -- how much of a heavy pipeline's time is its two waves per SIMD (scripts/walk_probe.py)
+    static const unsigned dyn_lds = std::getenv("RF_EXPERIMENT_DYN_LDS") ? (unsigned)std::atoi(std::getenv("RF_EXPERIMENT_DYN_LDS")) : 0u;
+    hipLaunchKernelGGL((stream_kernel<Px, PF, T, S...>), dim3(sh.grid), dim3(64 * kWavesPerBlock), dyn_lds, stream, A);
     return hipGetLastError();
 }
 
@@ -494,7 +513,7 @@ bool stream_supported(const Op* ops, int n, bool allow_jit)
     StageList sl;
     if (!ops_to_stages(ops, n, sl)) return false;
     if (stream_in_catalogue(sl)) return true;
-    return n >= 2 && allow_jit && stream_jit_admissible(sl) && jit_available();
+    return (n >= 2 || sl.has_user()) && allow_jit && stream_jit_admissible(sl) && jit_available();      // (a user stage is never in the catalogue: compiled even alone)
 }
 
 int ops_radius(const Op* ops, int n)
@@ -504,6 +523,7 @@ int ops_radius(const Op* ops, int n)
         switch (ops[i].kind) {
             case OP_GAUSSIAN: r += ops[i].radius; break;
             case OP_SHARPEN: r += 1; break;
+            case OP_USER: r += ops[i].radius; break;
             case OP_CONV2D: r += ops[i].radius; break;
             default: break;
         }
@@ -528,7 +548,7 @@ constexpr long kTwoTexelMinPixels = 24L << 20;   // two texels per lane from 8K 
 
 static int choose_texels(int fmt, const StageList& sl, Image src, Image dst, const Geom& g, StreamTuning& t)
 {
-    const long px = (long)g.W * (long)(g.y1 - g.y0);
+    const long px = (long)g.W * (long)((g.y1 - g.y0) + (g.yb1 > g.yb0 ? g.yb1 - g.yb0 : 0));
     const bool heavy = sl.taps() >= kHeavyTaps;
     // rgba8 pipelines are bound by vector issue whatever their length (conversion arithmetic): top-down as well
     // (4K 3-stage chain 40.1 -> 39.2 us, 8K gaussian9 117.7 -> 114.3 us)
@@ -561,7 +581,7 @@ int stream_texels_for(int fmt, const Op* ops, int n, int W, int rows, const Stre
 static hipError_t launch_stages(int fmt, const StageList& sl, const Op* ops, int n, Image src, Image dst, const Geom& g,
                                 const StreamTuning& tune, hipStream_t stream)
 {
-    if (g.y1 - g.y0 <= 0 || g.W <= 0) return hipSuccess;
+    if ((g.y1 - g.y0 <= 0 && g.yb1 - g.yb0 <= 0) || g.W <= 0) return hipSuccess;
     StreamTuning t = tune;
     const int texels = choose_texels(fmt, sl, src, dst, g, t);
     unsigned char pbytes[kMaxParamBytes];

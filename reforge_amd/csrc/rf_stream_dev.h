@@ -456,6 +456,64 @@ struct StNodeEnd {
     }
 };
 
+// A USER stage: a filter type that is a FILE, `{shader_path}/{type}.stage.hip` -- the counterpart of the reference's
+// `{shader_path}/{type}.comp` (src/config/config.rs:59-75), compiled when a graph that names it is created
+// (src/vulkan/shader.rs:29-93) and recompiled when it changes (src/render.rs:225-249).  The file declares
+//     struct Params { float a; int b; bool c; };     // the config's parameter names (uniform members, render.rs:169-185)
+//     static constexpr int RADIUS = 0 | 1;           // point op | 3 x 3 neighbourhood
+//     RF_STAGE f4 apply(const Params& p, f4 c);                       // RADIUS 0
+//     RF_STAGE f4 apply(const Params& p, const f4 (&n)[3][3]);        // RADIUS 1: n[dy + 1][dx + 1], clamp-to-edge
+// rf_user.cpp wraps the text into namespace rfuser::u_<hash> with a `Stage` type (U below) and rf_jit.cpp appends it to this
+// source; a user stage is a row stage like any other, so user nodes FUSE with the built-in ones.
+// The 3 x 3 form keeps a window of the two previous rows with their west / east neighbours (fetched through the wave's LDS
+// row when a row arrives, like StCross3); rows are handed to apply() in FRAME order whatever the walk direction.
+template <class U> struct StUser {
+    static constexpr int RV = U::R, RH = U::R, LDS_ROWS = U::R > 0 ? 1 : 0;
+    struct Params { typename U::P p; };
+    struct Row3 { f4 w, c, e; };
+    template <class Px, int T> struct State { Row3 prev[T], cur[T]; };      // walk order: prev = row y-1, cur = row y
+    template <class Px, int T> using Feed = OwnFeed<Px, T>;
+    template <int T> RF_DEV static void exchange(const Lane<T>& L, f4* lds, const Tex<T>& v, Row3* r)
+    {
+#pragma unroll
+        for (int j = 0; j < T; ++j) lds[L.pos(j)] = v.v[j];
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            r[j].w = lds[L.nbr(j, -1)];
+            r[j].c = v.v[j];
+            r[j].e = lds[L.nbr(j, +1)];
+        }
+    }
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, State<Px, T>& s, const Lane<T>& L, f4* lds, const Tex<T>& v, bool real, bool first, bool emit, Tex<T>& out)
+    {
+        if constexpr (U::R == 0) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) out.v[j] = U::point(p.p, v.v[j]);
+        } else {
+            Row3 nw[T];
+            if (real) exchange<T>(L, lds, v, nw);
+            if (first) {                     // clamp-to-edge before the stage's first row: it is its own predecessor
+#pragma unroll
+                for (int j = 0; j < T; ++j) { s.prev[j] = nw[j]; s.cur[j] = nw[j]; }
+                return;
+            }
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const Row3 next = real ? nw[j] : s.cur[j];          // past the last row: the newest row again
+                if (emit) {
+                    const Row3& north = REV ? next : s.prev[j];
+                    const Row3& south = REV ? s.prev[j] : next;
+                    const f4 n[3][3] = {{north.w, north.c, north.e}, {s.cur[j].w, s.cur[j].c, s.cur[j].e}, {south.w, south.c, south.e}};
+                    out.v[j] = U::box(p.p, n);
+                }
+                s.prev[j] = s.cur[j];
+                if (real) s.cur[j] = nw[j];
+            }
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------
 // Fork / join in ONE launch (the diamond of src/vulkan/pipeline_graph.rs:462-468: two branches read one image
 // and a `combination` node joins them).  Between the fork and the join the value that travels down the stage
@@ -750,11 +808,15 @@ struct alignas(8) StreamHdr {
     int W, row_lo, row_hi, y0, y1, rows_per_chunk, n_strips;
     int n_work;   // workgroups with work = strip groups x chunks (the grid is padded to a multiple of 8)
     int alternate;   // odd chunks walk bottom-up (halo rows shared through L2)
+    // a second range of output rows [yb0, yb1) served by the chunks from index `chunks_a` on (Geom::yb0: the two boundary
+    // slivers of a row strip as one launch); a launch with one range has chunks_a = its chunk count and an empty second range
+    int chunks_a, yb0, yb1;
+    int reserved;
 };
 template <class... S> struct StreamArgs : StreamHdr {
-    ParamPack<S...> params;      // at offset sizeof(StreamHdr) = 72
+    ParamPack<S...> params;      // at offset sizeof(StreamHdr) = 88
 };
-static_assert(sizeof(StreamHdr) == 72, "the host assembles kernel arguments as bytes: header, then the parameter slots");
+static_assert(sizeof(StreamHdr) == 88, "the host assembles kernel arguments as bytes: header, then the parameter slots");
 
 #ifndef RF_WAVES_PER_BLOCK
 #define RF_WAVES_PER_BLOCK 4
@@ -841,6 +903,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, T > 1 ? 2 : 1) void stream_ker
     // b and b+8 share an L2.  Give each XCD a CONTIGUOUS range of work items (strip groups
     // fastest, then chunks): workgroups that share halo columns or halo rows then share an L2.
     // Speed only -- any placement gives the same result.
+    // (Measured and NOT kept, profiles/r03_work_order_probe.txt, r03_stacked_chunks_probe.txt: workgroups in plain dispatch order,
+    // chunks fastest instead of strip groups, and "stacked" workgroups whose four waves walk four vertically adjacent chunks of
+    // one strip in alternating directions so that the seams' halo rows are shared inside the workgroup -- none was faster.)
     const int gx = (A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock;
     const int per_xcd = (int)gridDim.x >> 3;
     const int q = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
@@ -848,8 +913,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, T > 1 ? 2 : 1) void stream_ker
     const int strip = (q % gx) * kWavesPerBlock + wave;
     if (strip >= A.n_strips) return;                 // wave-uniform; no barriers below
     const int chunk = q / gx;
-    const int y0 = A.y0 + chunk * A.rows_per_chunk;
-    const int y1 = min(y0 + A.rows_per_chunk, A.y1);
+    const bool second = chunk >= A.chunks_a;          // wave-uniform
+    const int y0 = second ? A.yb0 + (chunk - A.chunks_a) * A.rows_per_chunk : A.y0 + chunk * A.rows_per_chunk;
+    const int y1 = min(y0 + A.rows_per_chunk, second ? A.yb1 : A.y1);
     if (y0 >= y1) return;
 
     Lane<T> L;

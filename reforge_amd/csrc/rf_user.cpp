@@ -1,0 +1,185 @@
+// rf_user.cpp -- see rf_user.h.  Host only.
+#include "rf_user.h"
+
+#include <sys/stat.h>
+
+#include <cctype>
+#include <cstdio>
+#include <deque>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <sstream>
+
+namespace rf {
+
+namespace {
+
+std::mutex g_mu;
+std::string g_dir;
+std::deque<UserStage> g_stages;                        // stable addresses: NodeType pointers are handed out
+std::map<std::string, int> g_latest;                   // type name -> newest entry
+std::map<const NodeType*, int> g_by_type;
+
+uint64_t fnv1a(const std::string& s)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+
+std::string strip_comments(const std::string& t)
+{
+    std::string o;
+    for (size_t i = 0; i < t.size();) {
+        if (t.compare(i, 2, "//") == 0) { while (i < t.size() && t[i] != '\n') ++i; }
+        else if (t.compare(i, 2, "/*") == 0) { size_t e = t.find("*/", i + 2); i = e == std::string::npos ? t.size() : e + 2; o += ' '; }
+        else o += t[i++];
+    }
+    return o;
+}
+
+bool ident_ok(const std::string& s)
+{
+    if (s.empty() || !(std::isalpha((unsigned char)s[0]) || s[0] == '_')) return false;
+    for (char c : s)
+        if (!(std::isalnum((unsigned char)c) || c == '_')) return false;
+    return true;
+}
+
+long long file_mtime_ns(const std::string& path)
+{
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) return -1;
+    return (long long)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+}
+
+}  // namespace
+
+bool parse_user_stage(const std::string& type, const std::string& text, UserStage& out, std::string& err)
+{
+    out = UserStage();
+    out.type_name = type;
+    out.text = text;
+    char hx[32];
+    std::snprintf(hx, sizeof(hx), "u_%016llx", (unsigned long long)fnv1a(type + "\n" + text));
+    out.ident = hx;
+    const std::string t = strip_comments(text);
+    // static constexpr int RADIUS = N;
+    size_t r = t.find("RADIUS");
+    if (r == std::string::npos) { err = type + ".stage.hip: no `static constexpr int RADIUS = 0 | 1;`"; return false; }
+    size_t eq = t.find('=', r);
+    if (eq == std::string::npos) { err = type + ".stage.hip: RADIUS has no value"; return false; }
+    out.radius = std::atoi(t.c_str() + eq + 1);
+    if (out.radius != 0 && out.radius != 1) { err = type + ".stage.hip: RADIUS must be 0 (point op) or 1 (3x3 neighbourhood)"; return false; }
+    // struct Params { <type> <name>; ... };
+    size_t sp = t.find("struct Params");
+    if (sp == std::string::npos) { err = type + ".stage.hip: no `struct Params { ... };`"; return false; }
+    size_t ob = t.find('{', sp), cb = ob == std::string::npos ? ob : t.find('}', ob);
+    if (ob == std::string::npos || cb == std::string::npos) { err = type + ".stage.hip: struct Params is not closed"; return false; }
+    std::stringstream body(t.substr(ob + 1, cb - ob - 1));
+    std::string decl;
+    int off = 0, align = 1;
+    while (std::getline(body, decl, ';')) {
+        std::stringstream ds(decl);
+        std::string ty, name, extra;
+        if (!(ds >> ty)) continue;                    // whitespace only
+        if (!(ds >> name) || (ds >> extra)) { err = type + ".stage.hip: cannot read the Params member `" + decl + "` (expected `float|int|bool name;`)"; return false; }
+        UserParam p;
+        if (ty == "float") { p.type = PARAM_F32; p.size = 4; }
+        else if (ty == "int") { p.type = PARAM_I32; p.size = 4; }
+        else if (ty == "bool") { p.type = PARAM_BOOL; p.size = 1; }
+        else { err = type + ".stage.hip: Params member `" + name + "` has type `" + ty + "`; uniform members are float, int or bool (render.rs:169-185)"; return false; }
+        if (!ident_ok(name)) { err = type + ".stage.hip: `" + name + "` is not a member name"; return false; }
+        for (const auto& q : out.params)
+            if (q.name == name) { err = type + ".stage.hip: Params member `" + name + "` is declared twice"; return false; }
+        off = (off + p.size - 1) / p.size * p.size;
+        p.offset = off;
+        off += p.size;
+        align = std::max(align, p.size);
+        p.name = name;
+        out.params.push_back(p);
+    }
+    if (out.params.size() > 14 || off > 56) { err = type + ".stage.hip: Params is limited to 56 bytes"; return false; }
+    out.params_size = std::max(1, (off + align - 1) / align * align);
+    if (t.find("apply") == std::string::npos) { err = type + ".stage.hip: no `RF_STAGE f4 apply(const Params&, ...)`"; return false; }
+    return true;
+}
+
+std::string UserStage::wrapper() const
+{
+    std::string w = "\nnamespace rfuser { namespace " + ident + " {\nusing rf::f4;\n#define RF_STAGE static __device__ __forceinline__\n#line 1 \"" +
+                    type_name + ".stage.hip\"\n" + text + "\n#undef RF_STAGE\nstruct Stage {\n    typedef Params P;\n    static constexpr int R = RADIUS;\n"
+                    "    static_assert(R == " + std::to_string(radius) + ", \"RADIUS is not the value the host read\");\n"
+                    "    static_assert(sizeof(Params) == " + std::to_string(params_size) + ", \"struct Params is not laid out as the host computed\");\n";
+    for (const auto& p : params)
+        w += "    static_assert(__builtin_offsetof(Params, " + p.name + ") == " + std::to_string(p.offset) + ", \"struct Params is not laid out as the host computed\");\n";
+    // templates: only the form the file defines is ever instantiated (apply is found by argument-dependent lookup)
+    w += "    template <class Q> static __device__ __forceinline__ f4 point(const Q& p, f4 c) { return apply(p, c); }\n"
+         "    template <class Q> static __device__ __forceinline__ f4 box(const Q& p, const f4 (&n)[3][3]) { return apply(p, n); }\n};\n} }\n";
+    return w;
+}
+
+void set_shader_path(const std::string& dir)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_dir = dir;
+}
+
+const std::string& shader_path()
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    static thread_local std::string copy;
+    copy = g_dir;
+    return copy;
+}
+
+const UserStage* user_stage_for_type(const std::string& type, std::string& err)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    err.clear();
+    if (g_dir.empty() || !ident_ok(type)) return nullptr;
+    const std::string path = g_dir + "/" + type + ".stage.hip";
+    const long long mt = file_mtime_ns(path);
+    if (mt < 0) return nullptr;                       // no such filter (Shader::from_path -> None, utils.rs:23)
+    auto it = g_latest.find(type);
+    if (it != g_latest.end() && g_stages[(size_t)it->second].mtime_ns == mt && g_stages[(size_t)it->second].path == path) return &g_stages[(size_t)it->second];
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return nullptr;
+    std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (it != g_latest.end() && g_stages[(size_t)it->second].text == text && g_stages[(size_t)it->second].path == path) {
+        g_stages[(size_t)it->second].mtime_ns = mt;   // touched, not edited
+        return &g_stages[(size_t)it->second];
+    }
+    UserStage st;
+    if (!parse_user_stage(type, text, st, err)) return nullptr;
+    st.path = path;
+    st.mtime_ns = mt;
+    st.id = (int)g_stages.size();
+    g_stages.push_back(std::move(st));
+    UserStage& s = g_stages.back();
+    static const std::vector<std::pair<const char*, int>> io = {{"input_image", 0}, {"output_image", 1}};   // passthrough.comp:4-5
+    s.node_type.name = s.type_name.c_str();
+    s.node_type.kind = OP_USER;
+    s.node_type.fixed_radius = s.radius;
+    s.node_type.images = io;
+    for (const auto& p : s.params) s.node_type.params.push_back(ParamDef{p.name.c_str(), p.type});
+    g_latest[type] = s.id;
+    g_by_type[&s.node_type] = s.id;
+    return &s;
+}
+
+const UserStage* user_stage_by_id(int id)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    return id >= 0 && id < (int)g_stages.size() ? &g_stages[(size_t)id] : nullptr;
+}
+
+const UserStage* user_stage_of(const NodeType* t)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_by_type.find(t);
+    return it == g_by_type.end() ? nullptr : &g_stages[(size_t)it->second];
+}
+
+}  // namespace rf

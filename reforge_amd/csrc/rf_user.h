@@ -1,0 +1,48 @@
+// rf_user.h -- filter types that are FILES: `{shader_path}/{type}.stage.hip`.
+//
+// In the reference a filter type T is the file {shader_path}/T.comp (src/config/config.rs:59-75), compiled and reflected when
+// the graph is built (src/vulkan/shader.rs:29-59, :106-160) and rebuilt when it changes (src/render.rs:225-249,
+// src/vulkan/pipeline_graph.rs:329-356).  Here the built-in types are a registry of hand-written stages (rf_plan.cpp); a type
+// the registry lacks is looked for as {shader_path}/T.stage.hip: a small HIP fragment (struct Params, RADIUS, apply()) that
+// becomes a row stage of the stream kernel (rf_stream_dev.h, StUser) and is compiled by hiprtc at rf_graph_create together
+// with whatever it is fused with.  "Reflection" = parsing `struct Params { ... }`: the member names are the config's
+// parameter names, f32 / i32 / bool as in render.rs:169-185, `_rf_time` members honoured (render.rs:190,:212-223).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "rf_plan.h"
+
+namespace rf {
+
+struct UserParam {
+    std::string name;
+    ParamType type;
+    int offset, size;
+};
+
+struct UserStage {
+    int id = -1;                  // index in the process-wide table (an edited file gets a NEW entry: old graphs keep theirs)
+    std::string type_name, path, text;
+    std::string ident;            // "u_<hash of the text>": the namespace its wrapper lives in
+    int radius = 0;
+    std::vector<UserParam> params;
+    int params_size = 1;          // sizeof(Params) as the device compiler lays it out (checked there by static_assert)
+    long long mtime_ns = 0;
+    NodeType node_type;           // the registry entry (names point into `params` / `type_name`)
+    std::string wrapper() const;  // device source appended to the run-time compiler's translation unit
+};
+
+// [host] directory searched for {type}.stage.hip ("" = none); process-wide like Render's shader_path (render.rs:537-588)
+void set_shader_path(const std::string& dir);
+const std::string& shader_path();
+// the stage of a type the built-in registry lacks: loads / reloads {shader_path}/{type}.stage.hip.  nullptr: no such file
+// (err empty) or a file that does not parse (err set)
+const UserStage* user_stage_for_type(const std::string& type, std::string& err);
+const UserStage* user_stage_by_id(int id);
+const UserStage* user_stage_of(const NodeType* t);
+// parse one stage file's text (exposed for the tests of the parser)
+bool parse_user_stage(const std::string& type, const std::string& text, UserStage& out, std::string& err);
+
+}  // namespace rf

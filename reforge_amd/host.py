@@ -59,6 +59,15 @@ def registry_binding(type_name, descriptor):
     return lib().rf_registry_binding(type_name.encode(), descriptor.encode())
 
 
+def set_shader_path(path):
+    """Directory searched for {type}.stage.hip when a config names a type the built-in registry lacks (config.rs:59-75)."""
+    _check(lib().rf_set_shader_path(os.fsencode(path) if path else b""), "rf_set_shader_path")
+
+
+def shader_path():
+    return lib().rf_shader_path().decode()
+
+
 def strip_rows(height, world, rank):
     y0, y1 = C.c_int(), C.c_int()
     _check(lib().rf_strip_rows(height, world, rank, C.byref(y0), C.byref(y1)), "rf_strip_rows")
@@ -352,6 +361,12 @@ class Graph:
         _check(lib().rf_graph_time_frames(self._h, iters, C.byref(ms)), "rf_graph_time_frames")
         return ms.value
 
+    def time_frames_rotating(self, iters):
+        """Total GPU ms of `iters` frames, frame i on slot i % num_frames, all on one queue (the cache-cold rate)."""
+        ms = C.c_float()
+        _check(lib().rf_graph_time_frames_rotating(self._h, iters, C.byref(ms)), "rf_graph_time_frames_rotating")
+        return ms.value
+
     def time_each_frame(self, iters):
         """GPU milliseconds of each of `iters` frames (hipEvent pair per frame)."""
         ms = (C.c_float * iters)()
@@ -378,7 +393,7 @@ class RenderInfo:
     height: int
     num_frames: int = 1
     config_path: Optional[str] = None
-    shader_path: str = "shaders"          # unused: node types come from the registry
+    shader_path: str = "shaders"          # where {type}.stage.hip is looked for when a type is not built in (config.rs:59-75)
     format: int = _lib.RF_FORMAT_RGBA32F
     swapchain: bool = False                # no display on an MI355X box
     has_input_image: bool = True
@@ -402,7 +417,10 @@ class Render:
         self.frame_index = 0
         self.staging = np.zeros((info.height, info.width, 4), np.uint8)    # render.rs:552-555
         self._config_mtime = None
+        self._stage_mtimes = {}
         self.graph = None
+        if info.shader_path:
+            set_shader_path(info.shader_path)
         self._create()
         if self.graph is None:
             raise ValueError("Unable to create config")                    # render.rs:543
@@ -438,6 +456,9 @@ class Render:
         if self.graph is not None:
             self.graph.close()
         self.graph = g
+        # the stage files this graph was built from (reload_changed_pipelines, render.rs:225-249)
+        types = {v["type"] for v in cfg.nodes().values()}
+        self._stage_mtimes = {t: lib().rf_user_stage_mtime(t.encode()) for t in types if lib().rf_user_stage_mtime(t.encode()) >= 0}
         self._first_run = [True] * self.info.num_frames
         self._input_loaded = False
         return True
@@ -448,18 +469,26 @@ class Render:
     def wait_for_frame_fence(self):           # render.rs:328-337
         self.graph.wait(self.frame_index)
 
-    def trigger_reloads(self):                # render.rs:497-519 (config only: node types are compiled in)
+    def trigger_reloads(self):                # render.rs:497-519: the config file, and the stage files of user types (:225-249)
+        changed = False
         p = self.info.config_path
-        if not p:
-            return False
-        try:
-            m = os.path.getmtime(p)
-        except OSError:
-            m = 0
-        if m != self._config_mtime:
-            self._config_mtime = m
-            return self._create()
-        return False
+        if p:
+            try:
+                m = os.path.getmtime(p)
+            except OSError:
+                m = 0
+            if m != self._config_mtime:
+                self._config_mtime = m
+                changed = True
+        for t, was in list(self._stage_mtimes.items()):
+            try:
+                now = os.stat(os.path.join(shader_path(), t + ".stage.hip")).st_mtime_ns
+            except OSError:
+                now = -1
+            if now != was:
+                self._stage_mtimes[t] = now              # a file that fails to build is not retried until it changes again
+                changed = True
+        return self._create() if changed else False
 
     def update_ubos(self, time_s):            # render.rs:212-223
         self.graph.set_time(time_s)

@@ -24,7 +24,7 @@ for sp in sys.argv[1:]:
         exs = {"alt": (rf.RF_EXEC_ALTERNATE,), "fwd": (rf.RF_EXEC_NO_ALTERNATE,), "auto": (0,)}.get(os.environ.get("WALK_EX", ""), (rf.RF_EXEC_ALTERNATE, rf.RF_EXEC_NO_ALTERNATE))
         for ex in exs:
             for rpc in rpcs:
-                g = rf.Graph(ctx, rf.Config(TEXTS[name]), W, H, fmt, texels_per_lane=t, rows_per_chunk=rpc, exec_flags=ex)
+                g = rf.Graph(ctx, rf.Config(TEXTS[name]), W, H, fmt, texels_per_lane=t, rows_per_chunk=rpc, exec_flags=ex | int(os.environ.get("WALK_FLAGS", "0"), 0))
                 g.fill_synthetic(1)
                 g.execute(); g.wait()
                 n = max(4, int(20 / max(g.time_frames(2) / 2, 0.02)))
