@@ -170,6 +170,10 @@ int         rf_plan_launch_member_slot(const rf_plan* plan, int i, int k);
 int         rf_plan_launch_num_inputs(const rf_plan* plan, int i);
 const char* rf_plan_launch_input(const rf_plan* plan, int i, int k);
 const char* rf_plan_launch_output(const rf_plan* plan, int i);
+/* a node with several output bindings writes several allocated images (one per binding, pipeline_graph.rs:205-224; the
+ * built-in `split_luma` has luma_image and chroma_image): all of them, in binding order */
+int         rf_plan_launch_num_outputs(const rf_plan* plan, int i);
+const char* rf_plan_launch_output_at(const rf_plan* plan, int i, int k);
 /* rows a launch reads above/below the rows it writes (sum of its stencil radii) */
 int         rf_plan_launch_radius(const rf_plan* plan, int i);
 /* 1 if the launch's layer runs in plan order on one stream: one of its launches writes an image

@@ -221,6 +221,8 @@ NODE_TYPES = {
     "combination":  {"images": {"input_image0": 0, "input_image1": 1, "output_image": 2},
                      "params": {"mix": "f32"}},
 }
+# a node with TWO output images (one image per output binding, pipeline_graph.rs:205-224)
+NODE_TYPES["split_luma"] = {"images": {"input_image": 0, "luma_image": 1, "chroma_image": 2}, "params": {}}
 NODE_TYPES["colour-grade"] = NODE_TYPES["colour_grade"]
 NODE_TYPES["colour_grade_inplace"] = {"images": {"image": 0}, "params": NODE_TYPES["colour_grade"]["params"]}
 NODE_TYPES["grade"] = NODE_TYPES["colour_grade"]
@@ -447,6 +449,10 @@ class GraphOracle:
         if not info.input_images:
             raise ConfigError("node %s has no input image" % info.name)
         t, p = info.type, info.params
+        if t == "split_luma":
+            by_binding = {b: r for r, b in info.output_images}
+            pixel.split_luma(img(info.input_images[0][0]), img(by_binding[1]) if 1 in by_binding else None, img(by_binding[2]) if 2 in by_binding else None)
+            return
         dst = img(info.output_images[0][0])
         if t == "combination":
             by_binding = {b: r for r, b in info.input_images}

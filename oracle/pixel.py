@@ -60,6 +60,7 @@ def lib():
         L.rfo_sharpen.argtypes = [vp, sz, vp, sz, i32, i32, i32, f32]
         L.rfo_conv2d.argtypes = [vp, sz, vp, sz, i32, i32, i32, i32, fp]
         L.rfo_mix.argtypes = [vp, sz, vp, sz, vp, sz, i32, i32, i32, f32]
+        L.rfo_split_luma.argtypes = [vp, sz, vp, sz, vp, sz, i32, i32, i32]
         L.rfo_upload_srgb8.argtypes = [vp, sz, vp, sz, i32, i32, i32]
         L.rfo_download_srgb8.argtypes = [vp, sz, vp, sz, i32, i32, i32]
         _lib = L
@@ -188,6 +189,18 @@ def mix(a, b, t, dst=None):
     pb, pib, _, _, _, _, _ = _pair(b, dst)
     lib().rfo_mix(pa, pia, pb, pib, pd, pid, W, H, fmt, float(t))
     return dst
+
+
+def split_luma(src, luma=None, chroma=None):
+    """one input, two outputs (either may be None = not wired); returns (luma, chroma)"""
+    ps, pis, W, H, fmt = _chk(src)
+    pl = pil = pc = pic = 0
+    if luma is not None:
+        pl, pil, _, _, _ = _chk(luma)
+    if chroma is not None:
+        pc, pic, _, _, _ = _chk(chroma)
+    lib().rfo_split_luma(ps, pis, pl, pil, pc, pic, W, H, fmt)
+    return luma, chroma
 
 
 def upload_srgb8(rgba, fmt):

@@ -315,6 +315,25 @@ void rfo_mix(const void* a, size_t a_pitch, const void* b, size_t b_pitch,
     }
 }
 
+/* split_luma (authored; a node with TWO output images -- the reference allocates one image per output binding,
+ * pipeline_graph.rs:205-224): luma = fma(0.0722, b, fma(0.7152, g, 0.2126 r)); luma_image = (l, l, l, a);
+ * chroma_image = (fma(0.5, c - l, 0.5) for r, g, b; a).  A NULL output is not written. */
+void rfo_split_luma(const void* in, size_t in_pitch, void* luma, size_t luma_pitch, void* chroma, size_t chroma_pitch,
+                    int W, int H, int fmt)
+{
+    #pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int y = 0; y < H; ++y) {
+        for (int x = 0; x < W; ++x) {
+            px4 p = load_px(in, in_pitch, fmt, x, y);
+            const float l = fmaf(0.0722f, p.c[2], fmaf(0.7152f, p.c[1], 0.2126f * p.c[0]));
+            px4 a = {{l, l, l, p.c[3]}};
+            px4 b = {{fmaf(0.5f, p.c[0] - l, 0.5f), fmaf(0.5f, p.c[1] - l, 0.5f), fmaf(0.5f, p.c[2] - l, 0.5f), p.c[3]}};
+            if (luma) store_px(luma, luma_pitch, fmt, x, y, a);
+            if (chroma) store_px(chroma, chroma_pitch, fmt, x, y, b);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------- */
 /* sRGB boundary.  The reference leaves this arithmetic to the Vulkan driver   */
 /* (format-converting vkCmdBlitImage, src/vulkan/command.rs:97-141); the       */

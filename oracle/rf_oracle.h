@@ -86,6 +86,8 @@ void rfo_conv2d(const void* in, size_t in_pitch, void* out, size_t out_pitch,
  * pipeline_graph.rs:462-468); out may alias a or b */
 void rfo_mix(const void* a, size_t a_pitch, const void* b, size_t b_pitch,
              void* out, size_t out_pitch, int W, int H, int fmt, float mix);
+void rfo_split_luma(const void* in, size_t in_pitch, void* luma, size_t luma_pitch, void* chroma, size_t chroma_pitch,
+                    int W, int H, int fmt);
 
 /* ---- sRGB boundary (src/render.rs:264-313, :406-433) ------------------------ */
 void rfo_upload_srgb8(const uint8_t* rgba, size_t stride, void* img, size_t pitch,

@@ -92,6 +92,8 @@ SIGNATURES = {
     "rf_plan_launch_num_inputs": (_i, [_vp, _i]),
     "rf_plan_launch_input": (_cp, [_vp, _i, _i]),
     "rf_plan_launch_output": (_cp, [_vp, _i]),
+    "rf_plan_launch_num_outputs": (_i, [_vp, _i]),
+    "rf_plan_launch_output_at": (_cp, [_vp, _i, _i]),
     "rf_plan_launch_radius": (_i, [_vp, _i]),
     "rf_plan_launch_serial": (_i, [_vp, _i]),
     "rf_plan_signature": (C.c_uint64, [_vp]),

@@ -256,6 +256,16 @@ extern "C" const char* rf_plan_launch_output(const rf_plan* p, int i)
     const LaunchDesc* l = launch_at(p, i);
     return l ? l->dst.c_str() : nullptr;
 }
+extern "C" int rf_plan_launch_num_outputs(const rf_plan* p, int i)
+{
+    const LaunchDesc* l = launch_at(p, i);
+    return l ? (int)l->dsts.size() : -1;
+}
+extern "C" const char* rf_plan_launch_output_at(const rf_plan* p, int i, int k)
+{
+    const LaunchDesc* l = launch_at(p, i);
+    return l && k >= 0 && k < (int)l->dsts.size() ? l->dsts[(size_t)k].c_str() : nullptr;
+}
 extern "C" int rf_plan_launch_radius(const rf_plan* p, int i)
 {
     const LaunchDesc* l = launch_at(p, i);
@@ -277,7 +287,8 @@ extern "C" uint64_t rf_plan_signature(const rf_plan* p)
     mix(p->launch_error);
     for (const auto& l : p->launches) {
         mix(l.label);
-        mix(std::to_string(l.radius) + "/" + std::to_string(l.layer) + "/" + l.dst);
+        mix(std::to_string(l.radius) + "/" + std::to_string(l.layer));
+        for (const auto& d : l.dsts) mix(d);
     }
     return h ? h : 1;
 }

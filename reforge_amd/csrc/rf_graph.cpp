@@ -190,7 +190,12 @@ rf_status launch_rows(rf_graph* g, FrameSlot& f, const Launch& L, Geom geo, int 
     geo.y0 = y0;
     geo.y1 = y1;
     const DeviceImage& dst = f.images.at(L.dst);
-    if (L.ops.size() == 1 && L.ops[0].kind == OP_MIX) {
+    if (L.ops.size() == 1 && L.ops[0].kind == OP_SPLIT) {
+        // a node with several output bindings: one allocated image each (pipeline_graph.rs:205-224)
+        Image luma{}, chroma{};
+        for (size_t k = 0; k < L.dsts.size(); ++k) (L.dst_bindings[k] == 1 ? luma : chroma) = f.images.at(L.dsts[k]).view();
+        HIP_TRY(launch_split_luma(g->opt.format, f.images.at(L.src[0]).view(), luma, chroma, geo, stream));
+    } else if (L.ops.size() == 1 && L.ops[0].kind == OP_MIX) {
         HIP_TRY(launch_mix(g->opt.format, f.images.at(L.src[0]).view(), f.images.at(L.src[1]).view(), dst.view(), geo,
                            L.ops[0].slope, stream));
     } else {
@@ -238,7 +243,7 @@ rf_status run_launch(rf_graph* g, FrameSlot& f, size_t li, hipStream_t stream, b
         if (xchg) HIP_TRY(hipStreamWaitEvent(stream, f.halo_ready, 0));
         // the r top and r bottom rows: ONE launch over two row ranges for the stream kernels (two slivers of r rows leave
         // most of the chip idle, and each launch costs its start-up and its drain), two launches for the kernels of their own
-        const bool own_kernel = L.ops.size() == 1 && (L.ops[0].kind == OP_MIX || L.ops[0].kind == OP_CONV2D);
+        const bool own_kernel = L.ops.size() == 1 && (L.ops[0].kind == OP_MIX || L.ops[0].kind == OP_CONV2D || L.ops[0].kind == OP_SPLIT);
         if (own_kernel) {
             st = launch_rows(g, f, L, geo, geo.y0, geo.y0 + r, stream);
             if (st != RF_OK) return st;
@@ -1176,6 +1181,11 @@ extern "C" rf_status rf_graph_time_launch(rf_graph* g, int launch, int iters, fl
         const Launch& L = g->launches[(size_t)launch];
         const Geom geo = launch_geom(g, L);
         auto once = [&]() -> hipError_t {
+            if (L.ops.size() == 1 && L.ops[0].kind == OP_SPLIT) {
+                Image luma{}, chroma{};
+                for (size_t k = 0; k < L.dsts.size(); ++k) (L.dst_bindings[k] == 1 ? luma : chroma) = f->images.at(L.dsts[k]).view();
+                return launch_split_luma(g->opt.format, f->images.at(L.src[0]).view(), luma, chroma, geo, f->stream);
+            }
             if (L.ops.size() == 1 && L.ops[0].kind == OP_MIX)
                 return launch_mix(g->opt.format, f->images.at(L.src[0]).view(), f->images.at(L.src[1]).view(), f->images.at(L.dst).view(), geo,
                                   L.ops[0].slope, f->stream);

@@ -35,6 +35,7 @@ enum OpKind : int {
     // registry-level kinds (NodeParams::to_op turns them into one of the device ops above)
     OP_WEIGHTS     = 6,   // conv2d_weights: writes a ConvWeights storage buffer, passes its image through
     OP_PULSE       = 7,   // pulse: a colour grade whose slope follows `phase_rf_time`
+    OP_SPLIT       = 9,   // split_luma: one input image, TWO output images (luma_image, chroma_image); own kernel, never fused
     OP_USER        = 8    // a type that is a file, {shader_path}/{type}.stage.hip (rf_user.h): point op or 3x3 neighbourhood
 };
 
@@ -111,6 +112,9 @@ hipError_t launch_ops(int fmt, const Op* ops, int n, Image src, Image dst, const
 
 // dst = a + mix*(b-a) per channel (fmaf(mix, b-a, a)); a == dst or b == dst allowed
 hipError_t launch_mix(int fmt, Image a, Image b, Image dst, const Geom& g, float mix, hipStream_t stream);
+
+// split_luma: src -> luma and / or chroma (an Image with a null base is not written); any of them may alias src (point op)
+hipError_t launch_split_luma(int fmt, Image src, Image luma, Image chroma, const Geom& g, hipStream_t stream);
 
 // synthetic / structured fills of rows [y_begin, y_end) (local), whose global row is y + y_global0
 hipError_t launch_fill_synthetic(int fmt, Image dst, int W, int y_begin, int y_end, int y_global0,

@@ -127,6 +127,26 @@ __global__ __launch_bounds__(256) void mix_kernel(const char* a, size_t a_pitch,
     }
 }
 
+// split_luma: ONE input image, TWO output images (a node with several output bindings: the reference allocates one image per
+// output binding of every node, pipeline_graph.rs:205-224).  luma = fma(0.0722, b, fma(0.7152, g, 0.2126 r)) -- Rec.709, as
+// colour_grade; luma_image = (luma, luma, luma, a); chroma_image = (fma(0.5, c - luma, 0.5) for c in r, g, b; a).  Either
+// output may be absent (not wired by the graph).
+template <class Px>
+__global__ __launch_bounds__(256) void split_luma_kernel(const char* src, size_t src_pitch, char* luma, size_t luma_pitch, char* chroma,
+                                                         size_t chroma_pitch, int W, int y0, int y1)
+{
+    const int x = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (x >= W) return;
+    const unsigned xoff = (unsigned)x * (unsigned)Px::BPP;
+    for (int y = y0 + (int)blockIdx.y; y < y1; y += (int)gridDim.y) {
+        const f4 v = Px::decode(Px::load(src + (ptrdiff_t)y * (ptrdiff_t)src_pitch, xoff));
+        const float l = fmaf(0.0722f, v.z, fmaf(0.7152f, v.y, 0.2126f * v.x));
+        if (luma) Px::store(luma + (ptrdiff_t)y * (ptrdiff_t)luma_pitch, xoff, make_float4(l, l, l, v.w));
+        if (chroma)
+            Px::store(chroma + (ptrdiff_t)y * (ptrdiff_t)chroma_pitch, xoff, make_float4(fmaf(0.5f, v.x - l, 0.5f), fmaf(0.5f, v.y - l, 0.5f), fmaf(0.5f, v.z - l, 0.5f), v.w));
+    }
+}
+
 __global__ __launch_bounds__(256) void copy_kernel(const f4* __restrict__ src, f4* __restrict__ dst, size_t n)
 {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -203,6 +223,19 @@ hipError_t launch_mix(int fmt, Image a, Image b, Image dst, const Geom& g, float
         hipLaunchKernelGGL((mix_kernel<PxU8>), grid, dim3(256), 0, stream, pa, a.pitch, pb, b.pitch, pd, dst.pitch, g.W, g.y0, g.y1, mix);
     else
         hipLaunchKernelGGL((mix_kernel<PxF32>), grid, dim3(256), 0, stream, pa, a.pitch, pb, b.pitch, pd, dst.pitch, g.W, g.y0, g.y1, mix);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_luma(int fmt, Image src, Image luma, Image chroma, const Geom& g, hipStream_t stream)
+{
+    if (g.y1 <= g.y0 || g.W <= 0 || (!luma.base && !chroma.base)) return hipSuccess;
+    dim3 grid = fill_grid(g.W, g.y1 - g.y0);
+    const char* ps = static_cast<const char*>(src.base);
+    char *pl = static_cast<char*>(luma.base), *pc = static_cast<char*>(chroma.base);
+    if (fmt == kFmtRGBA8)
+        hipLaunchKernelGGL((split_luma_kernel<PxU8>), grid, dim3(256), 0, stream, ps, src.pitch, pl, luma.pitch, pc, chroma.pitch, g.W, g.y0, g.y1);
+    else
+        hipLaunchKernelGGL((split_luma_kernel<PxF32>), grid, dim3(256), 0, stream, ps, src.pitch, pl, luma.pitch, pc, chroma.pitch, g.W, g.y0, g.y1);
     return hipGetLastError();
 }
 

@@ -70,6 +70,8 @@ const std::vector<NodeType>& registry()
         {"conv2d", OP_CONV2D, -1, io, {{"ksize", PARAM_I32}, {"sigma", PARAM_F32}}, {{"ConvWeights", 3, 961 * sizeof(float)}}},
         {"conv2d_weights", OP_WEIGHTS, 0, io, {{"ksize", PARAM_I32}, {"sigma", PARAM_F32}}, {{"ConvWeights", 3, 961 * sizeof(float)}}},
         {"combination", OP_MIX, 0, io2, {{"mix", PARAM_F32}}, {}},
+        // a node with TWO output images: the reference allocates one image per output binding (pipeline_graph.rs:205-224)
+        {"split_luma", OP_SPLIT, 0, {{"input_image", 0}, {"luma_image", 1}, {"chroma_image", 2}}, {}, {}},
         // a member ending in `_rf_time` receives the seconds since start every frame (render.rs:190,:212-223)
         {"pulse", OP_PULSE, 0, io, {{"amount", PARAM_F32}, {"phase_rf_time", PARAM_F32}}, {}},
     };
@@ -471,7 +473,7 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
                 const std::string& n = producers[res][0];
                 const PipelineInfo& pi = infos.at(n);
                 const int kind = plan.nodes.at(n).type->kind;
-                if (!is_simple(pi) || in_place(pi) || kind == OP_MIX || kind == OP_CONV2D) return;
+                if (!is_simple(pi) || in_place(pi) || kind == OP_MIX || kind == OP_CONV2D || kind == OP_SPLIT) return;
                 nodes.insert(nodes.begin(), n);
                 res = pi.input_images[0].first;
                 sources.push_back(res);
@@ -516,7 +518,7 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
                 const std::string& n = producers[res][0];
                 const PipelineInfo& pi = infos.at(n);
                 const int kind = plan.nodes.at(n).type->kind;
-                if (!all_inside || !is_simple(pi) || in_place(pi) || kind == OP_MIX || kind == OP_CONV2D || in_diamond.count(n)) break;
+                if (!all_inside || !is_simple(pi) || in_place(pi) || kind == OP_MIX || kind == OP_CONV2D || kind == OP_SPLIT || in_diamond.count(n)) break;
                 pre.insert(pre.begin(), n);
                 inside.insert(n);
                 res = pi.input_images[0].first;
@@ -527,7 +529,7 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
                 const std::string& n = consumers[res][0];
                 const PipelineInfo& pi = infos.at(n);
                 const int kind = plan.nodes.at(n).type->kind;
-                if (!is_simple(pi) || in_place(pi) || kind == OP_MIX || kind == OP_CONV2D || in_diamond.count(n) || inside.count(n)) break;
+                if (!is_simple(pi) || in_place(pi) || kind == OP_MIX || kind == OP_CONV2D || kind == OP_SPLIT || in_diamond.count(n) || inside.count(n)) break;
                 post.push_back(n);
                 inside.insert(n);
                 res = pi.output_images[0].first;
@@ -747,7 +749,7 @@ std::vector<Op> ops_of_members(const Plan& plan, const std::vector<std::string>&
     return ops;
 }
 
-static bool point_kind(int kind) { return kind == OP_PASSTHROUGH || kind == OP_GRADE; }    // (device kinds: conv2d_weights is a passthrough, pulse a grade)
+static bool point_kind(int kind) { return kind == OP_PASSTHROUGH || kind == OP_GRADE || kind == OP_SPLIT; }    // (device kinds: conv2d_weights is a passthrough, pulse a grade)
 
 bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string& err)
 {
@@ -795,11 +797,25 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
                 }
                 L.src = {plan.resolve(info.input_images[0].first)};
             }
-            if (info.output_images.size() != 1) {
-                err = "node '" + unit + "' writes one output image, the graph wires " + std::to_string(info.output_images.size());
-                return false;
+            if (kind0 == OP_SPLIT) {
+                // several output bindings: an allocated image each (pipeline_graph.rs:205-224), in binding order
+                std::vector<std::pair<int, std::string>> outs;
+                for (const auto& o : info.output_images) outs.push_back({o.second, plan.resolve(o.first)});
+                std::sort(outs.begin(), outs.end());
+                for (size_t k = 0; k + 1 < outs.size(); ++k) {
+                    if (outs[k].first == outs[k + 1].first) { err = "node '" + unit + "' wires one output binding to two images"; return false; }
+                    if (outs[k].second == outs[k + 1].second) { err = "node '" + unit + "' would write two outputs into one image"; return false; }
+                }
+                for (const auto& o : outs) { L.dsts.push_back(o.second); L.dst_bindings.push_back(o.first); }
+            } else {
+                if (info.output_images.size() != 1) {
+                    err = "node '" + unit + "' writes one output image, the graph wires " + std::to_string(info.output_images.size());
+                    return false;
+                }
+                L.dsts = {plan.resolve(info.output_images[0].first)};
+                L.dst_bindings = {info.output_images[0].second};
             }
-            L.dst = plan.resolve(info.output_images[0].first);
+            L.dst = L.dsts[0];
             for (const auto& b : info.input_ssbos) {
                 const std::string& nm = plan.resolve_buffer(b.first);
                 if (std::find(plan.buffers.begin(), plan.buffers.end(), nm) == plan.buffers.end()) {
@@ -834,8 +850,11 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
     for (size_t a = 0; a < out.size(); ++a) {
         for (size_t b = 0; b < out.size(); ++b) {
             if (a == b || out[a].layer != out[b].layer) continue;
-            bool touches = out[a].dst == out[b].dst;
-            for (const auto& sname : out[b].src) touches = touches || sname == out[a].dst;
+            bool touches = false;
+            for (const auto& da : out[a].dsts) {
+                for (const auto& db : out[b].dsts) touches = touches || da == db;
+                for (const auto& sname : out[b].src) touches = touches || sname == da;
+            }
             if (touches) out[a].serial = out[b].serial = true;
         }
     }
@@ -863,8 +882,10 @@ void halo_schedule(std::vector<LaunchDesc>& launches, bool multi_rank, bool exch
     for (size_t k = launches.size(); k-- > 0;) {
         LaunchDesc& L = launches[k];
         int nd = 0;
-        auto it = need.find(L.dst);
-        if (it != need.end()) { nd = it->second; need.erase(it); }
+        for (const auto& d : L.dsts) {
+            auto it = need.find(d);
+            if (it != need.end()) { nd = std::max(nd, it->second); need.erase(it); }
+        }
         L.need_dst = nd;
         L.need_src = nd + L.radius;
         for (const auto& s : L.src) need[s] = std::max(need.count(s) ? need[s] : 0, L.need_src);

@@ -99,7 +99,9 @@ struct LaunchDesc {
     std::vector<int> member_slot;   // as PipelineInfo::member_slot
     int layer = 0;
     std::vector<std::string> src;   // allocated image names (1; 2 for OP_MIX in binding order)
-    std::string dst;                // allocated image name
+    std::string dst;                // allocated image name (the first of `dsts`)
+    std::vector<std::string> dsts;  // every allocated image the launch writes: 1, or up to 2 for a multi-output node (split_luma)
+    std::vector<int> dst_bindings;  // the output binding each entry of `dsts` is wired to
     std::vector<std::string> in_buffers, out_buffers;   // allocated storage-buffer names the launch reads / writes
     int radius = 0;                 // vertical halo read beyond the rows written
     int need_src = 0;               // ghost rows of src the launch reads (multi-rank)

@@ -167,6 +167,7 @@ class Plan:
                  "member_slots": [L.rf_plan_launch_member_slot(h, i, k) for k in range(L.rf_plan_launch_num_members(h, i))],
                  "inputs": [_s(L.rf_plan_launch_input(h, i, k)) for k in range(L.rf_plan_launch_num_inputs(h, i))],
                  "output": _s(L.rf_plan_launch_output(h, i)),
+                 "outputs": [_s(L.rf_plan_launch_output_at(h, i, k)) for k in range(L.rf_plan_launch_num_outputs(h, i))],
                  "radius": L.rf_plan_launch_radius(h, i),
                  "serial": bool(L.rf_plan_launch_serial(h, i))} for i in range(L.rf_plan_num_launches(h))]
 

@@ -259,6 +259,13 @@ def main():
     assert o == g == [("mix", "D", "A")], (o, g)
     assert re.search(r"d = b - a", strip_comments(sh("combination.comp")))
 
+    # split_luma: two output images; luma = fma(0.0722, b, fma(0.7152, g, 0.2126 r)), chroma = fma(0.5, c - luma, 0.5)
+    oc, gs = strip_comments(oracle_c), strip_comments(sh("split_luma.comp"))
+    assert re.search(r"l = fmaf\(0\.0722f, p\.c\[2\], fmaf\(0\.7152f, p\.c\[1\], 0\.2126f \* p\.c\[0\]\)\)", oc)
+    assert re.search(r"l = 0\.2126 \* c\.r;\s*l = fma\(0\.7152, c\.g, l\);\s*l = fma\(0\.0722, c\.b, l\);", gs)
+    assert len(re.findall(r"fmaf\(0\.5f, p\.c\[\d\] - l, 0\.5f\)", oc)) == 3 and len(re.findall(r"fma\(0\.5, d[rgb], 0\.5\)", gs)) == 3
+    assert re.search(r"binding = 1, rgba32f\) uniform writeonly image2D luma_image;", gs) and re.search(r"binding = 2, rgba32f\) uniform writeonly image2D chroma_image;", gs)
+
     # every shader: the contract of shaders/passthrough.comp, and `precise` on every fma destination
     for f in sorted(os.listdir(SHADERS)):
         if not f.endswith(".comp"):
@@ -269,6 +276,8 @@ def main():
             assert "input_image0" in text and "input_image1" in text and "output_image" in text
         elif f == "colour_grade_inplace.comp":
             assert re.search(r"uniform image2D image;", text)
+        elif f == "split_luma.comp":
+            assert re.search(r"binding = 0, rgba32f\) uniform readonly image2D input_image;", text), f
         else:
             assert re.search(r"binding = 0, rgba32f\) uniform readonly image2D input_image;", text), f
             assert re.search(r"binding = 1, rgba32f\) uniform writeonly image2D output_image;", text), f

@@ -118,6 +118,10 @@ PLAN_CASES = [
     "input -> gaussian5 -> colour_grade:image -> sharpen -> output",
     "input -> aa:image -> bb:image -> output\naa: grade {}\nbb: grade {}",
     "input -> aa -> output\ninput -> bb -> output\naa: sharpen {}\nbb: gaussian5 {}",
+    util.SPLIT2,
+    # only ONE of the two outputs wired; and a split whose outputs feed a chain each before the join
+    "input -> sp\nsp:chroma_image -> sharpen -> output\nsp: split_luma {}",
+    "input -> sp\nsp:luma_image -> aa -> bb -> mx:input_image0\nsp:chroma_image -> mx:input_image1\nmx -> output\nsp: split_luma {}\naa: sharpen {}\nbb: gaussian5 {}\nmx: combination {}",
 ]
 
 
@@ -131,6 +135,27 @@ def test_plan_matches_restatement(text):
     assert p.launches() == [n for l in layers for n in l]
     for r in list(reuse) + ["rf:final-output", "rf:file-input"]:
         assert p.resolve(r) == og._remap(r, reuse)
+
+
+def test_a_node_with_two_output_images_kat():
+    """pipeline_graph.rs:205-224: one image per output binding of every node.  split_luma writes luma_image and chroma_image."""
+    n = same_config(util.SPLIT2)
+    assert n["sp"]["inputs"] == [("rf:file-input", "input_image")]
+    assert n["sp"]["outputs"] == [("sp:luma_image", "luma_image"), ("sp:chroma_image", "chroma_image")]
+    p = rf.Plan(rf.Config(util.SPLIT2), NF)
+    assert p.layers() == [["sp"], ["cg", "lg"], ["mx"]]
+    info = {l["label"]: l for l in p.launch_info()}
+    assert len(info["sp"]["outputs"]) == 2 and len(set(info["sp"]["outputs"])) == 2 and info["sp"]["output"] == info["sp"]["outputs"][0]
+    assert info["sp"]["outputs"] == [p.resolve("sp:luma_image"), p.resolve("sp:chroma_image")]       # binding order
+    assert info["lg"]["inputs"] == [p.resolve("sp:luma_image")] and info["cg"]["inputs"] == [p.resolve("sp:chroma_image")]
+    # with fusion: the split keeps a launch of its own, its consumers are planned as before
+    q = rf.Plan(rf.Config(util.SPLIT2))
+    assert q.launches()[0] == "sp" and len(q.launch_info()[0]["outputs"]) == 2
+    # the strip schedule covers BOTH outputs: the gaussian behind luma_image needs 2 ghost rows of it
+    ns, nd, need_input, ghost = p.halo_schedule(exchange=False)
+    assert nd[0] == 2 and need_input == 2 and ghost == 2
+    with pytest.raises(rf.RfError):
+        rf.Plan(rf.Config("input -> sp:nonsense -> output\nsp: split_luma {}"))
 
 
 def test_diamond_layers_kat():

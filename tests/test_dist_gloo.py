@@ -99,6 +99,14 @@ def _worker(rank, world, port, text, W, H, fmt, exchange, fused, out_dir):
             row_lo, row_hi = max(-need_src[i], -y0), min(Hs - 1 + need_src[i], H - 1 - y0)
             o0, o1 = max(-need_dst[i], -y0), min(Hs + need_dst[i], H - y0)
             srcs = [images[s][ghost + row_lo:ghost + row_hi + 1] for s in L["inputs"]]
+            if cfg.type_of(L["members"][0]) == "split_luma" and len(L["members"]) == 1:
+                # a node with two output images: both get the rows (incl. the ghost rows) their readers want
+                src = np.ascontiguousarray(srcs[0])
+                luma, chroma = pixel.split_luma(src, np.empty_like(src), np.empty_like(src))
+                by_name = {plan.resolve(L["members"][0] + ":luma_image"): luma, plan.resolve(L["members"][0] + ":chroma_image"): chroma}
+                for name in L["outputs"]:
+                    images[name][ghost + o0:ghost + o1] = by_name[name][o0 - row_lo:o1 - row_lo]
+                continue
             if cfg.type_of(L["members"][0]) == "combination" and len(L["members"]) == 1:
                 t = float(np.float32(float(cfg.params_of(L["members"][0])["mix"])))
                 res = pixel.mix(srcs[0], srcs[1], t)
@@ -120,6 +128,8 @@ CASES = [
     (util.CHAIN5, 3, False, False),
     (util.DIAMOND, 2, True, True),
     (util.CHAIN3, 3, True, True),
+    (util.SPLIT2, 2, True, False),       # a node with two output images, exchange and over-fetch
+    (util.SPLIT2, 3, False, True),
 ]
 # graphs nobody wrote by hand (tests/util.py::random_graph), exchange and over-fetch schedules
 for _seed, _world, _xchg, _fused in ((3001, 2, True, True), (3002, 3, True, False), (3003, 2, False, True), (3004, 2, True, True)):

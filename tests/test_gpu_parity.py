@@ -343,6 +343,7 @@ def test_render_host_mirror(ctx, tmp_path):
 # ---- row strips on real kernels (one GPU standing in for N ranks) --------------------------
 @pytest.mark.parametrize("text,world,flags", [
     (util.CHAIN5, 2, 0), (util.CHAIN5, 3, NF), (util.CHAIN5_SPLIT, 3, 0), (util.CHAIN3, 4, 0), (util.DIAMOND, 2, 0),
+    (util.SPLIT2, 3, 0), (util.SPLIT2, 2, NF),       # a node with two output images: both carry the ghost rows their readers want
 ])
 def test_row_strips_overfetch_on_one_gpu(text, world, flags):
     """The N>1 path of rf_graph.cpp in over-fetch mode (RF_GRAPH_NO_HALO_XCHG: strips carry
@@ -556,6 +557,30 @@ def test_interior_boundary_split(ctx):
             want = util.run_oracle(text, x)
             for flags in (0, NF, rf.RF_GRAPH_TIMERS):
                 util.assert_same(util.run_hip(ctx, text, x, flags=flags, exec_flags=rf.RF_EXEC_FORCE_SPLIT), want, "split flags=%d" % flags)
+
+
+def test_a_node_with_two_output_images(ctx):
+    """split_luma writes luma_image and chroma_image (one image per output binding, pipeline_graph.rs:205-224): both outputs
+    against the oracle, each consumed by its own chain and joined; one output left unwired; every intermediate image too."""
+    for fmt in (util.F32, util.U8):
+        x = util.synthetic(157, 61, fmt, seed=21)
+        for text in (util.SPLIT2, "input -> sp\nsp:chroma_image -> sharpen -> output\nsp: split_luma {}",
+                     "input -> sp\nsp:luma_image -> output\nsp: split_luma {}"):
+            want = util.run_oracle(text, x)
+            for flags in (0, NF, rf.RF_GRAPH_HIPGRAPH):
+                for ex in (0, rf.RF_EXEC_FORCE_SPLIT, rf.RF_EXEC_CONCURRENT_LAYERS):
+                    util.assert_same(util.run_hip(ctx, text, x, flags=flags, exec_flags=ex), want, "split fmt=%d flags=%d ex=%d" % (fmt, flags, ex))
+        # the two images of the split node themselves
+        from oracle import graph as og
+        o = og.GraphOracle(util.SPLIT2, 157, 61, fmt)
+        o.upload_raw(x)
+        o.execute()
+        g = rf.Graph(ctx, rf.Config(util.SPLIT2), 157, 61, fmt, flags=NF)
+        g.upload_raw(x)
+        g.execute(); g.wait()
+        for res in ("sp:luma_image", "sp:chroma_image"):
+            util.assert_same(g.download_image(g.plan.resolve(res)), o.images[o.image_of(res)], res)
+        g.close()
 
 
 def test_exchange_mode_needs_a_communicator():

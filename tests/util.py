@@ -31,6 +31,18 @@ finish: colour_grade { slope: 0.95, offset: 0.01, saturation: 0.9 }
 # same shape with a gaussian5 in the middle: fuses as 3 + 2 launches (two fused launches per frame)
 CHAIN5_SPLIT = CHAIN5.replace("gaussian9    { sigma: 2.0 }", "gaussian5    { sigma: 2.0 }")
 
+# a node with TWO output images (split_luma: luma_image, chroma_image), each processed on its own and joined again
+SPLIT2 = """
+input -> sp
+sp:luma_image -> lg -> mx:input_image0
+sp:chroma_image -> cg -> mx:input_image1
+mx -> output
+sp: split_luma {}
+lg: gaussian5 { sigma: 1.0 }
+cg: colour_grade { slope: 1.2, offset: -0.05, saturation: 1.1 }
+mx: combination { mix: 0.4 }
+"""
+
 DIAMOND = """
 input -> blur -> mixer:input_image0
 input -> sharp -> mixer:input_image1
