@@ -79,10 +79,14 @@ WORKLOADS = {
                       seed=0x5EED0005, radius=15, strong=False, desc="BASELINE configs[4]: 31x31 dense convolution, 7680x4320 rgba32f"),
     "chain3_4k_u8": dict(text=CHAIN3, W=3840, H=2160, fmt=U8, nodes=3, seed=0x5EED0002, radius=3, strong=False,
                          desc="the headline chain on rgba8 (4 B/px): 3840x2160"),
+    "chain3_8k_u8": dict(text=CHAIN3, W=7680, H=4320, fmt=U8, nodes=3, seed=0x5EED0002, radius=3, strong=False,
+                         desc="the headline chain on rgba8 at 7680x4320 (4K is too few waves to judge the format)"),
+    "gauss9_8k_u8": dict(text="input -> gaussian9 -> output\ngaussian9: gaussian9 { sigma: 2.0 }", W=7680, H=4320, fmt=U8, nodes=1,
+                         seed=0x5EED0003, radius=4, strong=False, desc="9x9 separable gaussian on rgba8, 7680x4320"),
     "diamond_4k": dict(text=DIAMOND, W=3840, H=2160, fmt=F32, nodes=3, seed=0x5EED0006, radius=2, strong=False,
                        desc="fork/join graph of pipeline_graph.rs:462-468 (blur || sharpen -> combination), 3840x2160 rgba32f"),
 }
-SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "diamond_4k"]
+SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "chain3_8k_u8", "gauss9_8k_u8", "diamond_4k"]
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec)
 NO_POWER = False               # --no-power
@@ -304,7 +308,7 @@ def launch_roofline(g, wl, launches, rows, n_ev, traffic_key=None):
 COLD_SLOTS = 5
 
 
-def cold_leg(rf, ctx, wl, launches, flags, verify=True):
+def cold_leg(rf, ctx, wl, launches, flags, verify=True, in_flight=True):
     """The headline workload with NO help from the 256 MiB Infinity Cache: frames rotate over COLD_SLOTS frame slots, each
     with its own input and output image, on one queue -- the way the reference runs its frames in flight (--num-frames slots,
     a new frame per slot, one queue: src/main.rs:164-170, src/vulkan/core.rs:123).  Between two touches of a line lie the
@@ -326,6 +330,23 @@ def cold_leg(rf, ctx, wl, launches, flags, verify=True):
                "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                "note": "frame i on slot i % slots, all slots on one queue; time = hipEvents around the whole run / frames"}
         del dom
+        # the same rotation with every slot on its OWN stream (rf_graph_execute(slot): the reference's frames in flight, --num-frames):
+        # consecutive frames are independent, so a frame's ramp-up overlaps its predecessor's drain.  Wall clock around the run.
+        for i in range(2 * COLD_SLOTS if in_flight else 0):
+            g.execute(i % COLD_SLOTS)
+        ctx.synchronize()
+        best = None
+        for _ in range(3 if in_flight else 0):
+            t0 = time.perf_counter()
+            for i in range(n):
+                g.execute(i % COLD_SLOTS)
+            ctx.synchronize()
+            dt = (time.perf_counter() - t0) * 1e3 / n
+            best = dt if best is None else min(best, dt)
+        if in_flight:
+            out["in_flight"] = {"ms_per_frame": round(best, 5), "mpx_per_s": round(W * H / best / 1e3, 1), "achieved_gbs": round(alg / (best * 1e-3) / 1e9, 1),
+                                "frac": round(alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "note": "frame i on slot i % slots, each slot on its own stream (frames in flight); host wall clock / frames"}
         if verify:
             # the LAST slot written is checked against the oracle like the resident leg
             last = (n - 1) % COLD_SLOTS
@@ -454,6 +475,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="frame slots the batch alternates over (reforge's --num-frames; each slot has its own stream and images)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold", action="store_true", help="N = 1: skip the cache-cold leg (rotating frame slots) of the headline")
+    ap.add_argument("--cold-only", action="store_true", help="N = 1: run ONLY the cache-cold leg and print its JSON (profiling: the kernel-trace of "
+                                                             "this command holds cache-cold launches only)")
     ap.add_argument("--skip-workloads", action="store_true", help="N = 1: only the headline workload")
     ap.add_argument("--no-power", action="store_true", help="do not poll rocm-smi for package power / clock (it is never polled under a profiler)")
     ap.add_argument("--skip-strong", action="store_true", help="N > 1: skip the 16384^2 strong-scaling run")
@@ -536,6 +560,13 @@ def main():
     if args.hipgraph:
         flags0 |= rf.RF_GRAPH_HIPGRAPH
     nslots = max(1, args.frames_in_flight)
+    if args.cold_only:
+        if world != 1:
+            raise SystemExit("--cold-only is an N = 1 profiling aid")
+        plan_launches = rf.Plan(rf.Config(wl["text"]), flags0).launch_info()
+        print(json.dumps({"workload": wl["desc"], "cold": cold_leg(rf, ctx_plain, wl, plan_launches, flags0, verify=False, in_flight=False)}), flush=True)
+        ctx_plain.close()
+        return
 
     def make_graph(mode, wl_, H_):
         ctx = ctx_rccl if mode == "exchange" else ctx_plain
@@ -634,12 +665,13 @@ def main():
     roofline["mall_resident"] = bool(working_set <= MALL_BYTES)
     roofline["working_set_bytes"] = working_set
     # the same launch with every byte coming from / going to HBM (the resident figure is cache-assisted)
-    if rank == 0 and world == 1 and not args.no_fusion and not args.hipgraph:
+    if rank == 0 and world == 1 and not args.no_fusion and not args.hipgraph and not args.no_cold:
         try:
             cold = cold_leg(rf, ctx, wl, launches, flags0, verify=not args.skip_cpu_baseline)
             roofline["cold"] = cold
             roofline["frac_cold"] = cold["frac"] if len(launches) == 1 else None
             roofline["launch_ms_cold"] = cold["ms_per_frame"] if len(launches) == 1 else None
+            roofline["frac_cold_in_flight"] = cold["in_flight"]["frac"]
         except rf.RfError as e:
             roofline["cold"] = {"error": str(e)}
 

@@ -174,7 +174,11 @@ const char* rf_plan_launch_output(const rf_plan* plan, int i);
  * built-in `split_luma` has luma_image and chroma_image): all of them, in binding order */
 int         rf_plan_launch_num_outputs(const rf_plan* plan, int i);
 const char* rf_plan_launch_output_at(const rf_plan* plan, int i, int k);
-/* rows a launch reads above/below the rows it writes (sum of its stencil radii) */
+/* rows a launch reads above/below the rows it writes: the sum of its members' stencil radii.  For a fused fork/join launch
+ * this is pre + a + b + post, not pre + max(a, b) + post: the two branches run one behind the other inside the kernel (the
+ * other branch's row rides a delay line), so the launch READS -- and a row strip exchanges / over-fetches -- a + b rows for
+ * the pair although the arithmetic of an output row reaches only max(a, b).  Results are unaffected; the cost is min(a, b)
+ * extra halo rows per side and an earlier "strip height smaller than the halo" limit at N > 1. */
 int         rf_plan_launch_radius(const rf_plan* plan, int i);
 /* 1 if the launch's layer runs in plan order on one stream: one of its launches writes an image
  * another launch of the layer reads or writes (an in-place point op beside a second consumer).
@@ -207,6 +211,10 @@ long long   rf_user_stage_mtime(const char* type_name);
  * Optional disk cache of code objects: env RF_JIT_CACHE_DIR. */
 /* [host] 1 if libhiprtc can be loaded and RF_NO_JIT is unset */
 int         rf_jit_available(void);
+/* [host] path of the libhiprtc in use ("" if none).  The library binds libhiprtc by SONAME on first use: a process that
+ * imported PyTorch first compiles with the copy PyTorch bundles, another compiler build than /opt/rocm's (both are checked
+ * by tests/test_jit_isa.py; the disk cache keeps their objects apart) */
+const char* rf_jit_library(void);
 /* [host] kernels this process has compiled so far (cache hits not counted) */
 int         rf_jit_compile_count(void);
 /* [host] 1 if launch i needs a kernel the catalogue does not hold */

@@ -102,6 +102,7 @@ SIGNATURES = {
     "rf_user_stage_mtime": (C.c_longlong, [_cp]),
     "rf_jit_available": (_i, []),
     "rf_jit_compile_count": (_i, []),
+    "rf_jit_library": (_cp, []),
     "rf_plan_launch_needs_jit": (_i, [_vp, _i]),
     "rf_plan_jit_compile": (_i, [_vp, _i, C.POINTER(C.c_size_t)]),
     "rf_plan_jit_compile_texels": (_i, [_vp, _i, _i, C.POINTER(C.c_size_t)]),

@@ -352,6 +352,12 @@ extern "C" long long rf_user_stage_mtime(const char* type_name)
 // ---- kernels compiled at graph creation (rf_jit.cpp) --------------------------------------------
 extern "C" int rf_jit_available(void) { return jit_available() ? 1 : 0; }
 extern "C" int rf_jit_compile_count(void) { return jit_compile_count(); }
+extern "C" const char* rf_jit_library(void)
+{
+    static thread_local std::string s;
+    s = jit_library();
+    return s.c_str();
+}
 
 extern "C" int rf_plan_launch_member_slot(const rf_plan* p, int i, int k)
 {

@@ -115,9 +115,15 @@ std::string cache_path(const std::string& expr, int waves_per_block)
     const char* dir = std::getenv("RF_JIT_CACHE_DIR");
     if (!dir || !*dir) return "";
     int major = 0, minor = 0;
-    if (Rtc* r = rtc())
+    std::string where;
+    if (Rtc* r = rtc()) {
         if (r->Version) (void)r->Version(&major, &minor);
-    const std::string salt = expr + "|w" + std::to_string(waves_per_block) + "|" + kArch + "|rtc" + std::to_string(major) + "." + std::to_string(minor);
+        // WHICH libhiprtc: a process that imported PyTorch first gets the copy PyTorch bundles (same SONAME, another
+        // compiler build, other code for the same source) -- its objects must not be served to a process on /opt/rocm's
+        Dl_info info;
+        if (dladdr((void*)r->CompileProgram, &info) && info.dli_fname) where = info.dli_fname;
+    }
+    const std::string salt = expr + "|w" + std::to_string(waves_per_block) + "|" + kArch + "|rtc" + std::to_string(major) + "." + std::to_string(minor) + "|" + where;
     char buf[64];
     std::snprintf(buf, sizeof(buf), "%016llx", (unsigned long long)fnv1a(salt, fnv1a(kSource)));
     return std::string(dir) + "/rfjit_" + buf;
@@ -249,6 +255,15 @@ bool jit_available()
         if (std::atoi(e) != 0) return false;
     std::lock_guard<std::mutex> lock(g_mu);
     return rtc() != nullptr;
+}
+
+std::string jit_library()
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    Rtc* r = rtc();
+    Dl_info info;
+    if (r && dladdr((void*)r->CompileProgram, &info) && info.dli_fname) return info.dli_fname;
+    return "";
 }
 
 int jit_compile_count()

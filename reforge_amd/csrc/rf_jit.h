@@ -30,6 +30,8 @@ const JitKernel* jit_lookup(int fmt, int pf, int texels, const StageList& sl);
 // unregister a loaded kernel (an optional variant that turned out to spill): jit_lookup no longer returns it
 void jit_forget(int fmt, int pf, int texels, const StageList& sl);
 hipError_t jit_launch(const JitKernel& k, unsigned grid, unsigned block, void* args, size_t size, hipStream_t stream);
+// path of the libhiprtc this process compiles with ("" if none): a process that imported PyTorch first gets PyTorch's copy
+std::string jit_library();
 // number of kernels compiled by this process (not served from a cache): measurement / tests
 int jit_compile_count();
 // [host] compile only: code object size, 0 + err on failure (CPU tests: no device needed)

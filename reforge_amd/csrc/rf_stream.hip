@@ -295,7 +295,7 @@ static size_t param_bytes(const StageList& sl, const Op* ops, int n_ops, unsigne
         const int kind = sl.st[i].kind, r = sl.st[i].r;
         size_t size = 8;
         if (kind == ST_HTAP || kind == ST_VTAP) size = 8 * (size_t)(r + 1);
-        else if (kind == ST_GRADE) size = 16;
+        else if (kind == ST_GRADE || kind == ST_CROSS3) size = 16;
         else if (kind == ST_USER) { const UserStage* u = user_stage_by_id(sl.st[i].user); if (!u) return 0; size = (size_t)((u->params_size + 7) / 8 * 8); }
         if (off + size + 8 > cap) return 0;
         unsigned char* p = buf + off;
@@ -309,8 +309,8 @@ static size_t param_bytes(const StageList& sl, const Op* ops, int n_ops, unsigne
             const float g[3] = {op->slope, op->offset, op->saturation};
             std::memcpy(p, g, 12);
         } else if (kind == ST_CROSS3 && op) {
-            const float c[2] = {op->wc, op->ws};
-            std::memcpy(p, c, 8);
+            const float c[4] = {op->wc, op->wc, op->ws, op->ws};
+            std::memcpy(p, c, 16);
         } else if (kind == ST_USER && op) {
             std::memcpy(p, op->user_params, std::min(size, sizeof(op->user_params)));
         } else if (kind == ST_MIX && op) {

@@ -356,7 +356,11 @@ struct StGrade {
 // hides behind a whole iteration instead of stalling the wave.
 struct StCross3 {
     static constexpr int RV = 1, RH = 1, LDS_ROWS = 1;
-    struct Params { float wc, ws; };
+    // each weight twice, like the gaussian taps: the operand pair of a packed fma, ONE aligned 8-byte scalar load each.  As two
+    // adjacent floats, the older compiler PyTorch bundles (the hiprtc a process that imported torch gets) widened the loads into
+    // overlapping vector loads and pinned the block to scratch -- scratch loads inside the counted-vmcnt loops
+    // (tests/test_jit_isa.py found it; stream_prepare refuses such a kernel, so the cost was a split chain, not wrong texels)
+    struct Params { v2f wc, ws; };
     // bottom-up walks keep a window: n, c = rows y-1, y (in walk order), cw, ce = y's left/right neighbours.
     // Top-down walks keep RUNNING SUMS instead (as StVTap does): n = the sum of output row y so far (its N, W, C, E
     // taps), c = the N tap of output row y+1, cw = the newest real row (bottom-edge flush; KEEP phases only) -- the same

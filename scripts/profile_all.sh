@@ -9,21 +9,22 @@
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 TAG="$1"; shift
-WORKLOADS="${@:-chain3_4k chain3_4k_unfused gauss9_8k chain5_16k conv31_8k_valu conv31_8k_mfma chain3_4k_u8 diamond_4k}"
+WORKLOADS="${@:-chain3_4k chain3_4k_cold chain3_4k_unfused gauss9_8k chain5_16k conv31_8k_valu conv31_8k_mfma chain3_4k_u8 chain3_8k_u8 gauss9_8k_u8 diamond_4k}"
 export TMPDIR=/tmp
 OUT="$ROOT/gpurun_out/prof"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$ROOT"
 for wl in $WORKLOADS; do
   name="${wl%_unfused}"
-  extra="--skip-workloads --no-power"; [ "$wl" != "$name" ] && extra="$extra --no-fusion"
+  extra="--skip-workloads --no-power --no-cold"; [ "$wl" != "$name" ] && extra="$extra --no-fusion"
   case "$name" in
+    chain3_4k_cold)   name=chain3_4k; extra="--cold-only --no-power" ;;   # the kernel trace of this pass holds cache-cold launches only (rotating frame slots)
     conv31_8k_valu)   name=conv31_8k; extra="$extra --conv-path 3" ;;
     conv31_8k_mfma)   name=conv31_8k; extra="$extra --conv-path 2" ;;
   esac
   case "$name" in
     chain3_4k|chain3_4k_u8|diamond_4k)  steps=40; fps=8; psteps=4 ;;
-    gauss9_8k)  steps=20; fps=4; psteps=3 ;;
+    gauss9_8k|chain3_8k_u8|gauss9_8k_u8)  steps=20; fps=4; psteps=3 ;;
     chain5_16k) steps=5;  fps=2; psteps=2 ;;
     conv31_8k)  steps=5;  fps=1; psteps=2 ;;
   esac

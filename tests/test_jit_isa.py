@@ -12,7 +12,6 @@ import os
 import re
 import sys
 
-import numpy as np
 import pytest
 
 import reforge_amd as rf
@@ -24,70 +23,40 @@ import isa_obj  # noqa: E402
 
 pytestmark = pytest.mark.skipif(not rf.lib().rf_jit_available(), reason="libhiprtc cannot be loaded")
 
-KINDS = ["passthrough {}", "gaussian5 { sigma: 1.0 }", "gaussian9 { sigma: 2.0 }", "gaussian { sigma: 1.2, radius: %d }",
-         "colour_grade { slope: 1.1, offset: 0.0, saturation: 0.9 }", "sharpen { amount: 0.5 }"]
+from tests import jit_isa_compile as gen  # noqa: E402
 
 
-def chain_text(rng, n):
-    names = ["n%02d" % i for i in range(n)]
-    decl = []
-    for nm in names:
-        k = KINDS[rng.randint(len(KINDS))]
-        decl.append("%s: %s" % (nm, (k % rng.randint(0, 4)) if "%d" in k else k))
-    return "input -> " + " -> ".join(names) + " -> output\n" + "\n".join(decl)
+def _torch_importable():
+    import importlib.util
+    return importlib.util.find_spec("torch") is not None
 
 
-def fork_text(rng):
-    def branch(tag):
-        n = int(rng.randint(0, 3))
-        names = ["%s%d" % (tag, i) for i in range(n)]
-        decl = []
-        for nm in names:
-            k = KINDS[1 + rng.randint(len(KINDS) - 1)]
-            decl.append("%s: %s" % (nm, (k % rng.randint(1, 3)) if "%d" in k else k))
-        return names, decl
-    a, da = branch("a")
-    b, db = branch("b")
-    if not a and not b:
-        a, da = ["a0"], ["a0: sharpen { amount: 0.7 }"]
-    pre = ["p0"] if rng.randint(2) else []
-    post = ["q0"] if rng.randint(2) else []
-    src = pre[-1] if pre else "input"
-    lines = []
-    if pre:
-        lines.append("input -> p0")
-    lines.append(" -> ".join([src] + a + ["mx:input_image0"]))
-    lines.append(" -> ".join([src] + b + ["mx:input_image1"]))
-    lines.append(" -> ".join(["mx"] + post + ["output"]))
-    decl = da + db + ["mx: combination { mix: 0.3 }"] + (["p0: gaussian5 { sigma: 0.9 }"] if pre else []) + (["q0: colour_grade { slope: 1.0, offset: 0.0, saturation: 1.1 }"] if post else [])
-    return "\n".join(lines + decl)
-
-
-@pytest.fixture(scope="module")
-def compiled(tmp_path_factory):
-    """compile ~50 generated launches for both formats into a private cache dir; returns the .hsaco paths"""
+@pytest.fixture(scope="module", params=["this process", "a process that imported torch first"])
+def compiled(request, tmp_path_factory):
+    """compile ~50 generated launches for both formats into a private cache dir; returns the .hsaco paths.
+    Twice: in this process (whatever libhiprtc it has), and in a child that imports PyTorch FIRST and therefore compiles with the
+    libhiprtc / libamd_comgr PyTorch bundles -- another compiler build, which gave the sharpen parameters a scratch copy until
+    they were stored as aligned pairs (StCross3::Params)."""
     cache = tmp_path_factory.mktemp("jitcache")
-    old = os.environ.get("RF_JIT_CACHE_DIR")
-    os.environ["RF_JIT_CACHE_DIR"] = str(cache)
-    try:
-        rng = np.random.RandomState(20261004)
-        texts = [chain_text(rng, int(rng.randint(2, 6))) for _ in range(22)] + [fork_text(rng) for _ in range(12)]
-        n_jit = 0
-        for k, text in enumerate(texts):
-            p = rf.Plan(rf.Config(text))
-            if not any(p.needs_jit()):
-                continue
-            n_jit += 1
-            p.jit_compile(rf.RF_FORMAT_RGBA32F)
-            if k % 3 == 0:
-                p.jit_compile(rf.RF_FORMAT_RGBA8)
-    finally:
-        if old is None:
-            os.environ.pop("RF_JIT_CACHE_DIR", None)
-        else:
-            os.environ["RF_JIT_CACHE_DIR"] = old
+    if request.param == "this process":
+        old = os.environ.get("RF_JIT_CACHE_DIR")
+        os.environ["RF_JIT_CACHE_DIR"] = str(cache)
+        try:
+            n_jit = gen.compile_all(rf, os.path.join(ROOT, "shaders"))
+        finally:
+            if old is None:
+                os.environ.pop("RF_JIT_CACHE_DIR", None)
+            else:
+                os.environ["RF_JIT_CACHE_DIR"] = old
+        assert n_jit >= 20
+    else:
+        if not _torch_importable():
+            pytest.skip("no PyTorch here")
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "jit_isa_compile.py"), str(cache), "torch"], capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0 and "compiled" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     files = sorted(glob.glob(str(cache / "*.hsaco")))
-    assert n_jit >= 20 and len(files) >= 24, (n_jit, len(files))
+    assert len(files) >= 24, len(files)
     return files
 
 
