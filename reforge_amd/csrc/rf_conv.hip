@@ -277,16 +277,21 @@ constexpr int kCvStepRows = 32;     // output rows per step
 constexpr int kCvT = 8;             // output columns per lane
 constexpr int kCvSub = 20;          // texels per sub-row: (128 + 30 + 2) / 8; 8 x 20 x 16 B = 2560 B = 10 x 256 B per row
 constexpr int kCvLanesX = kCvStripW / kCvT;     // 16
-constexpr int kCvLanesY = 64 / kCvLanesX;       // 4 rows per wave
+constexpr int kCvLanesY = 64 / kCvLanesX;       // 4 rows per wave (of the default <8 columns, 8 waves> shape)
+static_assert(kCvLanesY * 8 == 32, "eight waves cover a 32-row step");
 
-template <class Px, int K>   // K is compile-time: the tap loop unrolls completely, the register window rotates by renaming
-__global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_t src_pitch, char* dst, size_t dst_pitch,
+// CT output columns per lane, WAVES waves per workgroup: <8, 8> = 16 column groups x 4 rows per wave, two waves per SIMD (the
+// default); <4, 16> = 32 column groups x 2 rows per wave, FOUR waves per SIMD on the same 32-row step and the same ring (RF_CONV_PATH=4)
+template <class Px, int K, int CT = kCvT, int WAVES = 8>   // K is compile-time: the tap loop unrolls completely, the register window rotates by renaming
+__global__ __launch_bounds__(64 * WAVES) void conv2d_valu_kernel(const char* src, size_t src_pitch, char* dst, size_t dst_pitch,
                                                           int W, int row_lo, int row_hi, int y0, int y1, int rows_per_chunk,
                                                           int ring, const float* __restrict__ weights)
 {
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     constexpr int KQ = (K + 3) / 4;                               // f4 per padded weight row
-    constexpr int WN = kCvT + 4;                                  // register window: kCvT texels in use + 4 in flight
+    constexpr int kLanesX = kCvStripW / CT, kLanesY = 64 / kLanesX, kSub = (kCvT * kCvSub) / CT, THREADS = 64 * WAVES;
+    static_assert(kLanesY * WAVES == kCvStepRows, "a step is 32 output rows");
+    constexpr int WN = CT + 4;                                  // register window: kCvT texels in use + 4 in flight
     f4* wl = reinterpret_cast<f4*>(dyn_smem);                    // weights, [K][KQ] f4
     f4* tile = wl + K * KQ;                                       // [ring][4][kCvSub]
     constexpr int kRowTexels = kCvT * kCvSub;                     // 160 texels = 2560 B per ring row
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
     constexpr int xin = kCvStripW + 2 * r;
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int lx = lane & (kCvLanesX - 1), ly = lane / kCvLanesX;
+    const int lx = lane & (kLanesX - 1), ly = lane / kLanesX;
 
     const int x_out0 = (int)blockIdx.x * kCvStripW;
     const int cy0 = y0 + (int)blockIdx.y * rows_per_chunk;
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
     if (cy0 >= cy1) return;
 
     // weight rows into LDS (a per-tap scalar load from global would stall the wave on every tap)
-    for (int i = tid; i < K * KQ * 4; i += 512) {
+    for (int i = tid; i < K * KQ * 4; i += THREADS) {
         const int dy = i / (KQ * 4), dx = i % (KQ * 4);
         reinterpret_cast<float*>(wl)[i] = dx < K ? weights[dy * K + dx] : 0.0f;
     }
@@ -314,14 +319,14 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
     };
     auto put = [&](int rr, int c, typename Px::Raw v) {
         const int slot = (rr - first_in) % ring;
-        tile[slot * kRowTexels + (c % kCvT) * kCvSub + (c / kCvT)] = Px::decode(v);
+        tile[slot * kRowTexels + (c % CT) * kSub + (c / CT)] = Px::decode(v);
     };
     // first fill: the ring's worth of rows of step 0 (32 + 2r rows)
     int loaded_to = cy0 + kCvStepRows + r;
-    for (int i = tid; i < (loaded_to - first_in) * xin; i += 512) put(first_in + i / xin, i % xin, fetch(first_in + i / xin, i % xin));
+    for (int i = tid; i < (loaded_to - first_in) * xin; i += THREADS) put(first_in + i / xin, i % xin, fetch(first_in + i / xin, i % xin));
     // the 32 rows of the NEXT step travel global -> registers while this step's 31 weight rows compute, and go to the
     // ring after it (the slots they take are the 32 oldest rows, free once every wave has passed the barrier)
-    constexpr int NPF = (kCvStepRows * xin + 511) / 512;
+    constexpr int NPF = (kCvStepRows * xin + THREADS - 1) / THREADS;
     for (int ys = cy0; ys < cy1; ys += kCvStepRows) {
         const bool has_next = ys + kCvStepRows < cy1;
         typename Px::Raw pf[NPF];
@@ -329,15 +334,15 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
         if (has_next) {
 #pragma unroll
             for (int q = 0; q < NPF; ++q) {
-                const int i = tid + 512 * q;
+                const int i = tid + THREADS * q;
                 if (i < kCvStepRows * xin) pf[q] = fetch(loaded_to + i / xin, i % xin);
             }
         }
 
-        f4 acc[kCvT];
+        f4 acc[CT];
 #pragma unroll
-        for (int t = 0; t < kCvT; ++t) acc[t] = f4_zero();
-        int slot = ((ys - cy0) + kCvLanesY * wave + ly) % ring;   // ring slot of input row (ys + 4*wave + ly + dy - r)
+        for (int t = 0; t < CT; ++t) acc[t] = f4_zero();
+        int slot = ((ys - cy0) + kLanesY * wave + ly) % ring;   // ring slot of input row (ys + 4*wave + ly + dy - r)
         for (int dy = 0; dy < K; ++dy) {
             const f4* row = tile + slot * kRowTexels + lx;        // texel m of this lane's window: row[(m % T) * kCvSub + m / T]
             const f4* wrow = wl + dy * KQ;                        // same address in every lane: LDS broadcast
@@ -349,25 +354,25 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
             }
             f4 win[WN];
 #pragma unroll
-            for (int m = 0; m < WN; ++m) win[m] = row[(m % kCvT) * kCvSub + m / kCvT];
+            for (int m = 0; m < WN; ++m) win[m] = row[(m % CT) * kSub + m / CT];
 #pragma unroll
             for (int dx = 0; dx < K; ++dx) {
 #pragma unroll
-                for (int t = 0; t < kCvT; ++t) acc[t] = fma4(wv[dx], win[(dx + t) % WN], acc[t]);
+                for (int t = 0; t < CT; ++t) acc[t] = fma4(wv[dx], win[(dx + t) % WN], acc[t]);
                 // texel dx is done: its register takes texel dx + WN (needed 4 taps from now)
-                if (dx + WN <= K - 1 + kCvT - 1) {
+                if (dx + WN <= K - 1 + CT - 1) {
                     const int m = dx + WN;
-                    win[dx % WN] = row[(m % kCvT) * kCvSub + m / kCvT];
+                    win[dx % WN] = row[(m % CT) * kSub + m / CT];
                 }
             }
             slot = slot + 1 == ring ? 0 : slot + 1;
         }
-        const int oy = ys + kCvLanesY * wave + ly;
+        const int oy = ys + kLanesY * wave + ly;
         if (oy < cy1) {
             char* orow = dst + (ptrdiff_t)oy * (ptrdiff_t)dst_pitch;
 #pragma unroll
-            for (int t = 0; t < kCvT; ++t) {
-                const int ox = x_out0 + kCvT * lx + t;
+            for (int t = 0; t < CT; ++t) {
+                const int ox = x_out0 + CT * lx + t;
                 if (ox < W) Px::store(orow, (unsigned)ox * (unsigned)Px::BPP, acc[t]);
             }
         }
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
         if (has_next) {
 #pragma unroll
             for (int q = 0; q < NPF; ++q) {
-                const int i = tid + 512 * q;
+                const int i = tid + THREADS * q;
                 if (i < kCvStepRows * xin) put(loaded_to + i / xin, i % xin, pf[q]);
             }
             loaded_to += kCvStepRows;
@@ -383,21 +388,21 @@ __global__ __launch_bounds__(512) void conv2d_valu_kernel(const char* src, size_
     }
 }
 
-template <class Px, int K = 3>
+template <class Px, int CT, int WAVES, int K = 3>
 static hipError_t launch_conv_valu(int k, dim3 grid, size_t lds, hipStream_t stream, const char* src, size_t src_pitch, char* dst,
                                    size_t dst_pitch, int W, int row_lo, int row_hi, int y0, int y1, int rpc, int ring, const float* weights)
 {
     if constexpr (K > 2 * kMaxRadius + 1) {
         return hipErrorInvalidValue;
     } else {
-        if (k != K) return launch_conv_valu<Px, K + 2>(k, grid, lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0, y1, rpc, ring, weights);
+        if (k != K) return launch_conv_valu<Px, CT, WAVES, K + 2>(k, grid, lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0, y1, rpc, ring, weights);
         static bool attr_done[kMaxDevices] = {};   // the attribute is per device
         bool& attr_set = attr_done[current_device()];
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_valu_kernel<Px, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_valu_kernel<Px, K, CT, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL((conv2d_valu_kernel<Px, K>), grid, dim3(512), lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0, y1, rpc,
+        hipLaunchKernelGGL((conv2d_valu_kernel<Px, K, CT, WAVES>), grid, dim3(64 * WAVES), lds, stream, src, src_pitch, dst, dst_pitch, W, row_lo, row_hi, y0, y1, rpc,
                            ring, weights);
         return hipGetLastError();
     }
@@ -444,8 +449,11 @@ static hipError_t launch_conv2d_px(const Op& op, Image src, Image dst, const Geo
         int rpc = conv_rows_per_chunk(rows, strips, 256, kCvStepRows, 2 * kCvStepRows);   // one workgroup (up to 159 KiB of LDS) per CU
         if (tune.rows_per_chunk > 0) rpc = (tune.rows_per_chunk + kCvStepRows - 1) / kCvStepRows * kCvStepRows;
         dim3 grid((unsigned)strips, (unsigned)((rows + rpc - 1) / rpc));
-        return launch_conv_valu<Px>(K, grid, lds, stream, static_cast<const char*>(src.base), src.pitch, static_cast<char*>(dst.base),
-                                    dst.pitch, g.W, g.row_lo, g.row_hi, g.y0, g.y1, rpc, ring, op.dev_weights);
+        // (<4 columns per lane, 16 waves> = four waves per SIMD on the same ring was built and measured in round 3: bit-exact and
+        // 7 % SLOWER, 2.60-2.64 ms against 2.43-2.45 at 31x31 8K -- its extra LDS reads pull the clock from 2.11-2.14 down to 1.96 GHz,
+        // profiles/r03_conv_four_waves_probe.txt; the kernel keeps the template parameters, the product instantiates <8, 8> only)
+        return launch_conv_valu<Px, kCvT, 8>(K, grid, lds, stream, static_cast<const char*>(src.base), src.pitch, static_cast<char*>(dst.base),
+                                             dst.pitch, g.W, g.row_lo, g.row_hi, g.y0, g.y1, rpc, ring, op.dev_weights);
     }
     if (mfma) {
         const int ring = kCm2StepRows + 2 * op.radius;
