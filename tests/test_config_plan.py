@@ -527,6 +527,21 @@ kw: conv2d_weights { ksize: 5, sigma: 1.2 }
 cv: conv2d { ksize: 5, sigma: 9.0 }"""
 
 
+def test_planner_matches_restatement_on_random_dags_with_two_output_nodes():
+    """random DAGs in which some nodes are `split_luma` (two output images, either or both wired): layers and aliasing against
+    the restatement, and every launch that writes two images writes two DIFFERENT allocations"""
+    import numpy as np
+    n_split = 0
+    for seed in range(200):
+        text = util.random_dag(np.random.RandomState(7000 + seed), split=True)
+        p, layers, reuse = plans(text)
+        assert p.layers() == layers and p.aliases() == reuse, text
+        for l in p.launch_info() + rf.Plan(rf.Config(text)).launch_info():
+            assert len(set(l["outputs"])) == len(l["outputs"]) >= 1, text
+            n_split += len(l["outputs"]) == 2
+    assert n_split > 60
+
+
 def test_storage_buffer_edges_follow_the_reference_rules():
     """A descriptor that is no image variable is looked up as a storage buffer by its block TYPE name
     (vkutils.rs:165-170, shader.rs:144-147); buffer edges order the layers like image edges

@@ -614,6 +614,36 @@ def test_random_graphs(ctx, seed):
             util.assert_same(util.run_hip(ctx, text, x, flags=flags, exec_flags=ex), want, "seed %d flags %d %dx%d\n%s" % (seed, flags, W, H, text))
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_dags_with_two_output_nodes(ctx, seed):
+    """random DAGs in which some nodes write TWO images (split_luma): aliasing of both outputs, their readers in later layers,
+    fused and unfused, both formats; every third seed also as 2-3 row strips in over-fetch mode"""
+    rng = np.random.RandomState(7000 + seed)
+    text = util.random_dag(rng, split=True)
+    W, H = int(rng.randint(1, 200)), int(rng.randint(40, 120))
+    for fmt in (util.F32, util.U8):
+        x = util.synthetic(W, H, fmt, seed=seed)
+        want = util.run_oracle(text, x)
+        for flags in (0, NF, rf.RF_GRAPH_HIPGRAPH):
+            util.assert_same(util.run_hip(ctx, text, x, flags=flags, exec_flags=rf.RF_EXEC_CONCURRENT_LAYERS if seed & 1 else 0), want,
+                             "seed %d flags %d %dx%d\n%s" % (seed, flags, W, H, text))
+    if seed % 3 == 0:
+        world = 2 + seed % 2
+        p = rf.Plan(rf.Config(text))
+        if p.halo_schedule(False)[3] <= H // world:
+            want = util.run_oracle(text, pixel.fill_synthetic(W, H, util.F32, 0x5EED0004))
+            strips = []
+            for rank in range(world):
+                c = rf.Context(0, rank, world, None)
+                g = rf.Graph(c, rf.Config(text), W, H, util.F32, flags=rf.RF_GRAPH_NO_HALO_XCHG)
+                g.fill_synthetic(0x5EED0004)
+                g.execute(); g.wait()
+                strips.append(g.download_raw())
+                g.close()
+                c.close()
+            util.assert_same(np.concatenate(strips, axis=0), want, "strips seed %d world %d\n%s" % (seed, world, text))
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_random_graphs_as_row_strips(seed, monkeypatch):
     """Random graphs again, cut into 2..4 row strips in over-fetch mode (every rank's context on

@@ -139,8 +139,9 @@ def random_graph(rng):
     return "\n".join(lines + decl)
 
 
-def random_dag(rng):
-    """A wider generator than random_graph: up to 9 nodes, any earlier node's output (or the input)
+def random_dag(rng, split=False):
+    """(split=True: some nodes are `split_luma`, a node with TWO output images, each of which later nodes may read.)
+    A wider generator than random_graph: up to 9 nodes, any earlier node's output (or the input)
     may feed a new node, `combination` joins appear anywhere, type aliases, large radii and kernels,
     in-place point ops anywhere.  The last node drives the output; dangling nodes are pruned by
     making every node reachable from it (a node nobody reads feeds a final join)."""
@@ -153,6 +154,18 @@ def random_dag(rng):
         name = "n%02d" % i
         roll = rng.rand()
         src = outputs[rng.randint(len(outputs))] if rng.rand() < 0.35 else outputs[-1]
+        if split and rng.rand() < 0.18:
+            # one input, two readable outputs; a later node (or the final joins) must read each wired one
+            sname = "s%02d" % i
+            decl.append("%s: split_luma {}" % sname)
+            edges.append([src, sname])
+            readers[src] = readers.get(src, 0) + 1
+            which = rng.randint(3)               # 0: both outputs offered, 1: luma only, 2: chroma only
+            if which != 2:
+                outputs.append(sname + ":luma_image")
+            if which != 1:
+                outputs.append(sname + ":chroma_image")
+            continue
         if roll < 0.15 and len(outputs) >= 3:
             a, b = [outputs[k] for k in rng.choice(len(outputs), 2, replace=False)]
             if a != "input" or b != "input":
