@@ -170,3 +170,72 @@ def test_cli_live_reload(tmp_path):
     ref.upload_srgb8(rgba)
     ref.execute()
     assert np.fromfile(dst, np.uint8).reshape(64, 96, 4).tobytes() == ref.download_srgb8().tobytes()
+
+
+@pytest.mark.gpu
+def test_cli_user_stage_files_and_their_live_reload(tmp_path):
+    """--shader-path: a node type the registry lacks is the file {shader_path}/{type}.stage.hip (config.rs:59-75), compiled when
+    the graph is built; --watch polls the stage files of the running graph like reload_changed_pipelines (render.rs:225-249):
+    an edited file rebuilds the graph, one that no longer compiles prints the compiler's message and keeps the old graph."""
+    import shutil
+    import time
+    import reforge_amd as rf
+    rgba = pixel.fill_synthetic(96, 64, util.U8, 79)
+    rgba[..., 3] = 255
+    shaders = tmp_path / "sh"
+    shaders.mkdir()
+    for f in ("invert.stage.hip", "edge_detect.stage.hip"):
+        shutil.copy(os.path.join(ROOT, "shaders", f), shaders / f)
+    src, dst, cfg, log = str(tmp_path / "in.png"), str(tmp_path / "out.rgba"), tmp_path / "live.cfg", tmp_path / "err.log"
+    write_png(src, rgba, lambda y: 0)
+    cfg.write_text("input -> neg -> output\nneg: invert { enabled: true, strength: 1.0 }")
+    # one frame: equals the Python host on the same graph (same library, same stage file)
+    r = run_cli("-i", src, "--config", str(cfg), "-o", dst, "--shader-path", str(shaders))
+    assert r.returncode == 0 and "GPU: {neg: " in r.stderr, r.stderr
+    old = rf.shader_path()
+    rf.set_shader_path(str(shaders))
+    try:
+        ctx = rf.Context(0)
+        g = rf.Graph(ctx, rf.Config(cfg.read_text()), 96, 64, rf.RF_FORMAT_RGBA32F)
+        g.upload_srgb8(rgba)
+        g.execute(); g.wait()
+        want = g.download_srgb8()
+        g.close()
+        ctx.close()
+    finally:
+        rf.set_shader_path(old)
+    assert np.fromfile(dst, np.uint8).reshape(64, 96, 4).tobytes() == want.tobytes()
+    assert not np.array_equal(want[..., :3], rgba[..., :3])
+    # without --shader-path pointing at the file the type does not exist (Shader::from_path -> None, utils.rs:23)
+    r = run_cli("-i", src, "--config", str(cfg), "-o", dst, "--shader-path", str(tmp_path / "nowhere"))
+    assert r.returncode != 0 and "no such filter" in r.stderr
+
+    def wait_for(text, seconds=90.0):
+        end = time.time() + seconds
+        while time.time() < end:
+            if text in log.read_text(errors="replace"):
+                return True
+            time.sleep(0.01)
+        return False
+
+    stage = shaders / "invert.stage.hip"
+    good = stage.read_text()
+    with open(log, "wb") as err:
+        p = subprocess.Popen([CLI, "-i", src, "--config", str(cfg), "-o", dst, "--shader-path", str(shaders), "--frames", "400", "--watch",
+                              "--frame-interval-ms", "25"], stderr=err)
+        try:
+            assert wait_for("GPU: {neg: ")
+            stage.write_text(good.replace("(1.0f - c.x) - c.x", "(1.0f - c.x) - undeclared_thing"))       # no longer compiles
+            assert wait_for("undeclared_thing")
+            assert p.poll() is None                                # still rendering with the old graph
+            stage.write_text(good.replace("if (!p.enabled) return c;", "return c;"))                       # now a passthrough
+            time.sleep(0.05)
+            os.utime(stage, None)
+            time.sleep(1.5)                                        # several frames with the rebuilt graph
+            assert p.poll() is None or p.returncode == 0
+            assert p.wait(timeout=180) == 0
+        finally:
+            if p.poll() is None:
+                p.kill()
+    # the last frame came from the edited stage: a passthrough through the sRGB boundary = the input codes
+    assert np.fromfile(dst, np.uint8).reshape(64, 96, 4).tobytes() == rgba.tobytes()
