@@ -73,26 +73,25 @@ def blocks(ins):
     return out
 
 
-def regions(ins):
-    """strongly connected regions of the CFG with a cycle: [set of block start addrs]"""
-    bl = blocks(ins)
+def _sccs(nodes, succ):
+    """strongly connected components (iterative Tarjan) of the subgraph `nodes` with successor lists succ[a] (restricted to nodes)"""
     index, low, onstack, stack, res, counter = {}, {}, set(), [], [], [0]
-    for root in bl:
+    for root in nodes:
         if root in index:
             continue
-        work = [(root, iter(bl[root][1]))]
+        work = [(root, iter(succ[root]))]
         index[root] = low[root] = counter[0]; counter[0] += 1
         stack.append(root); onstack.add(root)
         while work:
             v, it = work[-1]
             advanced = False
             for w in it:
-                if w not in bl:
+                if w not in nodes:
                     continue
                 if w not in index:
                     index[w] = low[w] = counter[0]; counter[0] += 1
                     stack.append(w); onstack.add(w)
-                    work.append((w, iter(bl[w][1])))
+                    work.append((w, iter(succ[w])))
                     advanced = True
                     break
                 if w in onstack:
@@ -108,9 +107,31 @@ def regions(ins):
                     w = stack.pop(); onstack.discard(w); comp.add(w)
                     if w == v:
                         break
-                if len(comp) > 1 or v in bl[v][1]:
+                if len(comp) > 1 or v in succ[v]:
                     res.append(comp)
-    return bl, res
+    return res
+
+
+def regions(ins):
+    """(blocks, INNERMOST cyclic regions): a strongly connected region whose cycles all pass through its entry blocks; outer loops
+    are peeled by cutting the edges back into their entries and looking again (the stream kernel's walks sit inside one outer
+    loop over work items)"""
+    bl = blocks(ins)
+    succ = {a: [t for t in bl[a][1] if t in bl] for a in bl}
+    out = []
+
+    def walk(nodes, succ):
+        for comp in _sccs(nodes, succ):
+            entries = {a for a in comp if any(a in succ[p] for p in nodes if p not in comp)} or {min(comp)}
+            cut = {a: [t for t in succ[a] if not (t in entries and a in comp)] for a in comp}
+            inner = [c for c in _sccs(comp, cut)]
+            if not inner:
+                out.append(comp)
+            else:
+                walk(comp, cut)
+
+    walk(set(bl), succ)
+    return bl, out
 
 
 def loops(ins):

@@ -18,6 +18,10 @@ def innermost_loops(body):
         elif m2:
             blocks.append(cur)
             cur = (None, m2.group(1), [])
+        elif re.match(r"^\s+; (=>|  )", l) and not cur[2]:
+            # continuation of the block's header comment: a NESTED loop's header carries "Parent Loop ..." on the label line and
+            # "=>  This Inner Loop Header: Depth=2" on the next
+            cur = (cur[0], cur[1] + " " + l.strip(), cur[2])
         else:
             cur[2].append(l)
     blocks.append(cur)
