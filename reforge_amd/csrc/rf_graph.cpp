@@ -102,10 +102,6 @@ rf_status fail(rf_status st, const std::string& msg)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-constexpr float kXccRatioDefault = 0.0f;                        // (set from the measurements of DESIGN.md 6.1c)
-constexpr int kXccWsWords = 4096;                               // claim bits of up to ~32 000 work items (x 4 waves) + the counter
-constexpr size_t kXccWeightedMaxBytes = (size_t)256 << 20;      // the Infinity Cache
-
 // Row pitch of a device image.  EXPERIMENT (RF_PITCH_PAD = bytes added to every row): how the pitch maps rows onto the HBM
 // channels decides how well a column-strip walk streams (scripts/walk_probe.py, profiles/r03_pitch_*).
 size_t image_pitch(size_t row_bytes)
@@ -203,22 +199,8 @@ rf_status launch_rows(rf_graph* g, FrameSlot& f, const Launch& L, Geom geo, int 
         HIP_TRY(launch_mix(g->opt.format, f.images.at(L.src[0]).view(), f.images.at(L.src[1]).view(), dst.view(), geo,
                            L.ops[0].slope, stream));
     } else {
-        StreamTuning tune = g->tune;
-        const size_t li = (size_t)(&L - g->launches.data());
-        if (g->xcc_ratio > 1.0f && li < f.xcc_ws.size() && f.xcc_ws[li]) {
-            // XCC-weighted placement only where it was measured to pay: the launch's images stay in the 256 MiB Infinity Cache,
-            // where an odd XCC moves ~20 % fewer bytes per microsecond than an even one
-            const DeviceImage& src = f.images.at(L.src[0]);
-            const size_t rows = (size_t)strip_rows_of(g) + 2 * (size_t)g->ghost;
-            const size_t working_set = rows * (src.pitch + (L.src[0] == L.dst ? 0 : dst.pitch));
-            if (working_set <= kXccWeightedMaxBytes) {
-                tune.xcc_ws = f.xcc_ws[li];
-                tune.xcc_ws_words = kXccWsWords;
-                tune.xcc_ratio = g->xcc_ratio;
-            }
-        }
         HIP_TRY(launch_ops(g->opt.format, L.ops.data(), (int)L.ops.size(), f.images.at(L.src[0]).view(), dst.view(), geo,
-                           tune, stream));
+                           g->tune, stream));
     }
     return RF_OK;
 }
@@ -496,8 +478,6 @@ static void read_tuning(rf_graph* g)
     if (const char* e = std::getenv("RF_CONCURRENT_LAYERS")) g->concurrent_layers = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_FORCE_SPLIT")) g->force_split = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_NO_ALTERNATE")) g->tune.walk = std::atoi(e) ? 2 : 1;
-    g->xcc_ratio = kXccRatioDefault;
-    if (const char* e = std::getenv("RF_XCC_RATIO")) g->xcc_ratio = (float)std::atof(e);
     // Exchange mode shares ONE comm stream and one src_ready/halo_ready event pair per slot: two
     // stencils of a layer reading the same source would each re-exchange its ghost rows while the
     // other's boundary kernels may still read them.  Plan order on one stream keeps it ordered.
@@ -657,14 +637,6 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
             f.join.push_back(e);
         }
         HIP_TRY(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
-        if (g->xcc_ratio > 1.0f) {
-            for (size_t k = 0; k < g->launches.size(); ++k) {
-                unsigned* ws = nullptr;
-                HIP_TRY(hipMalloc((void**)&ws, kXccWsWords * sizeof(unsigned)));
-                f.xcc_ws.push_back(ws);
-                HIP_TRY(hipMemset(ws, 0, kXccWsWords * sizeof(unsigned)));
-            }
-        }
         if (exchange_mode(g) || g->force_split) {
             HIP_TRY(hipStreamCreateWithFlags(&f.comm, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&f.src_ready, hipEventDisableTiming));
@@ -719,7 +691,6 @@ extern "C" void rf_graph_destroy(rf_graph* g)
         for (auto e : f.t1) (void)hipEventDestroy(e);
         for (auto e : f.join) (void)hipEventDestroy(e);
         if (f.fork) (void)hipEventDestroy(f.fork);
-        for (unsigned* ws : f.xcc_ws) (void)hipFree(ws);
         if (f.src_ready) (void)hipEventDestroy(f.src_ready);
         if (f.halo_ready) (void)hipEventDestroy(f.halo_ready);
         if (f.comm) (void)hipStreamDestroy(f.comm);

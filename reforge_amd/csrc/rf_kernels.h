@@ -74,12 +74,6 @@ struct StreamTuning {
     int rows_per_chunk = 0;   // RF_ROWS_PER_CHUNK
     int walk = 0;             // chunk walk direction: 0 auto, 1 odd chunks bottom-up (halo rows shared through L2), 2 all top-down
     int texels_per_lane = 0;  // RF_TEXELS_PER_LANE: 0 auto, 1 or 2 (rgba32f stream kernels)
-    // XCC-weighted placement of a stream launch (rf_stream_dev.h, stream_kernel): the claim workspace of THIS launch in THIS frame
-    // slot (zeroed once, the kernel leaves it zeroed), its size in 32-bit words, and how much faster an even XCC is than an odd one
-    // (<= 1: equal shares, the static placement)
-    unsigned* xcc_ws = nullptr;
-    int xcc_ws_words = 0;
-    float xcc_ratio = 0.0f;
     int conv_path = 0;        // RF_CONV_PATH: 0 = register-blocked VALU kernel, 1 = 16x16 LDS tile, 2 = MFMA (K >= 9), 3 = VALU
 };
 

@@ -79,7 +79,6 @@ struct FrameSlot {
 
     std::vector<hipEvent_t> t0, t1;          // GpuTimer query pairs, one per launch
     bool timed_once = false;
-    std::vector<unsigned*> xcc_ws;           // per launch: the claim workspace of XCC-weighted stream launches (zeroed; the kernel leaves it so)
     hipGraphExec_t graph_exec = nullptr;
     hipGraph_t graph = nullptr;
 };
@@ -110,5 +109,4 @@ struct rf_graph {
     std::vector<std::string> time_names;   // scratch for rf_graph_node_times
     std::string jit_note;                  // why the graph fell back to catalogue-only fusion ("" if it did not)
     bool exchanged_once = false;           // the first halo exchange of THIS graph is waited for with a deadline
-    float xcc_ratio = 0.0f;                // speed of an even XCC over an odd one for launches that stay in the Infinity Cache (0: equal shares)
 };

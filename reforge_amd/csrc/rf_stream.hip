@@ -354,27 +354,13 @@ static bool launch_shape(Image src, Image dst, const Geom& g, const StreamTuning
     A.yb1 = g.yb0 + rows_b;
     const int chunks = A.chunks_a + (rows_b + A.rows_per_chunk - 1) / A.rows_per_chunk;
     A.alternate = tune.walk == 2 ? 0 : 1;
+    A.reserved = 0;
     A.n_work = groups * chunks;
     out.grid = (unsigned)((A.n_work + 7) / 8 * 8);   // 1-D, a multiple of the 8 XCDs (see the kernel's block order)
-    // XCC-weighted placement (stream_kernel): the even physical XCCs take `ratio` times the work items of the odd ones; the grid
-    // supplies the larger count on every XCC (the surplus workgroups of the odd ones find no item and leave at once)
-    A.ws = nullptr;
-    A.n_even = A.n_odd = 0;
-    if (tune.xcc_ws && tune.xcc_ratio > 1.0f && A.n_work >= 64 && (long)A.n_work * kWavesPerBlock / 32 + 3 <= (long)tune.xcc_ws_words) {
-        int n_odd = (int)((double)A.n_work / (4.0 * (1.0 + (double)tune.xcc_ratio)) + 0.5);
-        if (n_odd < 1) n_odd = 1;
-        const int n_even = (A.n_work - 4 * n_odd + 3) / 4;
-        if (n_even >= n_odd) {
-            A.ws = tune.xcc_ws;
-            A.n_even = n_even;
-            A.n_odd = n_odd;
-            out.grid = (unsigned)(8 * n_even);
-        }
-    }
     static const bool trace = std::getenv("RF_TRACE_SHAPE") != nullptr;      // diagnostics: the launch geometry, to stderr
     if (trace)
-        std::fprintf(stderr, "rf shape: %dx%d rows, bpp %d, texels %d, walk %d: %d strips in %d groups, %d-row chunks, %d workgroups on %d resident (%d CUs), per XCC %d even / %d odd\n",
-                     g.W, rows, bpp, texels, tune.walk, A.n_strips, groups, A.rows_per_chunk, A.n_work, resident, device_cus(), A.n_even, A.n_odd);
+        std::fprintf(stderr, "rf shape: %dx%d rows, bpp %d, texels %d, walk %d: %d strips in %d groups, %d-row chunks, %d workgroups on %d resident (%d CUs)\n",
+                     g.W, rows, bpp, texels, tune.walk, A.n_strips, groups, A.rows_per_chunk, A.n_work, resident, device_cus());
     return true;
 }
 

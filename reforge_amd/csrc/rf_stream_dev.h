@@ -815,15 +815,12 @@ struct alignas(8) StreamHdr {
     // a second range of output rows [yb0, yb1) served by the chunks from index `chunks_a` on (Geom::yb0: the two boundary
     // slivers of a row strip as one launch); a launch with one range has chunks_a = its chunk count and an empty second range
     int chunks_a, yb0, yb1;
-    // XCC-weighted placement (stream_kernel): work items per even / odd PHYSICAL XCC and the claim workspace (ws[0] = waves that
-    // have finished, ws[1..] = one bit per (work item, wave)); ws == nullptr: the static placement by blockIdx
-    int n_even, n_odd;
-    unsigned* ws;
+    int reserved;
 };
 template <class... S> struct StreamArgs : StreamHdr {
-    ParamPack<S...> params;      // at offset sizeof(StreamHdr) = 96
+    ParamPack<S...> params;      // at offset sizeof(StreamHdr) = 88
 };
-static_assert(sizeof(StreamHdr) == 96, "the host assembles kernel arguments as bytes: header, then the parameter slots");
+static_assert(sizeof(StreamHdr) == 88, "the host assembles kernel arguments as bytes: header, then the parameter slots");
 
 #ifndef RF_WAVES_PER_BLOCK
 #define RF_WAVES_PER_BLOCK 4
@@ -833,7 +830,7 @@ constexpr int kWavesPerBlock = RF_WAVES_PER_BLOCK;
 // One wave's walk over rows [y0, y1) of its strip.  REV = bottom-up: rows are addressed with
 // negated pitches and mirrored bounds, so the schedule code sees an ordinary top-down walk.
 template <class Px, int PF, int T, bool REV, class... S>
-RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane<T>& L, int wave, char* ring_wave, unsigned ring_lds, int y0, int y1, bool claim, unsigned item)
+RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane<T>& L, int wave, char* ring_wave, unsigned ring_lds, int y0, int y1)
 {
     constexpr int RH = SumRH<S...>::value;
     typedef Source<Px, PF, T> Src;
@@ -870,28 +867,9 @@ RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane<T>& L, int wave, c
     src.pitch = REV ? -(ptrdiff_t)A.src_pitch : (ptrdiff_t)A.src_pitch;
     src.ring = ring_wave;
     src.lds_base = ring_lds;
-    // weighted placement (stream_kernel): CLAIM bit `item` of the workspace before the first DMA.  ONE lane; the returned word
-    // lands in `claim_old` when the atomic retires, which is before the first row does (vector-memory operations retire in
-    // issue order) -- it is read only behind the wait for that row.
-    unsigned claim_old = 0;
-    if (claim && L.lane == 0) {
-        const unsigned voff = 4u * (1u + (item >> 5)), bit = 1u << (item & 31);
-        asm volatile("global_atomic_or %0, %1, %2, %3 sc0" : "=v"(claim_old) : "v"(voff), "v"(bit), "s"(A.ws) : "memory");      // agent scope
-    }
     src.prologue();
     Feed feed;
     src.wait_row(0, k);
-    // the claim of this (work item, wave) was issued before the first DMA and is older than all of them: it has returned
-    // by now (vector-memory operations retire in issue order).  Somebody else holds the item: leave, once the rows in flight
-    // have landed (a wave must not end with LDS-DMA writes outstanding into LDS the next workgroup will own).
-    if (claim) {
-        unsigned word;
-        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(word) : "v"(claim_old) : "memory");
-        if (word & (1u << (item & 31))) {
-            wait_vmcnt<0>();
-            return;
-        }
-    }
     feed.fetch(src, 0, L);
 
     // Phases: the generic loop (per-stage schedule tests) until the pipeline has emitted its
@@ -925,45 +903,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, T > 1 ? 2 : 1) void stream_ker
     __shared__ __attribute__((aligned(16))) char ring[kWavesPerBlock][Src::SLOTS * Src::SLOT_BYTES];
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(
-        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&ring[0][0]) + (unsigned)wave * (unsigned)(Src::SLOTS * Src::SLOT_BYTES));
-    const int gx = (A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock;
-
-    // One work item for one wave: strip `sw` (0..3) of item q, on the EXECUTING wave's LDS.  claim: take bit (q, sw) of the
-    // workspace first (weighted placement); a wave that finds it taken does nothing.
-    auto run_item = [&](int q, int sw, bool claim) {
-        const unsigned item = (unsigned)q * kWavesPerBlock + (unsigned)sw;
-        const int strip = (q % gx) * kWavesPerBlock + sw;
-        const int chunk = q / gx;
-        const bool second = chunk >= A.chunks_a;          // wave-uniform
-        const int y0 = second ? A.yb0 + (chunk - A.chunks_a) * A.rows_per_chunk : A.y0 + chunk * A.rows_per_chunk;
-        const int y1 = min(y0 + A.rows_per_chunk, second ? A.yb1 : A.y1);
-        if (strip >= A.n_strips || y0 >= y1) return;      // wave-uniform; no barriers anywhere (an item without rows is never claimed:
-                                                          // the sweep finds it, comes here again and leaves again)
-        Lane<T> L;
-        L.lane = (int)(threadIdx.x & 63);
-        L.x0 = strip * VALID - RH;
-        // T > 1: every one of the T stores of a row must have an active lane (the counted vmcnt waits
-        // assume T stores are really issued; hipcc branches around a store whose exec mask is empty).
-        // The last strip is therefore moved left until it ends at the frame edge -- it recomputes a
-        // few columns of its neighbour and writes the same values (the host launches T > 1 only when
-        // W >= 64 T and the launch is not in place).
-        if constexpr (T > 1) {
-            if (L.x0 + 64 * T - RH > A.W) L.x0 = A.W - 64 * T + RH;
-        }
-        L.W = A.W;
-        L.lds = smem[wave];
-        // Odd chunks walk bottom-up: a chunk and its neighbour then read the halo rows they
-        // share at the same moment (both at their start, or both at their end), so the second
-        // read is served by the XCD's L2 instead of the fabric.  Stencil-free pipelines have no
-        // halo and always walk top-down.
-        constexpr bool kHasHalo = SumRV<S...>::value > 0;
-        if (kHasHalo && A.alternate && (chunk & 1))
-            stream_wave<Px, PF, T, true, S...>(A, L, wave, ring[wave], ring_lds, y0, y1, claim, item);
-        else
-            stream_wave<Px, PF, T, false, S...>(A, L, wave, ring[wave], ring_lds, y0, y1, claim, item);
-    };
-
     // XCD-aware block order (guide T1): blocks are dealt round-robin over the 8 XCDs, so block
     // b and b+8 share an L2.  Give each XCD a CONTIGUOUS range of work items (strip groups
     // fastest, then chunks): workgroups that share halo columns or halo rows then share an L2.
@@ -971,68 +910,43 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, T > 1 ? 2 : 1) void stream_ker
     // (Measured and NOT kept, profiles/r03_work_order_probe.txt, r03_stacked_chunks_probe.txt: workgroups in plain dispatch order,
     // chunks fastest instead of strip groups, and "stacked" workgroups whose four waves walk four vertically adjacent chunks of
     // one strip in alternating directions so that the seams' halo rows are shared inside the workgroup -- none was faster.)
-    // (ONE call site of run_item below -- the static placement, the weighted placement and the sweep all pass through the same
-    // loop -- so the stage pipeline is instantiated once per walk direction, not three times)
-    const bool weighted = A.ws != nullptr;
-    int q, sw = wave;
-    bool have;
-    if (!weighted) {
-        const int per_xcd = (int)gridDim.x >> 3;
-        q = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-        have = q < A.n_work;
-    } else {
-        // XCC-WEIGHTED placement.  With the frame resident in the Infinity Cache the odd XCCs move about 20 % fewer bytes per
-        // microsecond than the even ones (per-workgroup timestamps, profiles/r03_workgroup_timestamps_4k.txt), and with equal
-        // shares the even ones idle for the last fifth of the launch.  Here every PHYSICAL XCC owns a contiguous range of work
-        // items sized by its speed: n_even items on XCC 0 / 2 / 4 / 6, n_odd on the others; the k-th workgroup the dispatcher
-        // places on an XCC (blockIdx >> 3, blocks being dealt round-robin) takes the k-th item of that XCC's range.  The
-        // round-robin deal is an OBSERVATION, not a contract, so nothing depends on it: every wave CLAIMS its (item, wave)
-        // bit with an atomic before it computes (taken already: it does nothing), and the last wave of the grid to finish
-        // computes whatever was never claimed, then clears the workspace for the next launch.  Under the observed placement
-        // the claims never collide and the sweep finds nothing.
-        const int p = (int)(__builtin_amdgcn_s_getreg(6164) & 7u);      // HW_REG_XCC_ID[3:0]
-        const int i = (int)blockIdx.x >> 3;
-        q = (p >> 1) * (A.n_even + A.n_odd) + ((p & 1) ? A.n_even : 0) + i;
-        have = i < ((p & 1) ? A.n_odd : A.n_even) && q < A.n_work;
+    const int gx = (A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int q = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (q >= A.n_work) return;
+    const int strip = (q % gx) * kWavesPerBlock + wave;
+    if (strip >= A.n_strips) return;                 // wave-uniform; no barriers below
+    const int chunk = q / gx;
+    const bool second = chunk >= A.chunks_a;          // wave-uniform
+    const int y0 = second ? A.yb0 + (chunk - A.chunks_a) * A.rows_per_chunk : A.y0 + chunk * A.rows_per_chunk;
+    const int y1 = min(y0 + A.rows_per_chunk, second ? A.yb1 : A.y1);
+    if (y0 >= y1) return;
+
+    Lane<T> L;
+    L.lane = (int)(threadIdx.x & 63);
+    L.x0 = strip * VALID - RH;
+    // T > 1: every one of the T stores of a row must have an active lane (the counted vmcnt waits
+    // assume T stores are really issued; hipcc branches around a store whose exec mask is empty).
+    // The last strip is therefore moved left until it ends at the frame edge -- it recomputes a
+    // few columns of its neighbour and writes the same values (the host launches T > 1 only when
+    // W >= 64 T and the launch is not in place).
+    if constexpr (T > 1) {
+        if (L.x0 + 64 * T - RH > A.W) L.x0 = A.W - 64 * T + RH;
     }
-    bool claim = weighted, sweeping = false;
-    unsigned next_word = 0, missing = 0;
-    const unsigned nbits = (unsigned)A.n_work * kWavesPerBlock, words = (nbits + 31) / 32;
-    for (;;) {
-        if (have) run_item(q, sw, claim);
-        if (!weighted) break;
-        wait_vmcnt<0>();
-        if (!sweeping) {
-            unsigned done = 0;
-            if ((threadIdx.x & 63) == 0) {
-                const unsigned zero = 0, one = 1;
-                asm volatile("global_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)" : "=v"(done) : "v"(zero), "v"(one), "s"(A.ws) : "memory");
-            }
-            if ((unsigned)__builtin_amdgcn_readfirstlane(done) != gridDim.x * kWavesPerBlock - 1u) break;
-            // the last wave of the grid: every claim has been performed (each wave drained its vector-memory operations before
-            // it counted itself out).  Compute what nobody claimed, then clear the workspace.
-            sweeping = true;
-            claim = false;
-        }
-        while (!missing && next_word < words) {
-            unsigned got = 0;
-            const unsigned voff = 4u * (1u + next_word), nothing = 0;
-            if ((threadIdx.x & 63) == 0)
-                asm volatile("global_atomic_or %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)" : "=v"(got) : "v"(voff), "v"(nothing), "s"(A.ws) : "memory");
-            got = (unsigned)__builtin_amdgcn_readfirstlane(got);
-            missing = ~got & (nbits - 32 * next_word >= 32 ? ~0u : (1u << (nbits - 32 * next_word)) - 1u);
-            ++next_word;
-        }
-        if (!missing) {
-            for (unsigned w = threadIdx.x & 63; w <= words; w += 64) A.ws[w] = 0;
-            break;
-        }
-        const unsigned item = 32 * (next_word - 1) + (unsigned)__builtin_ctz(missing);
-        missing &= missing - 1;
-        q = (int)(item / kWavesPerBlock);
-        sw = (int)(item % kWavesPerBlock);
-        have = true;
-    }
+    L.W = A.W;
+    L.lds = smem[wave];
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&ring[0][0]) + (unsigned)wave * (unsigned)(Src::SLOTS * Src::SLOT_BYTES));
+
+    // Odd chunks walk bottom-up: a chunk and its neighbour then read the halo rows they
+    // share at the same moment (both at their start, or both at their end), so the second
+    // read is served by the XCD's L2 instead of the fabric.  Stencil-free pipelines have no
+    // halo and always walk top-down.
+    constexpr bool kHasHalo = SumRV<S...>::value > 0;
+    if (kHasHalo && A.alternate && (chunk & 1))
+        stream_wave<Px, PF, T, true, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
+    else
+        stream_wave<Px, PF, T, false, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
 }
 
 }  // namespace rf
