@@ -786,6 +786,23 @@ def main():
         except rf.RfError:
             out["copy_gbps"] = None
         out["roofline"]["copy_gbps"] = out["copy_gbps"]
+        # a better yardstick than the float4 grid-stride copy above (which reads ~5.1 TB/s): the SAME stream-kernel structure with no
+        # arithmetic and no halo -- the passthrough node -- beyond the Infinity Cache (7680x4320) and inside it (3840x2160).  What a
+        # stencil launch of this design can hope for is this rate, not 8 TB/s.
+        try:
+            yard = {}
+            for key, (w_, h_) in (("8k", (7680, 4320)), ("4k", (3840, 2160))):
+                gp = rf.Graph(ctx, rf.Config("input -> passthrough -> output"), w_, h_, F32)
+                gp.fill_synthetic(1)
+                gp.execute(); gp.wait()
+                t1 = max(gp.time_frames(3) / 3, 1e-3)
+                n_ = int(max(5, min(20000, 200.0 / t1)))
+                ms_ = min(gp.time_frames(n_) / n_ for _ in range(2))
+                gp.close()
+                yard[key] = {"ms_per_frame": round(ms_, 5), "gbps": round(2 * w_ * h_ * 16 / (ms_ * 1e-3) / 1e9, 1)}
+            out["roofline"]["stream_copy"] = yard
+        except rf.RfError as e:
+            out["roofline"]["stream_copy"] = {"error": str(e)}
         if not args.skip_workloads and args.workload == "chain3_4k":
             out["workloads"] = {}
             for name in SIDE_WORKLOADS:

@@ -204,6 +204,21 @@ def conv2d(img, ksize, sigma):
     return out
 
 
+def split_luma(img):
+    """one input, two outputs: luma = fma(0.0722, b, fma(0.7152, g, 0.2126 r)); (l, l, l, a) and (fma(0.5, c - l, 0.5) ..., a)"""
+    kr, kg, kb, half = f32(0.2126), f32(0.7152), f32(0.0722), Fraction(1, 2)
+    luma, chroma = [], []
+    for row in img:
+        lr, cr = [], []
+        for t in row:
+            l = fma(kb, t[2], fma(kg, t[1], rn(kr * t[0])))
+            lr.append([l, l, l, t[3]])
+            cr.append([fma(half, rn(t[c] - l), half) for c in range(3)] + [t[3]])
+        luma.append(lr)
+        chroma.append(cr)
+    return luma, chroma
+
+
 def combination(a, b, mix):
     mix = f32(mix)
     return [[[fma(mix, rn(tb[c] - ta[c]), ta[c]) for c in range(4)] for ta, tb in zip(ra, rb)] for ra, rb in zip(a, b)]
@@ -240,7 +255,27 @@ def conv7(x, fmt):
     return node(conv2d, fmt, [x], 7, 1.5)
 
 
+def split2(x, fmt):
+    """tests/util.py SPLIT2: split_luma -> (gaussian5 on the luma image | colour_grade on the chroma image) -> combination"""
+    luma, chroma = split_luma(load(x, fmt))
+    luma, chroma = store(luma, fmt), store(chroma, fmt)
+    a = node(gaussian, fmt, [luma], 1.0, 2)
+    b = node(colour_grade, fmt, [chroma], 1.2, -0.05, 1.1)
+    return node(combination, fmt, [a, b], 0.4)
+
+
+def gauss_r7_sharp(x, fmt):
+    """a wide gaussian (radius 7, sigma 3) followed by a strong sharpen"""
+    a = node(gaussian, fmt, [x], 3.0, 7)
+    return node(sharpen, fmt, [a], 1.25)
+
+
 GRAPHS = {"chain3": chain3, "chain5": chain5, "diamond": diamond, "gauss9": gauss9, "conv7": conv7}
+# further graphs in golden.npz part B (round 3): name -> (function, config text the oracle / the kernels run)
+MORE_GRAPHS = {
+    "split2": (split2, None),              # text: tests/util.py SPLIT2
+    "gauss_r7_sharp": (gauss_r7_sharp, "input -> gg -> sh -> output\ngg: gaussian { sigma: 3.0, radius: 7 }\nsh: sharpen { amount: 1.25 }"),
+}
 
 
 def to_bytes(img, fmt):

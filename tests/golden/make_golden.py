@@ -74,7 +74,7 @@ def main():
     for tag, dt in (("f32", np.float32), ("u8", np.uint8)):
         x = ex.synthetic(W, H, tag, 0x5EED0002)
         out["in_" + tag] = np.frombuffer(ex.to_bytes(x, tag), dtype=dt).reshape(H, W, 4).copy()
-        for name, fn in ex.GRAPHS.items():
+        for name, fn in list(ex.GRAPHS.items()) + [(k, v[0]) for k, v in ex.MORE_GRAPHS.items()]:
             out["%s_%s" % (name, tag)] = np.frombuffer(ex.to_bytes(fn(x, tag), tag), dtype=dt).reshape(H, W, 4).copy()
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.npz"), **out)
     print("wrote golden.npz with", len(out), "arrays")

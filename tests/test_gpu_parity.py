@@ -85,6 +85,9 @@ def test_golden_vectors(ctx, tag, flags):
                        ("gauss9", "input -> gaussian9 -> output\ngaussian9: gaussian9 { sigma: 2.0 }"),
                        ("conv7", "input -> conv2d -> output\nconv2d: conv2d { ksize: 7, sigma: 1.5 }")):
         util.assert_same(util.run_hip(ctx, text, x, flags=flags), GOLDEN["%s_%s" % (name, tag)], "%s %s flags=%d" % (name, tag, flags))
+    from tests.golden import exact_eval as ex
+    for name, (_fn, text) in ex.MORE_GRAPHS.items():
+        util.assert_same(util.run_hip(ctx, text or util.SPLIT2, x, flags=flags), GOLDEN["%s_%s" % (name, tag)], "%s %s flags=%d" % (name, tag, flags))
 
 
 # ---- oracle parity on seeded frames: every node type, ragged sizes, chunk seams ---------

@@ -120,6 +120,9 @@ def test_golden_part_b_from_the_exact_evaluator(tag, fmt):
     util.assert_same(run(util.DIAMOND, x), GOLDEN["diamond_" + tag], "diamond")
     util.assert_same(run("input -> gaussian9 -> output\ngaussian9: gaussian9 { sigma: 2.0 }", x), GOLDEN["gauss9_" + tag], "gauss9")
     util.assert_same(run("input -> conv2d -> output\nconv2d: conv2d { ksize: 7, sigma: 1.5 }", x), GOLDEN["conv7_" + tag], "conv7")
+    from tests.golden import exact_eval as ex
+    for name, (_fn, text) in ex.MORE_GRAPHS.items():
+        util.assert_same(run(text or util.SPLIT2, x), GOLDEN["%s_%s" % (name, tag)], name)
 
 
 def test_aliasing_plan_does_not_change_results():
