@@ -372,6 +372,7 @@ extern "C" int rf_plan_launch_needs_jit(const rf_plan* p, int i)
     if (!l) return -1;
     std::vector<Op> ops = ops_of_members(p->plan, l->members, l->member_slot, nullptr);
     StageList sl;
+    if (ops.size() == 1 && ops[0].kind == OP_USERN) return 1;      // a user node: always compiled at graph creation
     if ((ops.size() < 2 && !(ops.size() == 1 && ops[0].kind == OP_USER)) || !ops_to_stages(ops.data(), (int)ops.size(), sl)) return 0;
     return stream_in_catalogue(sl) ? 0 : 1;
 }
@@ -388,8 +389,15 @@ extern "C" rf_status rf_plan_jit_compile_texels(const rf_plan* p, int format, in
     for (const auto& l : p->launches) {
         std::vector<Op> ops = ops_of_members(p->plan, l.members, l.member_slot, nullptr);
         StageList sl;
-        if ((ops.size() < 2 && !(ops.size() == 1 && ops[0].kind == OP_USER)) || !ops_to_stages(ops.data(), (int)ops.size(), sl) || stream_in_catalogue(sl)) continue;
         std::string err;
+        if (ops.size() == 1 && ops[0].kind == OP_USERN) {
+            if (texels_per_lane != 1) continue;
+            const size_t n = jit_compile_only_user_node(format, ops[0].user_id, err);
+            if (n == 0) return fail(RF_ERR_UNSUPPORTED, err);
+            total += n;
+            continue;
+        }
+        if ((ops.size() < 2 && !(ops.size() == 1 && ops[0].kind == OP_USER)) || !ops_to_stages(ops.data(), (int)ops.size(), sl) || stream_in_catalogue(sl)) continue;
         if (texels_per_lane == 2 && (sl.sum_rh() > 7 || sl.max_rv() > 4 || sl.pair())) continue;      // no two-texel variant of such a list (choose_texels)
         const size_t n = jit_compile_only(format, 4, texels_per_lane, sl, 4, err);
         if (n == 0) return fail(RF_ERR_UNSUPPORTED, err);

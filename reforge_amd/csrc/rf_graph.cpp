@@ -7,8 +7,11 @@
 #include <cstring>
 #include <thread>
 
+#include "rf_jit.h"
 #include "rf_rccl_abi.h"
 #include "rf_runtime.h"
+#include "rf_user.h"
+#include "rf_user_dev.h"
 
 using namespace rf;
 
@@ -183,6 +186,41 @@ rf_status exchange_rows(rf_graph* g, const DeviceImage& img, int r, hipStream_t 
 
 bool exchange_mode(const rf_graph* g) { return g->ctx->world > 1 && !(g->opt.flags & RF_GRAPH_NO_HALO_XCHG); }
 
+// a user NODE (rf_user.h, a stage file that declares its images): user_node_kernel of rf_user_dev.h, compiled at graph creation
+static hipError_t launch_user_node(int fmt, const Launch& L, FrameSlot& f, const Geom& geo, hipStream_t stream)
+{
+    if (geo.y1 <= geo.y0 || geo.W <= 0) return hipSuccess;
+    const Op& op = L.ops[0];
+    const UserStage* u = user_stage_by_id(op.user_id);
+    const JitKernel* k = jit_lookup_user_node(fmt, op.user_id);
+    if (!u || !k || L.src.size() != u->inputs.size()) return hipErrorInvalidDeviceFunction;      // graph_build compiled it: cannot happen
+    UserNodeArgs A;
+    std::memset(&A, 0, sizeof(A));
+    for (size_t i = 0; i < L.src.size(); ++i) {
+        const Image v = f.images.at(L.src[i]).view();
+        A.src[i] = static_cast<const char*>(v.base);
+        A.src_pitch[i] = v.pitch;
+    }
+    for (size_t k2 = 0; k2 < L.dsts.size(); ++k2) {
+        // the output variable this image is wired to (outputs the graph leaves unwired stay null: not stored)
+        for (size_t o = 0; o < u->outputs.size(); ++o) {
+            if (u->out_binding[o] != L.dst_bindings[k2]) continue;
+            const Image v = f.images.at(L.dsts[k2]).view();
+            A.dst[o] = static_cast<char*>(v.base);
+            A.dst_pitch[o] = v.pitch;
+        }
+    }
+    A.W = geo.W;
+    A.y0 = geo.y0;
+    A.y1 = geo.y1;
+    A.grid_x = (geo.W + 255) / 256;
+    static_assert(sizeof(A.params) == sizeof(op.user_params), "Params block");
+    std::memcpy(A.params, op.user_params, sizeof(A.params));
+    const int rows = geo.y1 - geo.y0;
+    const unsigned gy = (unsigned)(rows > 1024 ? 1024 : rows);
+    return jit_launch(*k, (unsigned)A.grid_x * gy, 256, &A, sizeof(A), stream);
+}
+
 // the kernel(s) of one launch over output rows [y0, y1) of `geo`
 rf_status launch_rows(rf_graph* g, FrameSlot& f, const Launch& L, Geom geo, int y0, int y1, hipStream_t stream)
 {
@@ -195,6 +233,8 @@ rf_status launch_rows(rf_graph* g, FrameSlot& f, const Launch& L, Geom geo, int 
         Image luma{}, chroma{};
         for (size_t k = 0; k < L.dsts.size(); ++k) (L.dst_bindings[k] == 1 ? luma : chroma) = f.images.at(L.dsts[k]).view();
         HIP_TRY(launch_split_luma(g->opt.format, f.images.at(L.src[0]).view(), luma, chroma, geo, stream));
+    } else if (L.ops.size() == 1 && L.ops[0].kind == OP_USERN) {
+        HIP_TRY(launch_user_node(g->opt.format, L, f, geo, stream));
     } else if (L.ops.size() == 1 && L.ops[0].kind == OP_MIX) {
         HIP_TRY(launch_mix(g->opt.format, f.images.at(L.src[0]).view(), f.images.at(L.src[1]).view(), dst.view(), geo,
                            L.ops[0].slope, stream));
@@ -243,7 +283,7 @@ rf_status run_launch(rf_graph* g, FrameSlot& f, size_t li, hipStream_t stream, b
         if (xchg) HIP_TRY(hipStreamWaitEvent(stream, f.halo_ready, 0));
         // the r top and r bottom rows: ONE launch over two row ranges for the stream kernels (two slivers of r rows leave
         // most of the chip idle, and each launch costs its start-up and its drain), two launches for the kernels of their own
-        const bool own_kernel = L.ops.size() == 1 && (L.ops[0].kind == OP_MIX || L.ops[0].kind == OP_CONV2D || L.ops[0].kind == OP_SPLIT);
+        const bool own_kernel = L.ops.size() == 1 && own_kernel_kind(L.ops[0].kind);
         if (own_kernel) {
             st = launch_rows(g, f, L, geo, geo.y0, geo.y0 + r, stream);
             if (st != RF_OK) return st;
@@ -506,6 +546,11 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
             std::vector<Op> ops = ops_of_members(g->plan.plan, d.members, d.member_slot, nullptr);
             bool has_user = false;
             for (const auto& o : ops) has_user = has_user || o.kind == OP_USER;
+            if (ops.size() == 1 && ops[0].kind == OP_USERN) {
+                // a user NODE (its file declares its images): a kernel of its own, rf_user_dev.h
+                if (user_only && !jit_compile_user_node(opt.format, ops[0].user_id, jerr)) return false;
+                continue;
+            }
             if (user_only ? !has_user : (ops.size() < 2 && !has_user)) continue;      // single built-in nodes are in the catalogue
             if (!stream_prepare(opt.format, ops.data(), (int)ops.size(), opt.width, Hs1 - Hs0, g->tune, jerr)) return false;
         }
@@ -1186,6 +1231,7 @@ extern "C" rf_status rf_graph_time_launch(rf_graph* g, int launch, int iters, fl
                 for (size_t k = 0; k < L.dsts.size(); ++k) (L.dst_bindings[k] == 1 ? luma : chroma) = f->images.at(L.dsts[k]).view();
                 return launch_split_luma(g->opt.format, f->images.at(L.src[0]).view(), luma, chroma, geo, f->stream);
             }
+            if (L.ops.size() == 1 && L.ops[0].kind == OP_USERN) return launch_user_node(g->opt.format, L, *f, geo, f->stream);
             if (L.ops.size() == 1 && L.ops[0].kind == OP_MIX)
                 return launch_mix(g->opt.format, f->images.at(L.src[0]).view(), f->images.at(L.src[1]).view(), f->images.at(L.dst).view(), geo,
                                   L.ops[0].slope, f->stream);

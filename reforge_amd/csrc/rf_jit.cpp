@@ -18,7 +18,7 @@ namespace rf {
 
 namespace {
 
-// the device source: rf_device.h + rf_stream_dev.h, generated into build/ by the Makefile
+// the device source: rf_device.h + rf_stream_dev.h + rf_user_dev.h, generated into build/ by the Makefile
 const char kSource[] =
 #include "build/rf_jit_source.inc"
     ;
@@ -183,9 +183,14 @@ void cache_store(const std::string& stem, const Compiled& c)
     if (write_file_atomically(stem + ".hsaco", c.code.data(), c.code.size())) (void)write_file_atomically(stem + ".name", name.data(), name.size());
 }
 
-const Compiled* compile(int fmt, int pf, int texels, const StageList& sl, int waves_per_block, std::string& err)
+std::string node_expression(int fmt, const UserStage& u)
 {
-    const std::string expr = name_expression(fmt, pf, texels, sl);
+    return std::string("rf::user_node_kernel<") + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", rfuser::" + u.ident + "::Stage>";
+}
+
+// expr: the kernel instantiation to build; users: the user stages (rf_user.h ids) whose wrappers the translation unit needs
+const Compiled* compile_expr(const std::string& expr, const std::vector<int>& users, int waves_per_block, std::string& err)
+{
     auto it = g_code.find(expr);
     if (it != g_code.end()) return &it->second;
     const std::string cpath = cache_path(expr, waves_per_block);
@@ -200,11 +205,10 @@ const Compiled* compile(int fmt, int pf, int texels, const StageList& sl, int wa
     // the stages of user types ({shader_path}/{type}.stage.hip) this list names, wrapped into their namespaces (rf_user.cpp)
     std::string source_with_users;
     const char* source = kSource;
-    if (sl.has_user()) {
+    if (!users.empty()) {
         source_with_users = kSource;
-        for (int i = 0; i < sl.n; ++i) {
-            if (sl.st[i].kind != ST_USER) continue;
-            const UserStage* u = user_stage_by_id(sl.st[i].user);
+        for (int id : users) {
+            const UserStage* u = user_stage_by_id(id);
             if (!u) { err = "a user stage of this launch is no longer registered"; return nullptr; }
             if (source_with_users.find("namespace " + u->ident + " {") == std::string::npos) source_with_users += u->wrapper();
         }
@@ -238,6 +242,14 @@ const Compiled* compile(int fmt, int pf, int texels, const StageList& sl, int wa
     ++g_compiled;
     if (!cpath.empty()) cache_store(cpath, c);
     return &(g_code[expr] = std::move(c));
+}
+
+const Compiled* compile(int fmt, int pf, int texels, const StageList& sl, int waves_per_block, std::string& err)
+{
+    std::vector<int> users;
+    for (int i = 0; i < sl.n; ++i)
+        if (sl.st[i].kind == ST_USER) users.push_back(sl.st[i].user);
+    return compile_expr(name_expression(fmt, pf, texels, sl), users, waves_per_block, err);
 }
 
 std::string loaded_key(const std::string& expr)
@@ -279,15 +291,15 @@ size_t jit_compile_only(int fmt, int pf, int texels, const StageList& sl, int wa
     return c ? c->code.size() : 0;
 }
 
-bool jit_compile(int fmt, int pf, int texels, const StageList& sl, int waves_per_block, std::string& err)
+namespace {
+// compile (or fetch) `expr` and load it on the current device; g_mu held
+bool load_expr(const std::string& expr, const std::vector<int>& users, int texels, int waves_per_block, std::string& err)
 {
-    std::lock_guard<std::mutex> lock(g_mu);
-    const std::string expr = name_expression(fmt, pf, texels, sl);
     const std::string lk = loaded_key(expr);
     if (g_loaded.count(lk)) return true;
     JitKernel k;
     for (int attempt = 0;; ++attempt) {
-        const Compiled* c = compile(fmt, pf, texels, sl, waves_per_block, err);
+        const Compiled* c = compile_expr(expr, users, waves_per_block, err);
         if (!c) return false;
         hipModule_t mod = nullptr;
         hipError_t e = hipModuleLoadData(&mod, c->code.data());
@@ -321,6 +333,43 @@ bool jit_compile(int fmt, int pf, int texels, const StageList& sl, int waves_per
     k.resident_workgroups = per_cu * (cus > 0 ? cus : 256);
     g_loaded[lk] = k;      // the module stays loaded for the life of the process (kernels are shared by every graph)
     return true;
+}
+}  // namespace
+
+bool jit_compile(int fmt, int pf, int texels, const StageList& sl, int waves_per_block, std::string& err)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    std::vector<int> users;
+    for (int i = 0; i < sl.n; ++i)
+        if (sl.st[i].kind == ST_USER) users.push_back(sl.st[i].user);
+    return load_expr(name_expression(fmt, pf, texels, sl), users, texels, waves_per_block, err);
+}
+
+// ---- user nodes (rf_user_dev.h): user_node_kernel<Px, rfuser::<ident>::Stage>, 256 threads per workgroup ----------------
+bool jit_compile_user_node(int fmt, int user_id, std::string& err)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    const UserStage* u = user_stage_by_id(user_id);
+    if (!u || !u->multi) { err = "not a user node"; return false; }
+    return load_expr(node_expression(fmt, *u), {user_id}, 1, 4, err);
+}
+
+const JitKernel* jit_lookup_user_node(int fmt, int user_id)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    const UserStage* u = user_stage_by_id(user_id);
+    if (!u) return nullptr;
+    auto it = g_loaded.find(loaded_key(node_expression(fmt, *u)));
+    return it == g_loaded.end() ? nullptr : &it->second;
+}
+
+size_t jit_compile_only_user_node(int fmt, int user_id, std::string& err)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    const UserStage* u = user_stage_by_id(user_id);
+    if (!u || !u->multi) { err = "not a user node"; return 0; }
+    const Compiled* c = compile_expr(node_expression(fmt, *u), {user_id}, 4, err);
+    return c ? c->code.size() : 0;
 }
 
 const JitKernel* jit_lookup(int fmt, int pf, int texels, const StageList& sl)

@@ -36,5 +36,10 @@ std::string jit_library();
 int jit_compile_count();
 // [host] compile only: code object size, 0 + err on failure (CPU tests: no device needed)
 size_t jit_compile_only(int fmt, int pf, int texels, const StageList& sl, int waves_per_block, std::string& err);
+// user NODES (a stage file that declares its images, rf_user.h): user_node_kernel<Px, Stage> of rf_user_dev.h, launched with
+// 256 threads per workgroup and a UserNodeArgs block
+bool jit_compile_user_node(int fmt, int user_id, std::string& err);
+const JitKernel* jit_lookup_user_node(int fmt, int user_id);
+size_t jit_compile_only_user_node(int fmt, int user_id, std::string& err);
 
 }  // namespace rf

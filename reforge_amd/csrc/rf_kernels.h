@@ -19,6 +19,7 @@ constexpr int kFmtRGBA8   = 0;
 constexpr int kFmtRGBA32F = 1;
 constexpr int kMaxRadius  = 15;     // conv2d up to 31x31, gaussian radius up to 15
 constexpr int kMaxFusedOps = 8;     // nodes one streaming launch may cover
+constexpr int kMaxUserImages = 4;   // input images, and output images, of a user node (OP_USERN)
 
 inline size_t bytes_per_pixel(int fmt) { return fmt == kFmtRGBA8 ? 4 : 16; }
 
@@ -36,8 +37,12 @@ enum OpKind : int {
     OP_WEIGHTS     = 6,   // conv2d_weights: writes a ConvWeights storage buffer, passes its image through
     OP_PULSE       = 7,   // pulse: a colour grade whose slope follows `phase_rf_time`
     OP_SPLIT       = 9,   // split_luma: one input image, TWO output images (luma_image, chroma_image); own kernel, never fused
-    OP_USER        = 8    // a type that is a file, {shader_path}/{type}.stage.hip (rf_user.h): point op or 3x3 neighbourhood
+    OP_USER        = 8,   // a type that is a file, {shader_path}/{type}.stage.hip (rf_user.h): point op or 3x3 neighbourhood
+    OP_USERN       = 10   // such a file that declares its images (RF_INPUTS / RF_OUTPUTS): up to 4 input and 4 output images, a point
+                          // op with a kernel of its own (rf_user_dev.h), never fused
 };
+// node kinds that run a kernel of their own and never join a fused stream launch
+inline bool own_kernel_kind(int kind) { return kind == OP_MIX || kind == OP_CONV2D || kind == OP_SPLIT || kind == OP_USERN; }
 
 struct Op {
     int   kind = OP_PASSTHROUGH;
@@ -46,7 +51,7 @@ struct Op {
     float slope = 0, offset = 0, saturation = 0;   // grade (slope doubles as the mix factor of OP_MIX)
     float wc = 1, ws = 0;            // sharpen centre / side weight
     const float* dev_weights = nullptr;   // conv2d: device pointer, [K][K]
-    int   user_id = -1;              // OP_USER: the stage (rf_user.h) ...
+    int   user_id = -1;              // OP_USER / OP_USERN: the stage (rf_user.h) ...
     unsigned char user_params[56] = {};   // ... and its Params block, laid out as the device compiler does
     int   slot = 0;                  // inside a fused fork/join launch: 1 = node of the branch feeding input_image0, 2 = of the branch
                                      // feeding input_image1; 0 = before the fork, the join itself, after the join, or a plain chain

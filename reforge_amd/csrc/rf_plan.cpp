@@ -221,6 +221,7 @@ Op NodeParams::to_op(const float* dev_weights) const
             op.slope = pf(values, "mix");
             break;
         case OP_USER:
+        case OP_USERN:
             if (const UserStage* u = user_stage_of(type)) {
                 op.user_id = u->id;
                 op.radius = u->radius;
@@ -473,7 +474,7 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
                 const std::string& n = producers[res][0];
                 const PipelineInfo& pi = infos.at(n);
                 const int kind = plan.nodes.at(n).type->kind;
-                if (!is_simple(pi) || in_place(pi) || kind == OP_MIX || kind == OP_CONV2D || kind == OP_SPLIT) return;
+                if (!is_simple(pi) || in_place(pi) || own_kernel_kind(kind)) return;
                 nodes.insert(nodes.begin(), n);
                 res = pi.input_images[0].first;
                 sources.push_back(res);
@@ -518,7 +519,7 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
                 const std::string& n = producers[res][0];
                 const PipelineInfo& pi = infos.at(n);
                 const int kind = plan.nodes.at(n).type->kind;
-                if (!all_inside || !is_simple(pi) || in_place(pi) || kind == OP_MIX || kind == OP_CONV2D || kind == OP_SPLIT || in_diamond.count(n)) break;
+                if (!all_inside || !is_simple(pi) || in_place(pi) || own_kernel_kind(kind) || in_diamond.count(n)) break;
                 pre.insert(pre.begin(), n);
                 inside.insert(n);
                 res = pi.input_images[0].first;
@@ -529,7 +530,7 @@ static void fuse_chains(const Plan& plan, std::map<std::string, PipelineInfo>& i
                 const std::string& n = consumers[res][0];
                 const PipelineInfo& pi = infos.at(n);
                 const int kind = plan.nodes.at(n).type->kind;
-                if (!is_simple(pi) || in_place(pi) || kind == OP_MIX || kind == OP_CONV2D || kind == OP_SPLIT || in_diamond.count(n) || inside.count(n)) break;
+                if (!is_simple(pi) || in_place(pi) || own_kernel_kind(kind) || in_diamond.count(n) || inside.count(n)) break;
                 post.push_back(n);
                 inside.insert(n);
                 res = pi.output_images[0].first;
@@ -749,7 +750,7 @@ std::vector<Op> ops_of_members(const Plan& plan, const std::vector<std::string>&
     return ops;
 }
 
-static bool point_kind(int kind) { return kind == OP_PASSTHROUGH || kind == OP_GRADE || kind == OP_SPLIT; }    // (device kinds: conv2d_weights is a passthrough, pulse a grade)
+static bool point_kind(int kind) { return kind == OP_PASSTHROUGH || kind == OP_GRADE || kind == OP_SPLIT || kind == OP_USERN; }    // (device kinds: conv2d_weights is a passthrough, pulse a grade)
 
 bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string& err)
 {
@@ -779,7 +780,36 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
                 err = "node '" + unit + "' has no input image (a graph must start at 'input')";
                 return false;
             }
-            if (kind0 == OP_MIX) {
+            const UserStage* unode = kind0 == OP_USERN ? user_stage_of(plan.nodes.at(info.members[0]).type) : nullptr;
+            if (kind0 == OP_USERN && !unode) { err = "node '" + unit + "': its stage file is no longer registered"; return false; }
+            if (unode) {
+                // every declared input image, in declaration order (= binding order)
+                for (size_t i = 0; i < unode->inputs.size(); ++i) {
+                    std::string res;
+                    for (const auto& in : info.input_images)
+                        if (in.second == unode->in_binding[i]) {
+                            if (!res.empty() && res != in.first) { err = "node '" + unit + "' wires two images to " + unode->inputs[i]; return false; }
+                            res = in.first;
+                        }
+                    if (res.empty()) { err = "node '" + unit + "' needs an image wired to " + unode->inputs[i]; return false; }
+                    L.src.push_back(plan.resolve(res));
+                }
+                auto name_of = [&](int binding) {
+                    for (const auto& im : unode->node_type.images)
+                        if (im.second == binding) return std::string(im.first);
+                    return std::string("?");
+                };
+                for (const auto& in : info.input_images)
+                    if (std::find(unode->in_binding.begin(), unode->in_binding.end(), in.second) == unode->in_binding.end()) {
+                        err = "node '" + unit + "': " + name_of(in.second) + " is an output image of " + unode->type_name + ", the graph wires it as an input";
+                        return false;
+                    }
+                for (const auto& o : info.output_images)
+                    if (std::find(unode->out_binding.begin(), unode->out_binding.end(), o.second) == unode->out_binding.end()) {
+                        err = "node '" + unit + "': " + name_of(o.second) + " is an input image of " + unode->type_name + ", the graph wires it as an output";
+                        return false;
+                    }
+            } else if (kind0 == OP_MIX) {
                 std::string a, b;
                 for (const auto& in : info.input_images) {
                     if (in.second == 0) a = in.first;
@@ -797,7 +827,7 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
                 }
                 L.src = {plan.resolve(info.input_images[0].first)};
             }
-            if (kind0 == OP_SPLIT) {
+            if (kind0 == OP_SPLIT || kind0 == OP_USERN) {
                 // several output bindings: an allocated image each (pipeline_graph.rs:205-224), in binding order
                 std::vector<std::pair<int, std::string>> outs;
                 for (const auto& o : info.output_images) outs.push_back({o.second, plan.resolve(o.first)});

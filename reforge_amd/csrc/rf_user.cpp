@@ -3,6 +3,7 @@
 
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <cctype>
 #include <cstdio>
 #include <deque>
@@ -103,17 +104,54 @@ bool parse_user_stage(const std::string& type, const std::string& text, UserStag
     if (out.params.size() > 14 || off > 56) { err = type + ".stage.hip: Params is limited to 56 bytes"; return false; }
     out.params_size = std::max(1, (off + align - 1) / align * align);
     if (t.find("apply") == std::string::npos) { err = type + ".stage.hip: no `RF_STAGE f4 apply(const Params&, ...)`"; return false; }
+    // RF_INPUTS(a, b, ...) / RF_OUTPUTS(c, ...): the image variables of a node with a kernel of its own
+    out.inputs = {"input_image"};                      // passthrough.comp:4-5
+    out.outputs = {"output_image"};
+    for (int side = 0; side < 2; ++side) {
+        const char* kw = side == 0 ? "RF_INPUTS" : "RF_OUTPUTS";
+        size_t at = t.find(kw);
+        if (at == std::string::npos) continue;
+        if (t.find(kw, at + 1) != std::string::npos) { err = type + ".stage.hip: " + kw + " is declared twice"; return false; }
+        size_t op = t.find('(', at), cp = op == std::string::npos ? op : t.find(')', op);
+        if (op == std::string::npos || cp == std::string::npos) { err = type + ".stage.hip: " + kw + "(...) is not closed"; return false; }
+        std::vector<std::string> names;
+        std::stringstream list(t.substr(op + 1, cp - op - 1));
+        std::string item;
+        while (std::getline(list, item, ',')) {
+            std::stringstream is(item);
+            std::string name, extra;
+            if (!(is >> name) || (is >> extra) || !ident_ok(name)) { err = type + ".stage.hip: " + kw + ": `" + item + "` is not an image variable name"; return false; }
+            if (std::find(names.begin(), names.end(), name) != names.end()) { err = type + ".stage.hip: " + kw + " lists `" + name + "` twice"; return false; }
+            names.push_back(name);
+        }
+        if (names.empty() || names.size() > (size_t)kMaxUserImages) { err = type + ".stage.hip: " + kw + " takes 1 to " + std::to_string(kMaxUserImages) + " image names"; return false; }
+        (side == 0 ? out.inputs : out.outputs) = names;
+        out.multi = true;
+    }
+    if (out.multi && out.radius != 0) { err = type + ".stage.hip: a node that declares its images (RF_INPUTS / RF_OUTPUTS) is a point op: RADIUS must be 0"; return false; }
+    for (size_t i = 0; i < out.inputs.size(); ++i) out.in_binding.push_back((int)i);
+    int next = (int)out.inputs.size();
+    for (const auto& o : out.outputs) {
+        auto it = std::find(out.inputs.begin(), out.inputs.end(), o);
+        out.out_binding.push_back(it != out.inputs.end() ? (int)(it - out.inputs.begin()) : next++);     // same name = same binding = in place
+    }
     return true;
 }
 
 std::string UserStage::wrapper() const
 {
-    std::string w = "\nnamespace rfuser { namespace " + ident + " {\nusing rf::f4;\n#define RF_STAGE static __device__ __forceinline__\n#line 1 \"" +
-                    type_name + ".stage.hip\"\n" + text + "\n#undef RF_STAGE\nstruct Stage {\n    typedef Params P;\n    static constexpr int R = RADIUS;\n"
+    std::string w = "\nnamespace rfuser { namespace " + ident + " {\nusing rf::f4;\n#define RF_STAGE static __device__ __forceinline__\n"
+                    "#define RF_INPUTS(...) static_assert(true, \"\")\n#define RF_OUTPUTS(...) static_assert(true, \"\")\n#line 1 \"" +
+                    type_name + ".stage.hip\"\n" + text + "\n#undef RF_STAGE\n#undef RF_INPUTS\n#undef RF_OUTPUTS\nstruct Stage {\n    typedef Params P;\n    static constexpr int R = RADIUS;\n"
                     "    static_assert(R == " + std::to_string(radius) + ", \"RADIUS is not the value the host read\");\n"
                     "    static_assert(sizeof(Params) == " + std::to_string(params_size) + ", \"struct Params is not laid out as the host computed\");\n";
     for (const auto& p : params)
         w += "    static_assert(__builtin_offsetof(Params, " + p.name + ") == " + std::to_string(p.offset) + ", \"struct Params is not laid out as the host computed\");\n";
+    if (multi) {
+        w += "    static constexpr int NI = " + std::to_string(inputs.size()) + ", NO = " + std::to_string(outputs.size()) + ";\n"
+             "    template <class Q> static __device__ __forceinline__ void node(const Q& p, const f4 (&in)[NI], f4 (&out)[NO]) { apply(p, in, out); }\n};\n} }\n";
+        return w;
+    }
     // templates: only the form the file defines is ever instantiated (apply is found by argument-dependent lookup)
     w += "    template <class Q> static __device__ __forceinline__ f4 point(const Q& p, f4 c) { return apply(p, c); }\n"
          "    template <class Q> static __device__ __forceinline__ f4 box(const Q& p, const f4 (&n)[3][3]) { return apply(p, n); }\n};\n} }\n";
@@ -158,11 +196,13 @@ const UserStage* user_stage_for_type(const std::string& type, std::string& err)
     st.id = (int)g_stages.size();
     g_stages.push_back(std::move(st));
     UserStage& s = g_stages.back();
-    static const std::vector<std::pair<const char*, int>> io = {{"input_image", 0}, {"output_image", 1}};   // passthrough.comp:4-5
     s.node_type.name = s.type_name.c_str();
-    s.node_type.kind = OP_USER;
+    s.node_type.kind = s.multi ? OP_USERN : OP_USER;
     s.node_type.fixed_radius = s.radius;
-    s.node_type.images = io;
+    // image variable -> binding (the names point into this entry, which never moves)
+    for (size_t i = 0; i < s.inputs.size(); ++i) s.node_type.images.push_back({s.inputs[i].c_str(), s.in_binding[i]});
+    for (size_t o = 0; o < s.outputs.size(); ++o)
+        if (std::find(s.inputs.begin(), s.inputs.end(), s.outputs[o]) == s.inputs.end()) s.node_type.images.push_back({s.outputs[o].c_str(), s.out_binding[o]});
     for (const auto& p : s.params) s.node_type.params.push_back(ParamDef{p.name.c_str(), p.type});
     g_latest[type] = s.id;
     g_by_type[&s.node_type] = s.id;

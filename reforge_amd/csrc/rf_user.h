@@ -7,6 +7,12 @@
 // becomes a row stage of the stream kernel (rf_stream_dev.h, StUser) and is compiled by hiprtc at rf_graph_create together
 // with whatever it is fused with.  "Reflection" = parsing `struct Params { ... }`: the member names are the config's
 // parameter names, f32 / i32 / bool as in render.rs:169-185, `_rf_time` members honoured (render.rs:190,:212-223).
+//
+// A file may also DECLARE its images -- `RF_INPUTS(base_image, detail_image); RF_OUTPUTS(output_image, mask_image);` -- the
+// counterpart of a .comp file's `uniform image2D` variables, found by name (shader.rs:151-153; a config wires them with
+// `-> node:detail_image`).  Such a type is a NODE with up to 4 input and 4 output images and a kernel of its own
+// (rf_user_dev.h, user_node_kernel; a point op: RADIUS 0), `apply(const Params&, const f4 (&in)[NI], f4 (&out)[NO])`; a name
+// listed on both sides is ONE binding, i.e. written in place (pipeline_graph.rs:228,:402-406).
 #pragma once
 
 #include <string>
@@ -27,6 +33,9 @@ struct UserStage {
     std::string type_name, path, text;
     std::string ident;            // "u_<hash of the text>": the namespace its wrapper lives in
     int radius = 0;
+    bool multi = false;           // declares RF_INPUTS / RF_OUTPUTS: a node with a kernel of its own (OP_USERN), not a row stage
+    std::vector<std::string> inputs, outputs;      // image variable names in declaration order ({input_image} / {output_image} by default)
+    std::vector<int> in_binding, out_binding;      // their bindings: inputs 0.., outputs after them; a name on both sides shares one
     std::vector<UserParam> params;
     int params_size = 1;          // sizeof(Params) as the device compiler lays it out (checked there by static_assert)
     long long mtime_ns = 0;

@@ -1,0 +1,176 @@
+"""GPU: user NODES -- stage files that declare their images (RF_INPUTS / RF_OUTPUTS): several input images, several output
+images, written in place when a name is on both sides.  Checked against an independent restatement in exact rationals
+(tests/golden/exact_eval.py), against numpy where numpy's float32 arithmetic IS the specification (one subtraction), and
+through size-independent properties at 4K.  Ref: src/vulkan/shader.rs:151-153, src/vulkan/pipeline_graph.rs:205-236,:402-406."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import reforge_amd as rf
+from tests import util
+from tests.golden import exact_eval as ex
+from tests.test_gpu_user_stage import from_img, to_img
+from tests.test_user_node import TINT, TINT_GRAPH, UNSHARP, UNSHARP_BOTH
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHADERS = os.path.join(ROOT, "shaders")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = rf.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture
+def stage_dir(tmp_path):
+    shutil.copy(os.path.join(SHADERS, "unsharp_mask.stage.hip"), tmp_path / "unsharp_mask.stage.hip")
+    (tmp_path / "tint.stage.hip").write_text(TINT)
+    old = rf.shader_path()
+    rf.set_shader_path(str(tmp_path))
+    yield tmp_path
+    rf.set_shader_path(old)
+
+
+# ---- the restatements: shaders/unsharp_mask.stage.hip and the `tint` of tests/test_user_node.py in exact arithmetic --------
+def unsharp(img, blurred, amount, threshold):
+    """-> (output_image, mask_image)"""
+    amount, threshold = ex.f32(amount), ex.f32(threshold)
+    out, mask = [], []
+    for ri, rb in zip(img, blurred):
+        o_row, m_row = [], []
+        for t, b in zip(ri, rb):
+            o, m = [], []
+            for c in range(3):
+                d = ex.rn(t[c] - b[c])
+                on = abs(d) >= threshold
+                o.append(ex.fma(amount, d, t[c]) if on else t[c])
+                m.append(abs(d) if on else ex.ZERO)
+            o_row.append(o + [t[3]])
+            m_row.append(m + [ex.ONE])
+        out.append(o_row)
+        mask.append(m_row)
+    return out, mask
+
+
+def tint(img, other, strength):
+    s = ex.f32(strength)
+    return [[[ex.fma(s, ex.rn(b[c] - a[c]), a[c]) for c in range(3)] + [a[3]] for a, b in zip(ra, rb)] for ra, rb in zip(img, other)]
+
+
+def want_unsharp_both(x, fmt):
+    xi = to_img(x)
+    blur = ex.node(ex.gaussian, fmt, [xi], 1.0, 2)
+    o, m = unsharp(ex.load(xi, fmt), ex.load(blur, fmt), 0.8, 0.05)
+    o, m = ex.store(o, fmt), ex.store(m, fmt)
+    gg = ex.node(ex.colour_grade, fmt, [m], 1.5, 0.0, 1.0)
+    return from_img(ex.node(ex.combination, fmt, [o, gg], 0.25), x.dtype)
+
+
+def want_tint(x, fmt):
+    xi = to_img(x)
+    aa = ex.node(ex.gaussian, fmt, [xi], 1.0, 2)
+    cc = ex.node(ex.colour_grade, fmt, [xi], 0.5, 0.1, 0.0)
+    tt = ex.node(tint, fmt, [aa, cc], 0.3)
+    return from_img(ex.node(ex.sharpen, fmt, [tt], 0.5), x.dtype)
+
+
+@pytest.mark.parametrize("fmt,tag", [(util.F32, "f32"), (util.U8, "u8")])
+def test_two_inputs_two_outputs_match_the_restatement(ctx, stage_dir, fmt, tag):
+    W, H = 71, 23                                             # ragged: the last workgroup of a row is partly outside the frame
+    x = util.synthetic(W, H, fmt, 41)
+    want = want_unsharp_both(x, tag)
+    for flags in (0, rf.RF_GRAPH_NO_FUSION, rf.RF_GRAPH_HIPGRAPH):
+        util.assert_same(util.run_hip(ctx, UNSHARP_BOTH, x, flags=flags), want, "unsharp_mask, both outputs read, %s flags=%d" % (tag, flags))
+    # a later frame slot, and layers on side streams: the node's launch takes its images from the slot it runs in
+    util.assert_same(util.run_hip(ctx, UNSHARP_BOTH, x, num_frames=3, slot=2, exec_flags=rf.RF_EXEC_CONCURRENT_LAYERS), want, "slot 2, concurrent layers")
+
+
+@pytest.mark.parametrize("fmt,tag", [(util.F32, "f32"), (util.U8, "u8")])
+def test_an_output_the_graph_leaves_unwired_is_not_stored(ctx, stage_dir, fmt, tag):
+    x = util.synthetic(64, 19, fmt, 43)
+    xi = to_img(x)
+    blur = ex.node(ex.gaussian, tag, [xi], 2.0, 4)
+    o, m = unsharp(ex.load(xi, tag), ex.load(blur, tag), 1.5, 0.02)
+    util.assert_same(util.run_hip(ctx, UNSHARP, x), from_img(ex.store(o, tag), x.dtype), "output_image only")
+    only_mask = UNSHARP.replace("um -> output", "um:mask_image -> output")
+    util.assert_same(util.run_hip(ctx, only_mask, x), from_img(ex.store(m, tag), x.dtype), "mask_image only")
+
+
+@pytest.mark.parametrize("fmt,tag", [(util.F32, "f32"), (util.U8, "u8")])
+def test_a_node_that_writes_its_first_input_in_place(ctx, stage_dir, fmt, tag):
+    x = util.synthetic(67, 21, fmt, 47)
+    want = want_tint(x, tag)
+    assert rf.Plan(rf.Config(TINT_GRAPH)).launch_info()[-2]["outputs"] == rf.Plan(rf.Config(TINT_GRAPH)).launch_info()[-2]["inputs"][:1]
+    for flags in (0, rf.RF_GRAPH_NO_FUSION):
+        util.assert_same(util.run_hip(ctx, TINT_GRAPH, x, flags=flags), want, "tint in place %s flags=%d" % (tag, flags))
+    # the second frame of an in-place graph starts from a fresh upload, not from what frame one left in the image
+    g = rf.Graph(ctx, rf.Config(TINT_GRAPH), 67, 21, fmt)
+    try:
+        for _ in range(2):
+            g.upload_raw(x)
+            g.execute(); g.wait()
+            util.assert_same(g.download_raw(), want, "frame after frame")
+    finally:
+        g.close()
+
+
+def test_parameters_of_a_user_node_are_uniform_members(ctx, stage_dir):
+    """rf_graph_set_param reaches the node's Params block (render.rs:167-210): amount 0 makes the node an identity on input_image"""
+    x = util.synthetic(80, 16, util.F32, 53)
+    g = rf.Graph(ctx, rf.Config(UNSHARP), 80, 16, util.F32)
+    try:
+        g.upload_raw(x)
+        g.execute(); g.wait()
+        sharpened = g.download_raw()
+        assert sharpened.tobytes() != x.tobytes()
+        g.set_param("um", "amount", 0.0)
+        g.execute(); g.wait()
+        assert g.download_raw().tobytes() == x.tobytes()
+        g.set_param("um", "amount", 1.5)
+        g.execute(); g.wait()
+        assert g.download_raw().tobytes() == sharpened.tobytes()
+    finally:
+        g.close()
+
+
+def test_user_node_at_4k_and_the_rate_it_streams_at(ctx, stage_dir):
+    """3840 x 2160 rgba32f.  The mask is ONE float32 subtraction per channel, which numpy computes as the device does; the
+    blurred image comes from the oracle.  A huge threshold turns the node into a copy of input_image (every texel checked).
+    Prints the launch's rate: 2 images read + 2 written, every byte once."""
+    W, H = 3840, 2160
+    x = util.synthetic(W, H, util.F32, 59)
+    blurred = util.run_oracle("input -> blur -> output\nblur: gaussian9 { sigma: 2.0 }", x)
+    d = x - blurred
+    thr = np.float32(0.02)
+    on = np.abs(d) >= thr
+    want_mask = np.where(on, np.abs(d), np.float32(0)).astype(np.float32)
+    want_mask[..., 3] = 1.0
+    got_mask = util.run_hip(ctx, UNSHARP.replace("um -> output", "um:mask_image -> output"), x)
+    util.assert_same(got_mask, want_mask, "mask_image at 4K")
+    ident = util.run_hip(ctx, UNSHARP.replace("threshold: 0.02", "threshold: 1000.0"), x)
+    assert ident.tobytes() == x.tobytes()
+    # where the mask is off the output is the input, bit for bit; where it is on it differs from it (amount 1.5, d != 0)
+    out = util.run_hip(ctx, UNSHARP, x)
+    assert np.array_equal(out[..., :3][~on[..., :3]], x[..., :3][~on[..., :3]]) and np.array_equal(out[..., 3], x[..., 3])
+    assert np.all(out[..., :3][on[..., :3]] != x[..., :3][on[..., :3]])
+    g = rf.Graph(ctx, rf.Config(UNSHARP_BOTH), W, H, util.F32)
+    try:
+        g.fill_synthetic(1)
+        g.execute(); g.wait()
+        k = g.plan.launches().index("um")
+        ms = min(g.time_launch(k, 50) for _ in range(3))
+        gbps = 4 * W * H * 16 / (ms * 1e-3) / 1e9
+        print("\nuser node unsharp_mask 3840x2160 rgba32f: %.4f ms per launch, %.0f GB/s (2 images in, 2 out)" % (ms, gbps))
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "user_node_rate.json"), "w") as f:
+            json.dump({"workload": "unsharp_mask user node, 3840x2160 rgba32f, 2 images in + 2 out", "ms_per_launch": round(ms, 5), "gbps": round(gbps, 1),
+                       "algorithmic_bytes": 4 * W * H * 16}, f)
+        assert gbps > 1500.0                                  # a point op that moved every byte twice, or ran one wave per row, would not
+    finally:
+        g.close()

@@ -1,0 +1,165 @@
+"""CPU: user NODES -- stage files that declare their images (RF_INPUTS / RF_OUTPUTS, rf_user.h): the counterpart of a .comp
+file with several `uniform image2D` variables, each bound by its NAME (src/vulkan/shader.rs:151-153, vkutils.rs:159-183), one
+allocated image per output binding (src/vulkan/pipeline_graph.rs:205-224), a name used on both sides written in place
+(pipeline_graph.rs:228,:402-406).  Parsing, planning, error texts and the gfx950 code object (no device needed);
+tests/test_gpu_user_node.py runs them."""
+import glob
+import os
+import shutil
+import sys
+
+import pytest
+
+import reforge_amd as rf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHADERS = os.path.join(ROOT, "shaders")
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+UNSHARP = """
+input -> blur -> um:blurred_image
+input -> um:input_image
+um -> output
+blur: gaussian9 { sigma: 2.0 }
+um: unsharp_mask { amount: 1.5, threshold: 0.02 }
+"""
+
+# both outputs of the node are read: the mask is graded and mixed back over the sharpened image
+UNSHARP_BOTH = """
+input -> blur -> um:blurred_image
+input -> um:input_image
+um -> mm:input_image0
+um:mask_image -> gg -> mm:input_image1
+mm -> output
+blur: gaussian5 { sigma: 1.0 }
+um: unsharp_mask { amount: 0.8, threshold: 0.05 }
+gg: colour_grade { slope: 1.5, offset: 0.0, saturation: 1.0 }
+mm: combination { mix: 0.25 }
+"""
+
+# `image` is listed on both sides: ONE binding, the node writes its first input in place
+TINT = """struct Params { float strength; };
+static constexpr int RADIUS = 0;
+RF_INPUTS(image, tint_image);
+RF_OUTPUTS(image);
+RF_STAGE void apply(const Params& p, const f4 (&in)[2], f4 (&out)[1])
+{
+    out[0] = make_float4(fmaf(p.strength, in[1].x - in[0].x, in[0].x), fmaf(p.strength, in[1].y - in[0].y, in[0].y),
+                         fmaf(p.strength, in[1].z - in[0].z, in[0].z), in[0].w);
+}
+"""
+TINT_GRAPH = """
+input -> aa -> tt:image -> bb -> output
+input -> cc -> tt:tint_image
+aa: gaussian5 { sigma: 1.0 }
+bb: sharpen { amount: 0.5 }
+cc: colour_grade { slope: 0.5, offset: 0.1, saturation: 0.0 }
+tt: tint { strength: 0.3 }
+"""
+
+
+@pytest.fixture
+def stage_dir(tmp_path):
+    shutil.copy(os.path.join(SHADERS, "unsharp_mask.stage.hip"), tmp_path / "unsharp_mask.stage.hip")
+    (tmp_path / "tint.stage.hip").write_text(TINT)
+    old = rf.shader_path()
+    rf.set_shader_path(str(tmp_path))
+    yield tmp_path
+    rf.set_shader_path(old)
+
+
+def test_images_are_bound_by_the_names_the_file_declares(stage_dir):
+    L = rf.lib()
+    assert [L.rf_registry_binding(b"unsharp_mask", n) for n in (b"input_image", b"blurred_image", b"output_image", b"mask_image", b"nonsense")] == [0, 1, 2, 3, -1]
+    assert [L.rf_registry_binding(b"tint", n) for n in (b"image", b"tint_image")] == [0, 1]
+    p = rf.Plan(rf.Config(UNSHARP))
+    um = p.launch_info()[1]
+    assert um["label"] == "um" and um["radius"] == 0
+    assert um["inputs"] == ["rf:file-input", "blur:output_image"]          # declaration order, whatever order the config wires them in
+    assert um["outputs"] == ["rf:final-output"]                            # mask_image is not wired: not allocated, not stored
+    assert p.needs_jit() == [False, True]
+    flipped = rf.Plan(rf.Config(UNSHARP.replace("input -> blur -> um:blurred_image\ninput -> um:input_image", "input -> um:input_image\ninput -> blur -> um:blurred_image")))
+    assert flipped.launch_info()[1]["inputs"] == um["inputs"]
+
+
+def test_every_output_binding_gets_an_image_and_the_node_is_never_fused(stage_dir):
+    p = rf.Plan(rf.Config(UNSHARP_BOTH))
+    info = {l["label"]: l for l in p.launch_info()}
+    assert set(info) == {"blur", "um", "gg", "mm"}                          # a user node keeps a launch of its own; so do its neighbours here
+    assert len(info["um"]["outputs"]) == 2 and len(set(info["um"]["outputs"])) == 2
+    assert info["mm"]["inputs"][0] == info["um"]["outputs"][0] and info["gg"]["inputs"] == [info["um"]["outputs"][1]]
+    # the over-fetch schedule of a row-strip partition treats it as the point op it is
+    need_src, need_dst, need_input, _ghost = p.halo_schedule(exchange=False)
+    k = [l["label"] for l in p.launch_info()].index("um")
+    assert need_src[k] == need_dst[k] == 0 and need_input == 2              # only the gaussian5 in front of it reads ghost rows
+
+
+def test_a_name_on_both_sides_is_written_in_place(stage_dir):
+    p = rf.Plan(rf.Config(TINT_GRAPH))
+    info = {l["label"]: l for l in p.launch_info()}
+    tt = info["tt"]
+    assert tt["outputs"] == [tt["inputs"][0]] == info["aa"]["outputs"]     # pipeline_graph.rs:402-406: the output IS the input image
+    assert tt["inputs"][1] == info["cc"]["outputs"][0] and tt["inputs"][1] != tt["inputs"][0]
+
+
+def test_wiring_errors_name_the_image_variable(stage_dir):
+    cases = {
+        "input -> um:input_image\num -> output\num: unsharp_mask {}": "needs an image wired to blurred_image",
+        "input -> um:input_image\ninput -> um:blurred_image\ninput -> um:mask_image\num -> output\num: unsharp_mask {}": "mask_image is an output image of unsharp_mask",
+        "input -> um:input_image\ninput -> um:blurred_image\num:blurred_image -> output\num: unsharp_mask {}": "blurred_image is an input image of unsharp_mask",
+        "input -> um:input_image\ninput -> um:nonsense\num -> output\num: unsharp_mask {}": "no binding named: nonsense",
+    }
+    for text, want in cases.items():
+        with pytest.raises(rf.RfError) as e:
+            rf.Plan(rf.Config(text)).halo_schedule()          # what the kernels cannot execute is reported by everything that needs the launch list
+        assert want in str(e.value), (text, str(e.value))
+
+
+def test_bad_declarations_are_refused_with_a_reason(stage_dir):
+    body = "RF_STAGE void apply(const Params& p, const f4 (&in)[1], f4 (&out)[1]) { out[0] = in[0]; }"
+    cases = {
+        "stencil": ("struct Params { };\nstatic constexpr int RADIUS = 1;\nRF_INPUTS(aa_image);\n" + body, "RADIUS must be 0"),
+        "toomany": ("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_INPUTS(a1, a2, a3, a4, a5);\n" + body, "1 to 4 image names"),
+        "twice": ("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_OUTPUTS(o1, o1);\n" + body, "lists `o1` twice"),
+        "notaname": ("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_INPUTS(a b);\n" + body, "is not an image variable name"),
+        "empty": ("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_INPUTS();\n" + body, "1 to 4 image names"),
+    }
+    for name, (text, want) in cases.items():
+        (stage_dir / (name + ".stage.hip")).write_text(text)
+        with pytest.raises(rf.RfError) as e:
+            rf.Plan(rf.Config("input -> nn -> output\nnn: %s {}" % name))
+        assert name + ".stage.hip" in str(e.value) and want in str(e.value), str(e.value)
+
+
+@pytest.mark.skipif(not rf.lib().rf_jit_available(), reason="libhiprtc cannot be loaded")
+def test_user_nodes_compile_for_gfx950_and_move_every_texel_once(stage_dir, tmp_path, monkeypatch):
+    """the code object of user_node_kernel<Px, Stage> (rf_user_dev.h): per texel ONE load per input image and ONE store per
+    output image, no scratch, no LDS, no barrier -- the launch is bound by HBM, (NI + NO) x W x H x bytes-per-pixel"""
+    import isa_obj
+    cache = tmp_path / "cache"
+    monkeypatch.setenv("RF_JIT_CACHE_DIR", str(cache))
+    for text, ni, no in ((UNSHARP_BOTH, 2, 2), (TINT_GRAPH, 2, 1)):
+        for fmt, ld, st in ((rf.RF_FORMAT_RGBA32F, "global_load_dwordx4", "global_store_dwordx4"), (rf.RF_FORMAT_RGBA8, "global_load_dword", "global_store_dword")):
+            before = set(glob.glob(str(cache / "*.hsaco")))
+            assert rf.Plan(rf.Config(text)).jit_compile(fmt) > 2048
+            new = sorted(set(glob.glob(str(cache / "*.hsaco"))) - before)
+            nodes = [f for f in new if open(f[:-6] + ".name").read().startswith("_ZN2rf16user_node_kernel")]
+            assert len(nodes) == 1, new
+            (name, ins), = [(n, i) for n, i in isa_obj.functions(nodes[0]).items() if n.startswith("_ZN2rf16user_node_kernel")]
+            ops = [i.op for i in ins]
+            assert not any(o.startswith(("scratch_", "ds_", "buffer_", "flat_")) for o in ops) and "s_barrier" not in ops, name
+            # loads: one per input image, or narrower pieces where apply() ignores a channel (the compiler drops dead channels)
+            loads = [o for o in ops if o.startswith("global_load")]
+            dwords = sum({"global_load_dword": 1, "global_load_dwordx2": 2, "global_load_dwordx3": 3, "global_load_dwordx4": 4}[o] for o in loads)
+            assert ni <= len(loads) <= 2 * ni and dwords <= ni * (4 if ld.endswith("x4") else 1), (name, loads)
+            assert [o for o in ops if o.startswith("global_store")] == [st] * no, (name, [o for o in ops if o.startswith("global_")])
+
+
+@pytest.mark.skipif(not rf.lib().rf_jit_available(), reason="libhiprtc cannot be loaded")
+def test_a_node_whose_apply_does_not_match_its_declaration_reports_the_compiler_message(stage_dir):
+    (stage_dir / "wrongarity.stage.hip").write_text("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_INPUTS(aa_image, bb_image);\n"
+                                                    "RF_STAGE void apply(const Params& p, const f4 (&in)[1], f4 (&out)[1]) { out[0] = in[0]; }")
+    p = rf.Plan(rf.Config("input -> nn:aa_image\ninput -> gg -> nn:bb_image\nnn -> output\nnn: wrongarity {}\ngg: gaussian5 { sigma: 1.0 }"))
+    with pytest.raises(rf.RfError) as e:
+        p.jit_compile()
+    assert "wrongarity.stage.hip" in str(e.value) or "apply" in str(e.value)
