@@ -187,9 +187,10 @@ rf_status exchange_rows(rf_graph* g, const DeviceImage& img, int r, hipStream_t 
 bool exchange_mode(const rf_graph* g) { return g->ctx->world > 1 && !(g->opt.flags & RF_GRAPH_NO_HALO_XCHG); }
 
 // a user NODE (rf_user.h, a stage file that declares its images): user_node_kernel of rf_user_dev.h, compiled at graph creation
-static hipError_t launch_user_node(int fmt, const Launch& L, FrameSlot& f, const Geom& geo, hipStream_t stream)
+static hipError_t launch_user_node(rf_graph* g, const Launch& L, FrameSlot& f, const Geom& geo, hipStream_t stream)
 {
     if (geo.y1 <= geo.y0 || geo.W <= 0) return hipSuccess;
+    const int fmt = g->opt.format;
     const Op& op = L.ops[0];
     const UserStage* u = user_stage_by_id(op.user_id);
     const JitKernel* k = jit_lookup_user_node(fmt, op.user_id);
@@ -216,6 +217,21 @@ static hipError_t launch_user_node(int fmt, const Launch& L, FrameSlot& f, const
     A.grid_x = (geo.W + 255) / 256;
     static_assert(sizeof(A.params) == sizeof(op.user_params), "Params block");
     std::memcpy(A.params, op.user_params, sizeof(A.params));
+    // storage buffers by block type name (shader.rs:144-147): the one it reads must be wired (build_launches), the one it fills
+    // is filled only when the graph wires it to something
+    if (!u->buf_in.empty()) {
+        auto it = L.in_buffers.empty() ? g->dev_buffers.end() : g->dev_buffers.find(L.in_buffers[0]);
+        if (it == g->dev_buffers.end()) return hipErrorInvalidValue;
+        A.buf_in = it->second;
+    }
+    if (!u->buf_out.empty() && !L.out_buffers.empty()) {
+        auto it = g->dev_buffers.find(L.out_buffers[0]);
+        const JitKernel* fk = jit_lookup_user_fill(op.user_id);
+        if (it == g->dev_buffers.end() || !fk) return hipErrorInvalidValue;
+        A.buf_out = it->second;
+        hipError_t e = jit_launch(*fk, (unsigned)((u->buf_out[0].count + 255) / 256), 256, &A, sizeof(A), stream);
+        if (e != hipSuccess) return e;
+    }
     const int rows = geo.y1 - geo.y0;
     const unsigned gy = (unsigned)(rows > 1024 ? 1024 : rows);
     return jit_launch(*k, (unsigned)A.grid_x * gy, 256, &A, sizeof(A), stream);
@@ -234,7 +250,7 @@ rf_status launch_rows(rf_graph* g, FrameSlot& f, const Launch& L, Geom geo, int 
         for (size_t k = 0; k < L.dsts.size(); ++k) (L.dst_bindings[k] == 1 ? luma : chroma) = f.images.at(L.dsts[k]).view();
         HIP_TRY(launch_split_luma(g->opt.format, f.images.at(L.src[0]).view(), luma, chroma, geo, stream));
     } else if (L.ops.size() == 1 && L.ops[0].kind == OP_USERN) {
-        HIP_TRY(launch_user_node(g->opt.format, L, f, geo, stream));
+        HIP_TRY(launch_user_node(g, L, f, geo, stream));
     } else if (L.ops.size() == 1 && L.ops[0].kind == OP_MIX) {
         HIP_TRY(launch_mix(g->opt.format, f.images.at(L.src[0]).view(), f.images.at(L.src[1]).view(), dst.view(), geo,
                            L.ops[0].slope, stream));
@@ -646,6 +662,12 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
         }
     }
     rebuild_ops(g);
+    for (const auto& L : g->launches) {
+        if (L.ops.size() != 1 || L.ops[0].kind != OP_USERN || L.out_buffers.empty()) continue;
+        const UserStage* u = user_stage_by_id(L.ops[0].user_id);
+        if (u && !u->buf_out.empty()) g->fills_buffers = true;
+    }
+    if (g->fills_buffers && opt.num_frames > 1) HIP_TRY(hipEventCreateWithFlags(&g->buffers_idle, hipEventDisableTiming));
     g->input_image = std::find(plan.images.begin(), plan.images.end(), kFileInput) != plan.images.end() ? kFileInput : "";
     g->output_image = plan.resolve(kFinalOutput);
     if (std::find(plan.images.begin(), plan.images.end(), g->output_image) == plan.images.end())
@@ -744,6 +766,7 @@ extern "C" void rf_graph_destroy(rf_graph* g)
     }
     for (auto& kv : g->dev_weights) (void)hipFree(kv.second);
     for (auto& kv : g->dev_buffers) (void)hipFree(kv.second);
+    if (g->buffers_idle) (void)hipEventDestroy(g->buffers_idle);
     if (g->d_staging) (void)hipFree(g->d_staging);
     delete g;
 }
@@ -965,7 +988,22 @@ static bool use_hipgraph(const rf_graph* g)
     return (g->opt.flags & RF_GRAPH_HIPGRAPH) && !(g->opt.flags & RF_GRAPH_TIMERS) && g->ctx->world == 1;
 }
 
+static rf_status submit_frame_unordered(rf_graph* g, FrameSlot& f);
+
 static rf_status submit_frame(rf_graph* g, FrameSlot& f)
+{
+    // device-filled storage buffers are shared by the frame slots: this frame starts when the previous one (any slot) is done
+    const bool ordered = g->fills_buffers && g->frames.size() > 1 && g->buffers_idle;
+    if (ordered && g->buffers_idle_set) HIP_TRY(hipStreamWaitEvent(f.stream, g->buffers_idle, 0));
+    rf_status st = submit_frame_unordered(g, f);
+    if (st == RF_OK && ordered) {
+        HIP_TRY(hipEventRecord(g->buffers_idle, f.stream));
+        g->buffers_idle_set = true;
+    }
+    return st;
+}
+
+static rf_status submit_frame_unordered(rf_graph* g, FrameSlot& f)
 {
     const bool timers = (g->opt.flags & RF_GRAPH_TIMERS) != 0;
     if (use_hipgraph(g)) {
@@ -1231,7 +1269,7 @@ extern "C" rf_status rf_graph_time_launch(rf_graph* g, int launch, int iters, fl
                 for (size_t k = 0; k < L.dsts.size(); ++k) (L.dst_bindings[k] == 1 ? luma : chroma) = f->images.at(L.dsts[k]).view();
                 return launch_split_luma(g->opt.format, f->images.at(L.src[0]).view(), luma, chroma, geo, f->stream);
             }
-            if (L.ops.size() == 1 && L.ops[0].kind == OP_USERN) return launch_user_node(g->opt.format, L, *f, geo, f->stream);
+            if (L.ops.size() == 1 && L.ops[0].kind == OP_USERN) return launch_user_node(g, L, *f, geo, f->stream);
             if (L.ops.size() == 1 && L.ops[0].kind == OP_MIX)
                 return launch_mix(g->opt.format, f->images.at(L.src[0]).view(), f->images.at(L.src[1]).view(), f->images.at(L.dst).view(), geo,
                                   L.ops[0].slope, f->stream);

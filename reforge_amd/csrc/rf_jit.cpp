@@ -188,6 +188,8 @@ std::string node_expression(int fmt, const UserStage& u)
     return std::string("rf::user_node_kernel<") + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", rfuser::" + u.ident + "::Stage>";
 }
 
+std::string fill_expression(const UserStage& u) { return "rf::user_fill_kernel<rfuser::" + u.ident + "::Stage>"; }
+
 // expr: the kernel instantiation to build; users: the user stages (rf_user.h ids) whose wrappers the translation unit needs
 const Compiled* compile_expr(const std::string& expr, const std::vector<int>& users, int waves_per_block, std::string& err)
 {
@@ -351,7 +353,17 @@ bool jit_compile_user_node(int fmt, int user_id, std::string& err)
     std::lock_guard<std::mutex> lock(g_mu);
     const UserStage* u = user_stage_by_id(user_id);
     if (!u || !u->multi) { err = "not a user node"; return false; }
+    if (!u->buf_out.empty() && !load_expr(fill_expression(*u), {user_id}, 1, 4, err)) return false;      // RF_BUFFER_OUT: its fill kernel
     return load_expr(node_expression(fmt, *u), {user_id}, 1, 4, err);
+}
+
+const JitKernel* jit_lookup_user_fill(int user_id)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    const UserStage* u = user_stage_by_id(user_id);
+    if (!u || u->buf_out.empty()) return nullptr;
+    auto it = g_loaded.find(loaded_key(fill_expression(*u)));
+    return it == g_loaded.end() ? nullptr : &it->second;
 }
 
 const JitKernel* jit_lookup_user_node(int fmt, int user_id)
@@ -368,8 +380,14 @@ size_t jit_compile_only_user_node(int fmt, int user_id, std::string& err)
     std::lock_guard<std::mutex> lock(g_mu);
     const UserStage* u = user_stage_by_id(user_id);
     if (!u || !u->multi) { err = "not a user node"; return 0; }
+    size_t total = 0;
+    if (!u->buf_out.empty()) {
+        const Compiled* f = compile_expr(fill_expression(*u), {user_id}, 4, err);
+        if (!f) return 0;
+        total += f->code.size();
+    }
     const Compiled* c = compile_expr(node_expression(fmt, *u), {user_id}, 4, err);
-    return c ? c->code.size() : 0;
+    return c ? total + c->code.size() : 0;
 }
 
 const JitKernel* jit_lookup(int fmt, int pf, int texels, const StageList& sl)

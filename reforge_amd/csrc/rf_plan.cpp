@@ -855,6 +855,17 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
                 L.in_buffers.push_back(nm);
             }
             for (const auto& b : info.output_ssbos) L.out_buffers.push_back(plan.resolve_buffer(b.first));
+            if (unode && !unode->buf_in.empty() && L.in_buffers.empty()) {
+                err = "node '" + unit + "' needs a storage buffer wired to " + unode->buf_in[0].name;
+                return false;
+            }
+            if (unode) {
+                // a block type name wired on the wrong side (the planner looked it up without regard to direction)
+                for (const auto& b : info.input_ssbos)
+                    if (unode->buf_in.empty() || b.second != unode->buf_in[0].binding) { err = "node '" + unit + "': " + unode->buf_out[0].name + " is the buffer " + unode->type_name + " writes, the graph wires it as an input"; return false; }
+                for (const auto& b : info.output_ssbos)
+                    if (unode->buf_out.empty() || b.second != unode->buf_out[0].binding) { err = "node '" + unit + "': " + unode->buf_in[0].name + " is the buffer " + unode->type_name + " reads, the graph wires it as an output"; return false; }
+            }
             for (const auto& s : L.src) {
                 if (std::find(plan.images.begin(), plan.images.end(), s) == plan.images.end()) {
                     err = "No image found for input " + s;   // pipeline_graph.rs:236

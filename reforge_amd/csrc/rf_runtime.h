@@ -109,4 +109,9 @@ struct rf_graph {
     std::vector<std::string> time_names;   // scratch for rf_graph_node_times
     std::string jit_note;                  // why the graph fell back to catalogue-only fusion ("" if it did not)
     bool exchanged_once = false;           // the first halo exchange of THIS graph is waited for with a deadline
+    // A storage buffer a user node FILLS on the device (RF_BUFFER_OUT) is one per graph, where the reference has one per frame
+    // slot: frames of such a graph on different slots are ordered one behind the other (submit_frame) instead of overlapping
+    bool fills_buffers = false;
+    hipEvent_t buffers_idle = nullptr;
+    bool buffers_idle_set = false;
 };

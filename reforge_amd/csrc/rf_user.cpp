@@ -128,6 +128,32 @@ bool parse_user_stage(const std::string& type, const std::string& text, UserStag
         (side == 0 ? out.inputs : out.outputs) = names;
         out.multi = true;
     }
+    for (int side = 0; side < 2; ++side) {
+        const char* kw = side == 0 ? "RF_BUFFER_IN" : "RF_BUFFER_OUT";
+        size_t at = t.find(kw);
+        if (at == std::string::npos) continue;
+        if (t.find(kw, at + 1) != std::string::npos) { err = type + ".stage.hip: " + kw + " is declared twice (one buffer read, one written)"; return false; }
+        size_t op = t.find('(', at), cp = op == std::string::npos ? op : t.find(')', op);
+        if (op == std::string::npos || cp == std::string::npos) { err = type + ".stage.hip: " + kw + "(...) is not closed"; return false; }
+        const std::string inside = t.substr(op + 1, cp - op - 1);
+        const size_t comma = inside.find(',');
+        std::stringstream ns(inside.substr(0, comma)), cs(comma == std::string::npos ? std::string() : inside.substr(comma + 1));
+        UserStage::Buffer b;
+        std::string extra;
+        long count = 0;
+        if (!(ns >> b.name) || (ns >> extra) || !ident_ok(b.name) || !(cs >> count) || (cs >> extra) || count < 1 || count > 65536) {
+            err = type + ".stage.hip: " + kw + "(BlockTypeName, number of floats 1..65536), got `" + inside + "`";
+            return false;
+        }
+        b.count = (int)count;
+        (side == 0 ? out.buf_in : out.buf_out).push_back(b);
+        out.multi = true;
+    }
+    if (!out.buf_in.empty() && !out.buf_out.empty() && out.buf_in[0].name == out.buf_out[0].name) {
+        err = type + ".stage.hip: " + out.buf_in[0].name + " is both read and written; a node reads one buffer and fills another";
+        return false;
+    }
+    if (!out.buf_out.empty() && t.find("fill") == std::string::npos) { err = type + ".stage.hip: RF_BUFFER_OUT needs `RF_STAGE float fill(const Params&, int i)`"; return false; }
     if (out.multi && out.radius != 0) { err = type + ".stage.hip: a node that declares its images (RF_INPUTS / RF_OUTPUTS) is a point op: RADIUS must be 0"; return false; }
     for (size_t i = 0; i < out.inputs.size(); ++i) out.in_binding.push_back((int)i);
     int next = (int)out.inputs.size();
@@ -135,21 +161,28 @@ bool parse_user_stage(const std::string& type, const std::string& text, UserStag
         auto it = std::find(out.inputs.begin(), out.inputs.end(), o);
         out.out_binding.push_back(it != out.inputs.end() ? (int)(it - out.inputs.begin()) : next++);     // same name = same binding = in place
     }
+    for (auto& b : out.buf_in) b.binding = next++;
+    for (auto& b : out.buf_out) b.binding = next++;
     return true;
 }
 
 std::string UserStage::wrapper() const
 {
     std::string w = "\nnamespace rfuser { namespace " + ident + " {\nusing rf::f4;\n#define RF_STAGE static __device__ __forceinline__\n"
-                    "#define RF_INPUTS(...) static_assert(true, \"\")\n#define RF_OUTPUTS(...) static_assert(true, \"\")\n#line 1 \"" +
-                    type_name + ".stage.hip\"\n" + text + "\n#undef RF_STAGE\n#undef RF_INPUTS\n#undef RF_OUTPUTS\nstruct Stage {\n    typedef Params P;\n    static constexpr int R = RADIUS;\n"
+                    "#define RF_INPUTS(...) static_assert(true, \"\")\n#define RF_OUTPUTS(...) static_assert(true, \"\")\n"
+                    "#define RF_BUFFER_IN(...) static_assert(true, \"\")\n#define RF_BUFFER_OUT(...) static_assert(true, \"\")\n#line 1 \"" +
+                    type_name + ".stage.hip\"\n" + text + "\n#undef RF_STAGE\n#undef RF_INPUTS\n#undef RF_OUTPUTS\n#undef RF_BUFFER_IN\n#undef RF_BUFFER_OUT\nstruct Stage {\n    typedef Params P;\n    static constexpr int R = RADIUS;\n"
                     "    static_assert(R == " + std::to_string(radius) + ", \"RADIUS is not the value the host read\");\n"
                     "    static_assert(sizeof(Params) == " + std::to_string(params_size) + ", \"struct Params is not laid out as the host computed\");\n";
     for (const auto& p : params)
         w += "    static_assert(__builtin_offsetof(Params, " + p.name + ") == " + std::to_string(p.offset) + ", \"struct Params is not laid out as the host computed\");\n";
     if (multi) {
-        w += "    static constexpr int NI = " + std::to_string(inputs.size()) + ", NO = " + std::to_string(outputs.size()) + ";\n"
-             "    template <class Q> static __device__ __forceinline__ void node(const Q& p, const f4 (&in)[NI], f4 (&out)[NO]) { apply(p, in, out); }\n};\n} }\n";
+        w += "    static constexpr int NI = " + std::to_string(inputs.size()) + ", NO = " + std::to_string(outputs.size()) +
+             ", FILL = " + std::to_string(buf_out.empty() ? 0 : buf_out[0].count) + ";\n"
+             "    template <class Q> static __device__ __forceinline__ void node(const Q& p, const f4 (&in)[NI], f4 (&out)[NO], const float* buf) { apply(p, in, out" +
+             std::string(buf_in.empty() ? "" : ", buf") + "); }\n";
+        if (!buf_out.empty()) w += "    template <class Q> static __device__ __forceinline__ float fill_at(const Q& p, int i) { return fill(p, i); }\n";
+        w += "};\n} }\n";
         return w;
     }
     // templates: only the form the file defines is ever instantiated (apply is found by argument-dependent lookup)
@@ -203,6 +236,8 @@ const UserStage* user_stage_for_type(const std::string& type, std::string& err)
     for (size_t i = 0; i < s.inputs.size(); ++i) s.node_type.images.push_back({s.inputs[i].c_str(), s.in_binding[i]});
     for (size_t o = 0; o < s.outputs.size(); ++o)
         if (std::find(s.inputs.begin(), s.inputs.end(), s.outputs[o]) == s.inputs.end()) s.node_type.images.push_back({s.outputs[o].c_str(), s.out_binding[o]});
+    for (const auto* list : {&s.buf_in, &s.buf_out})
+        for (const auto& b : *list) s.node_type.buffers.push_back(NodeType::BufferDef{b.name.c_str(), b.binding, (size_t)b.count * sizeof(float)});
     for (const auto& p : s.params) s.node_type.params.push_back(ParamDef{p.name.c_str(), p.type});
     g_latest[type] = s.id;
     g_by_type[&s.node_type] = s.id;

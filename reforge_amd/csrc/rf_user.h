@@ -12,7 +12,10 @@
 // counterpart of a .comp file's `uniform image2D` variables, found by name (shader.rs:151-153; a config wires them with
 // `-> node:detail_image`).  Such a type is a NODE with up to 4 input and 4 output images and a kernel of its own
 // (rf_user_dev.h, user_node_kernel; a point op: RADIUS 0), `apply(const Params&, const f4 (&in)[NI], f4 (&out)[NO])`; a name
-// listed on both sides is ONE binding, i.e. written in place (pipeline_graph.rs:228,:402-406).
+// listed on both sides is ONE binding, i.e. written in place (pipeline_graph.rs:228,:402-406).  A node may also read one storage
+// buffer and write one, found by the block's TYPE name like the reference's (shader.rs:144-147, vkutils.rs:165-170):
+// `RF_BUFFER_IN(ToneCurve, 256);` adds a `const float*` argument to apply(); `RF_BUFFER_OUT(ToneCurve, 256);` asks for
+// `RF_STAGE float fill(const Params&, int i)`, evaluated for i = 0..255 in front of the node's own kernel, every frame.
 #pragma once
 
 #include <string>
@@ -36,6 +39,10 @@ struct UserStage {
     bool multi = false;           // declares RF_INPUTS / RF_OUTPUTS: a node with a kernel of its own (OP_USERN), not a row stage
     std::vector<std::string> inputs, outputs;      // image variable names in declaration order ({input_image} / {output_image} by default)
     std::vector<int> in_binding, out_binding;      // their bindings: inputs 0.., outputs after them; a name on both sides shares one
+    // storage buffers of a node (RF_BUFFER_IN / RF_BUFFER_OUT: block TYPE name + number of floats; shader.rs:144-147): at most one
+    // read (handed to apply() as `const float*`) and one written (element i = fill(params, i), by a small kernel in front of the node's)
+    struct Buffer { std::string name; int count = 0, binding = -1; };
+    std::vector<Buffer> buf_in, buf_out;
     std::vector<UserParam> params;
     int params_size = 1;          // sizeof(Params) as the device compiler lays it out (checked there by static_assert)
     long long mtime_ns = 0;

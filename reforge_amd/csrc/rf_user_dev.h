@@ -24,11 +24,13 @@ struct UserNodeArgs {
     const char* src[kUserNodeImages];
     char* dst[kUserNodeImages];                   // nullptr: the graph does not wire this output
     unsigned long long src_pitch[kUserNodeImages], dst_pitch[kUserNodeImages];
+    const float* buf_in;                          // RF_BUFFER_IN: the storage buffer the graph wires to it (never null when declared)
+    float* buf_out;                               // RF_BUFFER_OUT: nullptr if the graph does not wire it (then nothing is filled)
     int W, y0, y1;                                // output rows [y0, y1) of the strip
     int grid_x;                                   // workgroups along x (the launch is 1-D: blockIdx.x = by * grid_x + bx)
     unsigned char params[56];                     // the file's `struct Params`, laid out as the device compiler does
 };
-static_assert(sizeof(UserNodeArgs) == 4 * 8 * kUserNodeImages + 16 + 56, "UserNodeArgs is passed as a byte block");
+static_assert(sizeof(UserNodeArgs) == 4 * 8 * kUserNodeImages + 16 + 16 + 56, "UserNodeArgs is passed as a byte block");
 
 #ifdef __HIPCC_RTC__
 template <class Px, class U>
@@ -46,12 +48,24 @@ __global__ __launch_bounds__(256) void user_node_kernel(UserNodeArgs A)
         for (int i = 0; i < U::NI; ++i) in[i] = Px::decode(Px::load(A.src[i] + (long long)y * (long long)A.src_pitch[i], xoff));
 #pragma unroll
         for (int o = 0; o < U::NO; ++o) out[o] = f4_zero();
-        U::node(p, in, out);
+        U::node(p, in, out, A.buf_in);
         // every load of this texel is done before its first store: an output written in place (same binding as an input) is safe
 #pragma unroll
         for (int o = 0; o < U::NO; ++o)
             if (A.dst[o]) Px::store(A.dst[o] + (long long)y * (long long)A.dst_pitch[o], xoff, out[o]);
     }
+}
+
+// RF_BUFFER_OUT(Name, N): element i of the buffer = fill(params, i).  N <= 65536 floats: a handful of workgroups in front of
+// the node's own kernel on the same stream, every frame (the reference's node would rewrite its block every dispatch too).
+template <class U>
+__global__ __launch_bounds__(256) void user_fill_kernel(UserNodeArgs A)
+{
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= U::FILL || !A.buf_out) return;
+    typename U::P p;
+    __builtin_memcpy(&p, A.params, sizeof(p));
+    A.buf_out[i] = U::fill_at(p, i);
 }
 #endif
 

@@ -13,7 +13,7 @@ import reforge_amd as rf
 from tests import util
 from tests.golden import exact_eval as ex
 from tests.test_gpu_user_stage import from_img, to_img
-from tests.test_user_node import TINT, TINT_GRAPH, UNSHARP, UNSHARP_BOTH
+from tests.test_user_node import BOX_GRAPH, BOX_WEIGHTS, CURVE, TINT, TINT_GRAPH, UNSHARP, UNSHARP_BOTH
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,7 +29,9 @@ def ctx():
 
 @pytest.fixture
 def stage_dir(tmp_path):
-    shutil.copy(os.path.join(SHADERS, "unsharp_mask.stage.hip"), tmp_path / "unsharp_mask.stage.hip")
+    for f in ("unsharp_mask.stage.hip", "tone_curve.stage.hip", "apply_curve.stage.hip"):
+        shutil.copy(os.path.join(SHADERS, f), tmp_path / f)
+    (tmp_path / "box_weights.stage.hip").write_text(BOX_WEIGHTS)
     (tmp_path / "tint.stage.hip").write_text(TINT)
     old = rf.shader_path()
     rf.set_shader_path(str(tmp_path))
@@ -61,6 +63,36 @@ def unsharp(img, blurred, amount, threshold):
 def tint(img, other, strength):
     s = ex.f32(strength)
     return [[[ex.fma(s, ex.rn(b[c] - a[c]), a[c]) for c in range(3)] + [a[3]] for a, b in zip(ra, rb)] for ra, rb in zip(img, other)]
+
+
+def tone_curve(gamma, lift):
+    """shaders/tone_curve.stage.hip: the 256 floats fill() produces"""
+    gamma, lift, k = ex.f32(gamma), ex.f32(lift), ex.f32(0.003921569)
+    out = []
+    for i in range(256):
+        t = ex.rn(i * k)
+        c = ex.fma(gamma, ex.rn(ex.rn(t * t) - t), t)
+        out.append(ex.fma(lift, ex.rn(1 - c), c))
+    return out
+
+
+def apply_curve(img, curve, strength):
+    """shaders/apply_curve.stage.hip"""
+    s = ex.f32(strength)
+
+    def through(c):
+        x = ex.rn(ex.clamp01(c) * 255)
+        i = min(int(x), 254)                       # x >= 0: truncation is floor
+        f = ex.rn(x - i)
+        m = ex.fma(f, ex.rn(curve[i + 1] - curve[i]), curve[i])
+        return ex.fma(s, ex.rn(m - c), c)
+    return [[[through(t[c]) for c in range(3)] + [t[3]] for t in row] for row in img]
+
+
+def want_curve(x, fmt, gamma, lift, strength):
+    xi = to_img(x)
+    through = ex.store(ex.load(xi, fmt), fmt)       # tone_curve passes its image through (a load and a store)
+    return from_img(ex.store(apply_curve(ex.load(through, fmt), tone_curve(gamma, lift), strength), fmt), x.dtype)
 
 
 def want_unsharp_both(x, fmt):
@@ -118,6 +150,63 @@ def test_a_node_that_writes_its_first_input_in_place(ctx, stage_dir, fmt, tag):
             util.assert_same(g.download_raw(), want, "frame after frame")
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("text,world", [(UNSHARP_BOTH, 3), (TINT_GRAPH, 2)])
+def test_user_nodes_in_row_strips(stage_dir, ctx, text, world):
+    """over-fetch row strips on one GPU standing in for N ranks: the user node produces the ghost rows its readers
+    want like any point op; the stacked strips equal the whole frame"""
+    W, H = 150, 61
+    for fmt in (util.F32, util.U8):
+        whole = rf.Graph(ctx, rf.Config(text), W, H, fmt)
+        whole.fill_synthetic(0x5EED0004)
+        whole.execute(); whole.wait()
+        want = whole.download_raw()
+        whole.close()
+        strips = []
+        for rank in range(world):
+            c = rf.Context(0, rank, world, None)
+            g = rf.Graph(c, rf.Config(text), W, H, fmt, flags=rf.RF_GRAPH_NO_HALO_XCHG)
+            g.fill_synthetic(0x5EED0004)
+            g.execute(); g.wait()
+            strips.append(g.download_raw())
+            g.close()
+            c.close()
+        util.assert_same(np.concatenate(strips, axis=0), want, "world=%d fmt=%d" % (world, fmt))
+
+
+@pytest.mark.parametrize("fmt,tag", [(util.F32, "f32"), (util.U8, "u8")])
+def test_a_buffer_filled_by_one_user_node_and_read_by_another(ctx, stage_dir, fmt, tag):
+    """storage blocks by TYPE name (shader.rs:144-147): tone_curve fills ToneCurve on the device every frame, apply_curve reads it"""
+    W, H = 77, 19
+    x = util.synthetic(W, H, fmt, 61)
+    want = want_curve(x, tag, 0.6, 0.05, 0.8)
+    for flags in (0, rf.RF_GRAPH_HIPGRAPH):
+        util.assert_same(util.run_hip(ctx, CURVE, x, flags=flags), want, "tone curve %s flags=%d" % (tag, flags))
+    # a parameter of the FILLING node changes what the reading node computes on the next frame; with two frames in flight the
+    # frames of such a graph are ordered one behind the other (the buffer is one per graph), so each slot sees its own frame's curve
+    other = want_curve(x, tag, -0.4, 0.0, 0.8)
+    g = rf.Graph(ctx, rf.Config(CURVE), W, H, fmt, num_frames=2)
+    try:
+        g.upload_raw(x)
+        g.execute(0)
+        g.set_param("tc", "gamma", -0.4)
+        g.set_param("tc", "lift", 0.0)
+        g.execute(1)
+        g.wait(0); g.wait(1)
+        util.assert_same(g.download_raw(0), want, "slot 0: the curve of the parameters it was submitted with")
+        util.assert_same(g.download_raw(1), other, "slot 1: the edited curve")
+    finally:
+        g.close()
+
+
+def test_user_written_weights_feed_the_builtin_conv2d(ctx, stage_dir):
+    """a user node fills a ConvWeights block (961 floats, the leading K x K used); the built-in conv2d reads it through the edge
+    `bw:ConvWeights -> cv:ConvWeights` exactly as it reads conv2d_weights' -- the oracle runs conv2d with the same weights"""
+    for fmt in (util.F32, util.U8):
+        x = util.synthetic(90, 41, fmt, 67)
+        want = util.run_oracle("input -> cv -> output\ncv: conv2d { ksize: 5 }", x, weights={"cv": np.full((5, 5), np.float32(0.04), np.float32)})
+        util.assert_same(util.run_hip(ctx, BOX_GRAPH, x), want, "box weights fmt=%d" % fmt)
 
 
 def test_parameters_of_a_user_node_are_uniform_members(ctx, stage_dir):

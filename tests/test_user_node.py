@@ -58,9 +58,36 @@ tt: tint { strength: 0.3 }
 """
 
 
+# storage buffers by block type name (shader.rs:144-147): tone_curve fills ToneCurve, apply_curve reads it
+CURVE = """
+input -> tc -> ac -> output
+tc:ToneCurve -> ac:ToneCurve
+tc: tone_curve  { gamma: 0.6, lift: 0.05 }
+ac: apply_curve { strength: 0.8 }
+"""
+
+# a user node that generates the K x K weights a built-in conv2d reads through its ConvWeights block
+BOX_WEIGHTS = """struct Params { int ksize; float weight; };
+static constexpr int RADIUS = 0;
+RF_INPUTS(image);
+RF_OUTPUTS(image);
+RF_BUFFER_OUT(ConvWeights, 961);
+RF_STAGE float fill(const Params& p, int i) { return i < p.ksize * p.ksize ? p.weight : 0.0f; }
+RF_STAGE void apply(const Params& p, const f4 (&in)[1], f4 (&out)[1]) { out[0] = in[0]; }
+"""
+BOX_GRAPH = """
+input -> bw:image -> cv -> output
+bw:ConvWeights -> cv:ConvWeights
+bw: box_weights { ksize: 5, weight: 0.04 }
+cv: conv2d { ksize: 5 }
+"""
+
+
 @pytest.fixture
 def stage_dir(tmp_path):
-    shutil.copy(os.path.join(SHADERS, "unsharp_mask.stage.hip"), tmp_path / "unsharp_mask.stage.hip")
+    for f in ("unsharp_mask.stage.hip", "tone_curve.stage.hip", "apply_curve.stage.hip"):
+        shutil.copy(os.path.join(SHADERS, f), tmp_path / f)
+    (tmp_path / "box_weights.stage.hip").write_text(BOX_WEIGHTS)
     (tmp_path / "tint.stage.hip").write_text(TINT)
     old = rf.shader_path()
     rf.set_shader_path(str(tmp_path))
@@ -115,6 +142,31 @@ def test_wiring_errors_name_the_image_variable(stage_dir):
         assert want in str(e.value), (text, str(e.value))
 
 
+def test_storage_buffers_are_found_by_their_block_type_name(stage_dir):
+    L = rf.lib()
+    assert L.rf_registry_buffer_binding(b"tone_curve", b"ToneCurve") == 2 and L.rf_registry_buffer_binding(b"apply_curve", b"ToneCurve") == 2
+    assert L.rf_registry_buffer_binding(b"apply_curve", b"Nonsense") == -1
+    p = rf.Plan(rf.Config(CURVE))
+    assert p.launches() == ["tc", "ac"] and p.layers() == [["tc"], ["ac"]]      # the buffer edge orders the nodes like an image edge
+    assert p.buffers() == {"tc:ToneCurve": 256 * 4}
+    assert p.needs_jit() == [True, True]
+    # the buffer edge alone orders them: no image edge between the writer and the reader
+    q = rf.Plan(rf.Config("input -> tc\ninput -> ac -> output\ntc:ToneCurve -> ac:ToneCurve\ntc -> mm:input_image0\nac -> mm:input_image1\nmm -> output\n"
+                          "tc: tone_curve {}\nac: apply_curve {}\nmm: combination { mix: 0.5 }".replace("input -> ac -> output", "input -> ac")))
+    assert q.layers() == [["tc"], ["ac"], ["mm"]]
+    # a built-in reader of a user-written block: conv2d takes its K x K weights from what box_weights fills
+    b = rf.Plan(rf.Config(BOX_GRAPH))
+    assert b.launches() == ["bw", "cv"] and b.buffers() == {"bw:ConvWeights": 961 * 4}
+    cases = {
+        "input -> ac -> output\nac: apply_curve { strength: 1.0 }": "needs a storage buffer wired to ToneCurve",
+        "input -> tc -> ac -> output\ntc:ToneCurve -> ac:ToneCurve\nac:ToneCurve -> tc:ToneCurve\ntc: tone_curve {}\nac: apply_curve {}": "",
+    }
+    for text, want in cases.items():
+        with pytest.raises(rf.RfError) as e:
+            rf.Plan(rf.Config(text)).halo_schedule()
+        assert want in str(e.value), str(e.value)
+
+
 def test_bad_declarations_are_refused_with_a_reason(stage_dir):
     body = "RF_STAGE void apply(const Params& p, const f4 (&in)[1], f4 (&out)[1]) { out[0] = in[0]; }"
     cases = {
@@ -123,6 +175,11 @@ def test_bad_declarations_are_refused_with_a_reason(stage_dir):
         "twice": ("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_OUTPUTS(o1, o1);\n" + body, "lists `o1` twice"),
         "notaname": ("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_INPUTS(a b);\n" + body, "is not an image variable name"),
         "empty": ("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_INPUTS();\n" + body, "1 to 4 image names"),
+        "nocount": ("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_BUFFER_IN(Curve);\n" + body, "number of floats"),
+        "toobig": ("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_BUFFER_IN(Curve, 70000);\n" + body, "number of floats"),
+        "nofill": ("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_BUFFER_OUT(Curve, 16);\n" + body, "RF_BUFFER_OUT needs"),
+        "both": ("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_BUFFER_IN(Curve, 16);\nRF_BUFFER_OUT(Curve, 16);\nRF_STAGE float fill(const Params& p, int i) { return 0.f; }\n" + body,
+                 "both read and written"),
     }
     for name, (text, want) in cases.items():
         (stage_dir / (name + ".stage.hip")).write_text(text)
@@ -138,12 +195,21 @@ def test_user_nodes_compile_for_gfx950_and_move_every_texel_once(stage_dir, tmp_
     import isa_obj
     cache = tmp_path / "cache"
     monkeypatch.setenv("RF_JIT_CACHE_DIR", str(cache))
-    for text, ni, no in ((UNSHARP_BOTH, 2, 2), (TINT_GRAPH, 2, 1)):
+    for text, ni, no in ((UNSHARP_BOTH, 2, 2), (TINT_GRAPH, 2, 1), (CURVE, 1, 1)):
         for fmt, ld, st in ((rf.RF_FORMAT_RGBA32F, "global_load_dwordx4", "global_store_dwordx4"), (rf.RF_FORMAT_RGBA8, "global_load_dword", "global_store_dword")):
             before = set(glob.glob(str(cache / "*.hsaco")))
             assert rf.Plan(rf.Config(text)).jit_compile(fmt) > 2048
             new = sorted(set(glob.glob(str(cache / "*.hsaco"))) - before)
             nodes = [f for f in new if open(f[:-6] + ".name").read().startswith("_ZN2rf16user_node_kernel")]
+            fills = [f for f in new if open(f[:-6] + ".name").read().startswith("_ZN2rf16user_fill_kernel")]
+            if text is CURVE:
+                # two user nodes; the curve lookups of apply_curve are extra loads from the 1 KiB buffer (L1/L2-resident), not image traffic
+                assert len(nodes) == 2 and len(fills) <= 1, new
+                for f in fills:
+                    (fname, fins), = [(n, i) for n, i in isa_obj.functions(f).items() if n.startswith("_ZN2rf16user_fill_kernel")]
+                    fops = [i.op for i in fins]
+                    assert fops.count("global_store_dword") == 1 and not any(o.startswith(("scratch_", "ds_", "global_load")) for o in fops), fname
+                continue
             assert len(nodes) == 1, new
             (name, ins), = [(n, i) for n, i in isa_obj.functions(nodes[0]).items() if n.startswith("_ZN2rf16user_node_kernel")]
             ops = [i.op for i in ins]
