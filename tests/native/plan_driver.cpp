@@ -1,7 +1,8 @@
 // Test driver (tests/test_sanitizers.py): feeds texts separated by 0x01 through the host-only half
 // of the C ABI -- config parser, planner, launch/halo accessors -- in a build of rf_config.cpp,
-// rf_plan.cpp and rf_abi.cpp with AddressSanitizer + UndefinedBehaviorSanitizer + LeakSanitizer.
+// rf_plan.cpp, rf_user.cpp and rf_abi.cpp with AddressSanitizer + UndefinedBehaviorSanitizer + LeakSanitizer.
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -33,5 +34,30 @@ int main(int argc, char** argv) {
         rf_config_destroy(c);
     }
     std::printf("texts %d plans %d\n", n, okc);
+    // argv[2] / argv[3]: a directory of generated stage files f0000.stage.hip ... and how many -- the "reflection" of user types
+    // (rf_user.cpp: parse_user_stage) on untrusted text, reached the way a config reaches it
+    if (argc > 3) {
+        rf_set_shader_path(argv[2]);
+        int parsed = 0;
+        const int count = std::atoi(argv[3]);
+        for (int k = 0; k < count; ++k) {
+            char name[32];
+            std::snprintf(name, sizeof(name), "f%04d", k);
+            const std::string text = std::string("input -> nn -> output\nnn: ") + name + " { amount: 1.0 }";
+            rf_config* c = nullptr;
+            if (rf_config_parse(text.c_str(), 1, &c) != RF_OK) continue;
+            rf_plan* p = nullptr;
+            if (rf_plan_create(c, 0, &p) == RF_OK) {
+                ++parsed;
+                int ns[8], nd[8], ni, gh;
+                (void)rf_plan_halo_schedule(p, 0, ns, nd, 8, &ni, &gh);
+                (void)rf_registry_binding(name, "input_image");
+                (void)rf_registry_buffer_binding(name, "ToneCurve");
+                rf_plan_destroy(p);
+            }
+            rf_config_destroy(c);
+        }
+        std::printf("stages %d parsed %d\n", count, parsed);
+    }
     return 0;
 }
