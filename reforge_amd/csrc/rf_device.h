@@ -21,6 +21,14 @@ namespace rf {
 typedef float4 f4;
 
 #define RF_DEV __device__ __forceinline__
+// cache-policy modifiers of the stream kernel's row store / LDS-DMA row load (" nt", " sc1", ...): empty in the product.  Measured
+// (scripts/mk_variant.sh trees, profiles/r03_cache_policy_probe.txt) and left empty.
+#ifndef RF_STORE_MOD
+#define RF_STORE_MOD ""
+#endif
+#ifndef RF_LOAD_MOD
+#define RF_LOAD_MOD ""
+#endif
 
 RF_DEV f4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 // four fmaf as two v_pk_fma_f32 (each lane-pair fma is still one single-rounding fmaf): a VALU
@@ -122,7 +130,7 @@ struct PxF32 {
         // two wait states after it issues, and hipcc's hazard recogniser, which would keep a VALU write to them away, cannot
         // see into an asm statement (scripts/fuzz_graphs.py seeds 7054 / 7063 / 7113: a run-time compiled fork/join kernel
         // scheduled such a write right behind the store -- a few thousand wrong texels per frame, different ones each run).
-        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(xoff), "v"(d), "s"(row) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2" RF_STORE_MOD "\n\ts_nop 1" ::"v"(xoff), "v"(d), "s"(row) : "memory");
     }
     RF_DEV static f4 requant(f4 v) { return v; }
 };
@@ -155,7 +163,7 @@ struct PxU8 {
     RF_DEV static void store_row(char* row, unsigned xoff, f4 v)       // wave-uniform row address: see PxF32::store_row
     {
         const unsigned d = pack(v);
-        asm volatile("global_store_dword %0, %1, %2" ::"v"(xoff), "v"(d), "s"(row) : "memory");
+        asm volatile("global_store_dword %0, %1, %2" RF_STORE_MOD ::"v"(xoff), "v"(d), "s"(row) : "memory");
     }
     // what a store followed by a load of the next node does to a value: decode(pack(v)) without
     // the trip through the integer byte (the code is the same number either way)

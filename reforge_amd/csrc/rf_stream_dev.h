@@ -108,10 +108,10 @@ template <class Px, int PF, int T> struct Source {
             const unsigned dst = dst0 + (unsigned)(j * 64 * Px::BPP);
             unsigned keep;
             if constexpr (Px::BPP == 16)
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" RF_LOAD_MOD "\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(xoff[j]), "s"(dst), "s"(g) : "memory");
             else
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3" RF_LOAD_MOD "\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(xoff[j]), "s"(dst), "s"(g) : "memory");
         }
     }

@@ -38,16 +38,16 @@ def test_no_jit_flag_and_env_plan_with_the_catalogue_alone(monkeypatch):
 
 
 def test_the_embedded_device_source_is_the_checked_in_headers():
-    """build/rf_jit_source.inc is generated from rf_device.h + rf_stream_dev.h by the Makefile: the text the run-time
+    """build/rf_jit_source.inc is generated from rf_device.h + rf_stream_dev.h + rf_user_dev.h by the Makefile: the text the run-time
     compiler sees must be the text the ahead-of-time kernels were built from."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "reforge_amd", "csrc")
     inc = open(os.path.join(csrc, "build", "rf_jit_source.inc")).read()
-    for f in ("rf_device.h", "rf_stream_dev.h"):
+    for f in ("rf_device.h", "rf_stream_dev.h", "rf_user_dev.h"):
         body = [l for l in open(os.path.join(csrc, f)).read().split("\n") if l.strip() and not l.startswith("#include \"") and l != "#pragma once"]
         for l in body[:: max(1, len(body) // 50)]:
             assert l in inc, (f, l)
-    assert os.path.getmtime(os.path.join(csrc, "build", "rf_jit_source.inc")) >= max(os.path.getmtime(os.path.join(csrc, f)) for f in ("rf_device.h", "rf_stream_dev.h"))
+    assert os.path.getmtime(os.path.join(csrc, "build", "rf_jit_source.inc")) >= max(os.path.getmtime(os.path.join(csrc, f)) for f in ("rf_device.h", "rf_stream_dev.h", "rf_user_dev.h"))
 
 
 def test_admission_rule_keeps_oversized_chains_split():
