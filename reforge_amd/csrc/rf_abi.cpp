@@ -399,7 +399,9 @@ extern "C" rf_status rf_plan_jit_compile_texels(const rf_plan* p, int format, in
         }
         if ((ops.size() < 2 && !(ops.size() == 1 && ops[0].kind == OP_USER)) || !ops_to_stages(ops.data(), (int)ops.size(), sl) || stream_in_catalogue(sl)) continue;
         if (texels_per_lane == 2 && (sl.sum_rh() > 7 || sl.max_rv() > 4 || sl.pair())) continue;      // no two-texel variant of such a list (choose_texels)
-        const size_t n = jit_compile_only(format, 4, texels_per_lane, sl, 4, err);
+        // the variant rf_graph_create would build: rgba32f with non-temporal stores where no launch reads the result (stream_prepare)
+        const int kc = stream_kernel_code(format, sl, l.result_only);
+        const size_t n = jit_compile_only(kc, 4, texels_per_lane, sl, 4, err);
         if (n == 0) return fail(RF_ERR_UNSUPPORTED, err);
         total += n;
     }

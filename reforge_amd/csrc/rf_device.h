@@ -135,6 +135,20 @@ struct PxF32 {
     RF_DEV static f4 requant(f4 v) { return v; }
 };
 
+// rgba32f with NON-TEMPORAL row stores: the kernel variant of a launch whose output no launch of the frame reads (the graph's
+// result).  Measured (profiles/r03_cache_policy_probe.txt, r03_store_nt_probe.txt: three interleaved rounds on one box): the fused
+// 4K chain -1.9 %, gaussian9 at 8K -2..-4 %, the 16384^2 5-stage chain -0..-2 % -- the written rows no longer displace input rows
+// neighbouring workgroups still want from L2.  NOT for an image the next launch reads (the unfused 4K chain loses 21 %: its
+// intermediate images live in the caches), not for rgba8 (+2..4 %), not on the row LOADS (halo rows are re-used: +15 %).
+struct PxF32NT : PxF32 {
+    RF_DEV static void store_row(char* row, unsigned xoff, f4 v)
+    {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f d = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(xoff), "v"(d), "s"(row) : "memory");      // the s_nop: see PxF32::store_row
+    }
+};
+
 struct PxU8 {
     typedef unsigned Raw;
     static constexpr int BPP = 4;

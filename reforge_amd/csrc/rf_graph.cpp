@@ -128,6 +128,7 @@ Geom launch_geom(const rf_graph* g, const Launch& L)
     geo.row_hi = std::min(Hs - 1 + L.need_src, H - 1 - g->strip_y0);
     geo.y0 = std::max(-L.need_dst, -g->strip_y0);
     geo.y1 = std::min(Hs + L.need_dst, H - g->strip_y0);
+    geo.nt_store = L.result_only && g->nt_stores;
     return geo;
 }
 
@@ -533,6 +534,7 @@ static void read_tuning(rf_graph* g)
     if (const char* e = std::getenv("RF_SYNC_LAUNCHES")) g->sync_launches = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_CONCURRENT_LAYERS")) g->concurrent_layers = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_FORCE_SPLIT")) g->force_split = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RF_NT_STORE")) g->nt_stores = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_NO_ALTERNATE")) g->tune.walk = std::atoi(e) ? 2 : 1;
     // Exchange mode shares ONE comm stream and one src_ready/halo_ready event pair per slot: two
     // stencils of a layer reading the same source would each re-exchange its ghost rows while the
@@ -568,7 +570,7 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
                 continue;
             }
             if (user_only ? !has_user : (ops.size() < 2 && !has_user)) continue;      // single built-in nodes are in the catalogue
-            if (!stream_prepare(opt.format, ops.data(), (int)ops.size(), opt.width, Hs1 - Hs0, g->tune, jerr)) return false;
+            if (!stream_prepare(opt.format, ops.data(), (int)ops.size(), opt.width, Hs1 - Hs0, g->tune, d.result_only && g->nt_stores, jerr)) return false;
         }
         return true;
     };

@@ -90,7 +90,7 @@ int g_compiled = 0;
 
 std::string name_expression(int fmt, int pf, int texels, const StageList& sl)
 {
-    return std::string("rf::stream_kernel<") + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", " + std::to_string(pf) + ", " +
+    return std::string("rf::stream_kernel<") + (fmt == kFmtRGBA8 ? "rf::PxU8" : (fmt == kPxF32Stream ? "rf::PxF32NT" : "rf::PxF32")) + ", " + std::to_string(pf) + ", " +
            std::to_string(texels) + ", " + sl.type_list() + ">";
 }
 

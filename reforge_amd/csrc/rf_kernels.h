@@ -17,6 +17,7 @@ namespace rf {
 
 constexpr int kFmtRGBA8   = 0;
 constexpr int kFmtRGBA32F = 1;
+constexpr int kPxF32Stream = 2;     // kernel selection only: rgba32f whose row stores carry the non-temporal hint (PxF32NT, rf_device.h)
 constexpr int kMaxRadius  = 15;     // conv2d up to 31x31, gaussian radius up to 15
 constexpr int kMaxFusedOps = 8;     // nodes one streaming launch may cover
 constexpr int kMaxUserImages = 4;   // input images, and output images, of a user node (OP_USERN)
@@ -70,6 +71,8 @@ struct Geom {
     int row_lo = 0;     // lowest readable row (clamp-to-edge bound), may be negative (ghost rows)
     int row_hi = 0;     // highest readable row, inclusive
     int y0 = 0, y1 = 0; // output rows [y0, y1)
+    bool nt_store = false;  // the image written is read by no launch of the frame (the graph's result): rgba32f stream kernels store it
+                            // with the non-temporal hint, so that it does not displace input rows other workgroups still want from L2
     int yb0 = 0, yb1 = 0;   // a SECOND range of output rows in the same launch (stream launches only; empty by default): the two
                             // boundary slivers of a row strip in exchange mode run as ONE launch (run_launch, rf_graph.cpp)
 };
@@ -100,13 +103,16 @@ struct StageList {
 constexpr size_t kMaxParamBytes = 2048;
 bool ops_to_stages(const Op* ops, int n, StageList& out);
 bool stream_in_catalogue(const StageList& sl);
+// which stream kernel a launch of this stage list takes: the format, or kPxF32Stream (rgba32f, non-temporal row stores) when
+// the launch's result is read by no launch (`nt_store`) and the pipeline is bound by the memory path, not by issue (rf_stream.hip)
+int stream_kernel_code(int fmt, const StageList& sl, bool nt_store);
 bool stream_jit_admissible(const StageList& sl);
 
 // true if `ops[0..n)` can run as ONE streaming launch (a fused pipeline): the catalogue holds the kernel, or
 // (allow_jit) it can be compiled when the graph is created
 bool stream_supported(const Op* ops, int n, bool allow_jit);
 // rf_graph_create: make the kernel of a fused launch available (compiles it if the catalogue lacks it); false + err if it cannot
-bool stream_prepare(int fmt, const Op* ops, int n, int W, int rows, const StreamTuning& tune, std::string& err);
+bool stream_prepare(int fmt, const Op* ops, int n, int W, int rows, const StreamTuning& tune, bool nt_store, std::string& err);
 // horizontal / vertical halo a fused pipeline reads beyond its output
 int  ops_radius(const Op* ops, int n);
 

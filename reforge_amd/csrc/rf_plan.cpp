@@ -899,6 +899,12 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
             if (touches) out[a].serial = out[b].serial = true;
         }
     }
+    for (auto& L : out) {
+        L.result_only = true;
+        for (const auto& other : out)
+            for (const auto& sname : other.src)
+                for (const auto& d : L.dsts) L.result_only = L.result_only && sname != d;
+    }
     for (size_t a = 0; a < out.size(); ++a)      // the whole layer, not only the pair
         for (size_t b = 0; b < out.size(); ++b)
             if (out[a].layer == out[b].layer && out[b].serial) out[a].serial = true;

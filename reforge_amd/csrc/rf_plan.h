@@ -106,6 +106,8 @@ struct LaunchDesc {
     int radius = 0;                 // vertical halo read beyond the rows written
     int need_src = 0;               // ghost rows of src the launch reads (multi-rank)
     int need_dst = 0;               // ghost rows of dst the launch must also produce (over-fetch mode)
+    bool result_only = false;       // no launch of the frame reads an image this one writes (the graph's result): rgba32f stream
+                                    // kernels store it with the non-temporal hint (Geom::nt_store)
     bool serial = false;            // its layer holds a launch that writes an image another launch of the layer touches: the
                                     // layer runs in plan (name) order on one stream instead of concurrently
 };

@@ -101,6 +101,7 @@ struct rf_graph {
     std::string output_image;          // allocated name rf:final-output resolves to
     int need_input = 0;                // ghost rows of the input the frame reads
     rf::StreamTuning tune;
+    bool nt_stores = true;             // RF_NT_STORE=0: never pick the non-temporal-store kernels (A/B measurements)
     bool force_split = false;          // RF_FORCE_SPLIT=1: interior/boundary split without an exchange (tests)
     bool sync_launches = false;        // RF_SYNC_LAUNCHES=1: host-synchronise after every launch (debugging aid)
     bool concurrent_layers = false;    // RF_CONCURRENT_LAYERS=1: the launches of a hazard-free layer run on side streams (slower, measured)

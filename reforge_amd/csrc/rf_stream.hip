@@ -404,7 +404,7 @@ static hipError_t launch_aot(Image src, Image dst, const Geom& g, const StreamTu
 
 typedef hipError_t (*AotFn)(Image, Image, const Geom&, const StreamTuning&, hipStream_t, const unsigned char*, size_t, int);
 struct AotEntry {
-    AotFn fn[2][3] = {};      // [format][texels per lane]
+    AotFn fn[3][3] = {};      // [format, or kPxF32Stream = rgba32f with non-temporal stores][texels per lane]
 };
 
 template <class S> struct StageKey;
@@ -445,9 +445,11 @@ template <int PF, class... S> static void add_to_catalogue(TL<S...>)
     AotEntry& e = catalogue()[key];
     e.fn[kFmtRGBA8][1] = &launch_aot<PxU8, PF, 1, S...>;
     e.fn[kFmtRGBA32F][1] = &launch_aot<PxF32, PF, 1, S...>;
+    e.fn[kPxF32Stream][1] = &launch_aot<PxF32NT, PF, 1, S...>;
     // two texels per lane: only where the doubled state still fits 256 VGPRs
     if constexpr (SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4 && MaxSlots<S...>::value == 1) e.fn[kFmtRGBA8][2] = &launch_aot<PxU8, (PF > 4 ? 4 : PF), 2, S...>;
     if constexpr (SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4 && MaxSlots<S...>::value == 1) e.fn[kFmtRGBA32F][2] = &launch_aot<PxF32, (PF > RF_PF_T2 ? RF_PF_T2 : (PF == PF_DEFAULT ? RF_PF_T2 : PF)), 2, S...>;
+    if constexpr (SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4 && MaxSlots<S...>::value == 1) e.fn[kPxF32Stream][2] = &launch_aot<PxF32NT, (PF > RF_PF_T2 ? RF_PF_T2 : (PF == PF_DEFAULT ? RF_PF_T2 : PF)), 2, S...>;
 }
 
 // The ahead-of-time catalogue: every node alone (gaussian radius 0..15), every ordered pair of
@@ -546,6 +548,14 @@ constexpr long kTopDownMinPixels = 48L << 20;       // light rgba32f pipelines w
 constexpr long kTwoTexelLightMinPixels = 200L << 20;   // ... and take two texels per lane from here up
 constexpr long kTwoTexelMinPixels = 24L << 20;   // two texels per lane from 8K frames up (5-stage chain at 4K: 64.4 us with one, 68.3 with two)
 
+// Non-temporal row stores (PxF32NT, rf_device.h) for the result of a frame: measured on MI355X, interleaved on one box
+// (profiles/r03_store_nt_probe.txt, r03_nt_store_final_ab.txt): gaussian9 at 8K -1.5..-4 %, the fused 4K chain -1.5..-2 %, the 8K
+// chain -0.5 %; the issue-bound 5-stage chain at 16384^2 +0.4 % (two texels per lane) / +2.5 % (one) -- so not for heavy pipelines.
+int stream_kernel_code(int fmt, const StageList& sl, bool nt_store)
+{
+    return (fmt == kFmtRGBA32F && nt_store && sl.taps() < kHeavyTaps) ? kPxF32Stream : fmt;
+}
+
 static int choose_texels(int fmt, const StageList& sl, Image src, Image dst, const Geom& g, StreamTuning& t)
 {
     const long px = (long)g.W * (long)((g.y1 - g.y0) + (g.yb1 > g.yb0 ? g.yb1 - g.yb0 : 0));
@@ -588,15 +598,16 @@ static hipError_t launch_stages(int fmt, const StageList& sl, const Op* ops, int
     const size_t psize = param_bytes(sl, ops, n, pbytes, sizeof(pbytes));
     if (psize == 0) return hipErrorInvalidValue;
     const int halo = sl.sum_rv();
+    const int kc = stream_kernel_code(fmt, sl, g.nt_store);      // which kernel: the format, or rgba32f with non-temporal stores
     auto it = built_catalogue().find(sl.key());
     if (it != built_catalogue().end()) {
-        AotFn fn = it->second.fn[fmt][texels];
-        if (!fn) fn = it->second.fn[fmt][1];
+        AotFn fn = it->second.fn[kc][texels];
+        if (!fn) fn = it->second.fn[kc][1];
         return fn(src, dst, g, t, stream, pbytes, psize, halo);
     }
     // compiled at graph creation (rf_graph_create -> stream_prepare); never compiled here, on the frame path
-    const JitKernel* k = jit_lookup(fmt, PF_DEFAULT, texels, sl);
-    if (!k && texels != 1) k = jit_lookup(fmt, PF_DEFAULT, 1, sl);
+    const JitKernel* k = jit_lookup(kc, PF_DEFAULT, texels, sl);
+    if (!k && texels != 1) k = jit_lookup(kc, PF_DEFAULT, 1, sl);
     if (!k) return hipErrorInvalidDeviceFunction;
     LaunchShape sh;
     const int bpp = fmt == kFmtRGBA8 ? 4 : 16;
@@ -608,17 +619,19 @@ static hipError_t launch_stages(int fmt, const StageList& sl, const Op* ops, int
 }
 
 // rf_graph_create: make sure the kernel of this fused launch exists (compile it if the catalogue lacks it)
-bool stream_prepare(int fmt, const Op* ops, int n, int W, int rows, const StreamTuning& tune, std::string& err)
+bool stream_prepare(int fmt, const Op* ops, int n, int W, int rows, const StreamTuning& tune, bool nt_store, std::string& err)
 {
     StageList sl;
     if (!ops_to_stages(ops, n, sl)) { err = "not a streaming launch"; return false; }
     if (stream_in_catalogue(sl)) return true;
+    const int real_fmt = fmt;
+    fmt = stream_kernel_code(fmt, sl, nt_store);      // the variant this launch will ask for (launch_stages)
     if (!jit_compile(fmt, PF_DEFAULT, 1, sl, kWavesPerBlock, err)) return false;
     if (const JitKernel* k = jit_lookup(fmt, PF_DEFAULT, 1, sl)) {
         // the admission rule is an estimate; a kernel that spills after all is not worth its launch
         if (k->scratch_bytes > 0) { err = "the compiled chain " + sl.key() + "spills " + std::to_string(k->scratch_bytes) + " bytes per lane"; return false; }
     }
-    if (stream_texels_for(fmt, ops, n, W, rows, tune) == 2) {
+    if (stream_texels_for(real_fmt, ops, n, W, rows, tune) == 2) {
         std::string e2;
         // optional variant: the one-texel kernel serves if it fails to compile -- or if it spills (its state is twice the
         // one-texel kernel's under the same 256-VGPR bound), which the ahead-of-time kernels are checked for by the ISA test

@@ -70,6 +70,7 @@ def steady_loops(body, pf=4, t=1):
 def test_stream_kernels_keep_the_counted_wait_contract(stream_asm):
     ks = kernels(stream_asm)
     assert len(ks) >= 40                      # every node type / fused pattern / format / prefetch depth
+    assert sum("7PxF32NT" in n for n in ks) >= 20
     checked = 0
     for name, body in ks.items():
         text = "\n".join(body)
@@ -88,6 +89,14 @@ def test_stream_kernels_keep_the_counted_wait_contract(stream_asm):
         for i, ins in enumerate(instrs):
             if ins.startswith("global_store_dwordx4"):
                 assert instrs[i + 1].split()[:2] == ["s_nop", "1"], (name, instrs[i:i + 3])
+        # the non-temporal hint is carried by every row store of the PxF32NT variants (launches whose result no launch reads)
+        # and by nothing else -- not by rgba8 stores, not by any row load (halo rows are re-used through L2)
+        stores = [x for x in instrs if x.startswith("global_store_dword")]
+        if "7PxF32NT" in name:
+            assert stores and all(x.split()[-1] == "nt" for x in stores), (name, stores[:2])
+        else:
+            assert not any(" nt" in x for x in stores), (name, stores[:2])
+        assert not any(" nt" in x for x in instrs if x.startswith("global_load_lds")), name
         pf, t = prefetch_depth(name)
         for loop in steady_loops(body, pf, t):
             ops = [x.split()[0] for x in loop]
