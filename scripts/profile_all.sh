@@ -42,4 +42,5 @@ for wl in $WORKLOADS; do
   python3 scripts/summarize_profiles.py "${TAG}_${wl}" "$wl" "$kt" "$fd" "$wd"
   mkdir -p "$ROOT/gpurun_out/profiles_new"
   cp profiles/${TAG}_${wl}_* profiles/traffic.json "$ROOT/gpurun_out/profiles_new/"
+  rm -rf "$OUT/${wl}_kt" "$OUT/${wl}_FETCH_SIZE" "$OUT/${wl}_WRITE_SIZE"      # raw traces: gpurun copies back at most 64 MiB
 done

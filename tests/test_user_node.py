@@ -129,6 +129,36 @@ def test_a_name_on_both_sides_is_written_in_place(stage_dir):
     assert tt["inputs"][1] == info["cc"]["outputs"][0] and tt["inputs"][1] != tt["inputs"][0]
 
 
+def test_plans_of_user_node_graphs_match_the_restatement(stage_dir):
+    """the planner's layers / aliases / allocated images / buffers for graphs that hold user nodes against the restatement of
+    order_by_execution and reusable_image_remapping (oracle/graph.py), which is handed the tables "reflection" of the files yields"""
+    from oracle import graph as og
+    L = rf.lib()
+    tables = {
+        "unsharp_mask": {"images": {n: L.rf_registry_binding(b"unsharp_mask", n.encode()) for n in ("input_image", "blurred_image", "output_image", "mask_image")},
+                         "params": {"amount": "f32", "threshold": "f32"}},
+        "tint": {"images": {n: L.rf_registry_binding(b"tint", n.encode()) for n in ("image", "tint_image")}, "params": {"strength": "f32"}},
+        "tone_curve": {"images": {"input_image": 0, "output_image": 1}, "params": {"gamma": "f32", "lift": "f32"},
+                       "buffers": {"ToneCurve": (L.rf_registry_buffer_binding(b"tone_curve", b"ToneCurve"), 256 * 4)}},
+        "apply_curve": {"images": {"input_image": 0, "output_image": 1}, "params": {"strength": "f32"},
+                        "buffers": {"ToneCurve": (L.rf_registry_buffer_binding(b"apply_curve", b"ToneCurve"), 256 * 4)}},
+    }
+    added = [k for k in tables if k not in og.NODE_TYPES]
+    og.NODE_TYPES.update(tables)
+    try:
+        for text in (UNSHARP, UNSHARP_BOTH, TINT_GRAPH, CURVE,
+                     "input -> um:input_image\ninput -> aa -> bb -> um:blurred_image\num:mask_image -> cc -> output\num: unsharp_mask {}\naa: gaussian5 {}\nbb: sharpen {}\ncc: sharpen {}"):
+            p = rf.Plan(rf.Config(text), rf.RF_GRAPH_NO_FUSION)
+            infos = og.synthesize(og.parse_config(text))
+            layers = og.order_by_execution(infos)
+            assert p.layers() == layers, text
+            assert p.aliases() == og.reusable_image_remapping(layers, infos), text
+            assert p.launches() == [n for l in layers for n in l]
+    finally:
+        for k in added:
+            del og.NODE_TYPES[k]
+
+
 def test_wiring_errors_name_the_image_variable(stage_dir):
     cases = {
         "input -> um:input_image\num -> output\num: unsharp_mask {}": "needs an image wired to blurred_image",
