@@ -20,6 +20,7 @@ import re
 import numpy as np
 
 from . import pixel
+from . import user_stage
 
 FILE_INPUT = "rf:file-input"      # pipeline_graph.rs:22
 FINAL_OUTPUT = "rf:final-output"  # pipeline_graph.rs:23
@@ -226,6 +227,14 @@ NODE_TYPES["split_luma"] = {"images": {"input_image": 0, "luma_image": 1, "chrom
 NODE_TYPES["colour-grade"] = NODE_TYPES["colour_grade"]
 NODE_TYPES["colour_grade_inplace"] = {"images": {"image": 0}, "params": NODE_TYPES["colour_grade"]["params"]}
 NODE_TYPES["grade"] = NODE_TYPES["colour_grade"]
+
+
+def register_user_type(name, path):
+    """a filter type that is a file, {shader_path}/{name}.stage.hip: reflected and compiled for the host by
+    oracle/user_stage.py.  Returns the UserType.  Test infrastructure: lets generated graphs hold user types."""
+    ut = user_stage.UserType(name, path)
+    NODE_TYPES[name] = ut.node_type()
+    return ut
 
 
 def _parse_param(s, ty):
@@ -449,6 +458,27 @@ class GraphOracle:
         if not info.input_images:
             raise ConfigError("node %s has no input image" % info.name)
         t, p = info.type, info.params
+        if "user" in NODE_TYPES.get(t, {}):
+            # a type that is a FILE (register_user_type): the file's own code, compiled for the host (oracle/user_stage.py)
+            ut = NODE_TYPES[t]["user"]
+            in_by = {b: r for r, b in info.input_images}
+            out_by = {b: r for r, b in info.output_images}
+            for i, nm in enumerate(ut.inputs):
+                if i not in in_by:
+                    raise ConfigError("node %s needs an image wired to %s" % (info.name, nm))
+            srcs = [img(in_by[i]) for i in range(len(ut.inputs))]
+            dsts = [img(out_by[b]) if b in out_by else None for b in ut.out_binding]
+            if not ut.multi and srcs[0] is dsts[0] and ut.radius > 0:
+                raise ConfigError("in-place execution of a stencil node")
+            buf_in = buf_out = None
+            if ut.buf_in:
+                if not info.input_ssbos:
+                    raise ConfigError("node %s needs a storage buffer wired to %s" % (info.name, ut.buf_in[0]))
+                buf_in = self.ssbos[_remap(info.input_ssbos[0][0], self.ssbo_remap)]
+            if ut.buf_out and info.output_ssbos:
+                buf_out = self.ssbos[_remap(info.output_ssbos[0][0], self.ssbo_remap)]
+            user_stage.run(ut, p, srcs, dsts, buf_in, buf_out)
+            return
         if t == "split_luma":
             by_binding = {b: r for r, b in info.output_images}
             pixel.split_luma(img(info.input_images[0][0]), img(by_binding[1]) if 1 in by_binding else None, img(by_binding[2]) if 2 in by_binding else None)

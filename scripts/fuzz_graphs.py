@@ -15,7 +15,13 @@ bad = 0
 t0 = time.time()
 for seed in range(first, first + count):
     rng = np.random.RandomState(seed)
-    text = (util.random_dag if os.environ.get("FUZZ_GEN") == "dag" else util.random_graph)(rng)
+    gen = os.environ.get("FUZZ_GEN")
+    if gen == "dag_user":      # user types (shaders/*.stage.hip) mixed in; the oracle compiles the same files for the host
+        if seed == first:
+            util.register_user_types()
+        text = util.random_dag(rng, split=seed % 2 == 0, user=True)
+    else:
+        text = (util.random_dag if gen == "dag" else util.random_graph)(rng)
     w = W if seed % 3 else int(rng.randint(1, W))
     h = H if seed % 5 else int(rng.randint(1, H))
     for fmt in (util.F32, util.U8):

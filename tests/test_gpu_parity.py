@@ -720,3 +720,43 @@ def test_conv_sigma_edit_regenerates_the_weights(ctx):
             g.execute(); g.wait()
             util.assert_same(g.download_raw(), util.run_oracle(t1, x), "after the edits, flags %d" % flags)
             g.close()
+
+
+@pytest.fixture
+def user_types():
+    old = util.register_user_types()
+    yield
+    rf.set_shader_path(old)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_dags_with_user_types(ctx, user_types, seed):
+    """random DAGs in which about a third of the nodes are USER types (shaders/*.stage.hip): invert / edge_detect fused with
+    whatever surrounds them, unsharp_mask with two inputs and up to two outputs read, tone_curve -> apply_curve over a
+    storage-buffer edge; split_luma nodes on even seeds.  The oracle runs the same files compiled for the host
+    (oracle/user_stage.py): this checks the EXECUTOR around user types (fusion, aliasing, layering, strips), the files'
+    arithmetic is checked against exact restatements in test_gpu_user_stage.py / test_gpu_user_node.py."""
+    rng = np.random.RandomState(9000 + seed)
+    text = util.random_dag(rng, split=seed % 2 == 0, user=True)
+    W, H = int(rng.randint(1, 200)), int(rng.randint(40, 120))
+    for fmt in (util.F32, util.U8):
+        x = util.synthetic(W, H, fmt, seed=seed)
+        want = util.run_oracle(text, x)
+        for flags in (0, NF, rf.RF_GRAPH_HIPGRAPH, rf.RF_GRAPH_NO_JIT):
+            util.assert_same(util.run_hip(ctx, text, x, flags=flags, exec_flags=rf.RF_EXEC_CONCURRENT_LAYERS if seed & 1 else 0), want,
+                             "seed %d flags %d %dx%d\n%s" % (seed, flags, W, H, text))
+    if seed % 3 == 0:
+        world = 2 + seed % 2
+        p = rf.Plan(rf.Config(text))
+        if p.halo_schedule(False)[3] <= H // world:
+            want = util.run_oracle(text, pixel.fill_synthetic(W, H, util.F32, 0x5EED0004))
+            strips = []
+            for rank in range(world):
+                c = rf.Context(0, rank, world, None)
+                g = rf.Graph(c, rf.Config(text), W, H, util.F32, flags=rf.RF_GRAPH_NO_HALO_XCHG)
+                g.fill_synthetic(0x5EED0004)
+                g.execute(); g.wait()
+                strips.append(g.download_raw())
+                g.close()
+                c.close()
+            util.assert_same(np.concatenate(strips, axis=0), want, "strips seed %d world %d\n%s" % (seed, world, text))

@@ -139,8 +139,26 @@ def random_graph(rng):
     return "\n".join(lines + decl)
 
 
-def random_dag(rng, split=False):
-    """(split=True: some nodes are `split_luma`, a node with TWO output images, each of which later nodes may read.)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHADERS = os.path.join(ROOT, "shaders")
+USER_TYPES = ("invert", "edge_detect", "unsharp_mask", "tone_curve", "apply_curve")
+
+
+def register_user_types():
+    """the shipped stage files ({shader_path} = shaders/) on BOTH sides: the library looks them up there, the oracle compiles the
+    same files for the host (oracle/user_stage.py).  Returns the previous shader path of the library (restore it afterwards)."""
+    for n in USER_TYPES:
+        if "user" not in ograph.NODE_TYPES.get(n, {}):
+            ograph.register_user_type(n, os.path.join(SHADERS, n + ".stage.hip"))
+    old = rf.shader_path()
+    rf.set_shader_path(SHADERS)
+    return old
+
+
+def random_dag(rng, split=False, user=False):
+    """(split=True: some nodes are `split_luma`, a node with TWO output images, each of which later nodes may read.
+    user=True: some nodes are USER types -- shaders/*.stage.hip: invert and edge_detect (row stages that fuse), unsharp_mask (two
+    inputs, up to two outputs read), tone_curve -> apply_curve (a storage-buffer edge); call register_user_types() first.)
     A wider generator than random_graph: up to 9 nodes, any earlier node's output (or the input)
     may feed a new node, `combination` joins appear anywhere, type aliases, large radii and kernels,
     in-place point ops anywhere.  The last node drives the output; dangling nodes are pruned by
@@ -165,6 +183,41 @@ def random_dag(rng, split=False):
                 outputs.append(sname + ":luma_image")
             if which != 1:
                 outputs.append(sname + ":chroma_image")
+            continue
+        if user and rng.rand() < 0.3:
+            kind = ["invert", "edge_detect", "unsharp_mask", "curve"][rng.randint(4)]
+            if kind == "invert":
+                decl.append("%s: invert { enabled: %s, strength: %.2f }" % (name, "true" if rng.rand() < 0.8 else "false", rng.uniform(0.0, 1.0)))
+            elif kind == "edge_detect":
+                decl.append("%s: edge_detect { scale: %.2f }" % (name, rng.uniform(0.2, 3.0)))
+            elif kind == "unsharp_mask" and len(outputs) >= 2:
+                a, b = [outputs[k] for k in rng.choice(len(outputs), 2, replace=False)]
+                decl.append("%s: unsharp_mask { amount: %.2f, threshold: %.3f }" % (name, rng.uniform(0.0, 2.0), rng.uniform(0.0, 0.1)))
+                edges.append([a, name + ":input_image"])
+                edges.append([b, name + ":blurred_image"])
+                readers[a] = readers.get(a, 0) + 1
+                readers[b] = readers.get(b, 0) + 1
+                which = rng.randint(3)               # 0: both outputs offered to later nodes, 1: output_image only, 2: mask_image only
+                if which != 2:
+                    outputs.append(name)
+                if which != 1:
+                    outputs.append(name + ":mask_image")
+                continue
+            elif kind == "curve":
+                # a node that fills a storage buffer, its reader behind it in the image chain AND wired to the buffer by its block type name
+                tc = "t%02d" % i
+                decl.append("%s: tone_curve { gamma: %.2f, lift: %.3f }" % (tc, rng.uniform(-0.8, 0.8), rng.uniform(0.0, 0.2)))
+                decl.append("%s: apply_curve { strength: %.2f }" % (name, rng.uniform(0.0, 1.0)))
+                edges.append([src, tc, name])
+                edges.append([tc + ":ToneCurve", name + ":ToneCurve"])
+                readers[src] = readers.get(src, 0) + 1
+                outputs.append(name)
+                continue
+            else:
+                decl.append("%s: invert { enabled: true, strength: 0.5 }" % name)
+            edges.append([src, name])
+            readers[src] = readers.get(src, 0) + 1
+            outputs.append(name)
             continue
         if roll < 0.15 and len(outputs) >= 3:
             a, b = [outputs[k] for k in rng.choice(len(outputs), 2, replace=False)]
