@@ -75,6 +75,7 @@ def _worker(rank, world, port, text, W, H, fmt, exchange, fused, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         flags = 0 if fused else rf.RF_GRAPH_NO_FUSION
+        util.register_user_types()              # shaders/*.stage.hip on both sides (the library's lookup, the oracle's host build)
         plan = rf.Plan(rf.Config(text), flags)
         launches = plan.launch_info()
         need_src, need_dst, need_input, ghost = plan.halo_schedule(exchange)
@@ -107,6 +108,19 @@ def _worker(rank, world, port, text, W, H, fmt, exchange, fused, out_dir):
                 for name in L["outputs"]:
                     images[name][ghost + o0:ghost + o1] = by_name[name][o0 - row_lo:o1 - row_lo]
                 continue
+            ut = og.NODE_TYPES.get(cfg.type_of(L["members"][0]), {}).get("user")
+            if ut is not None and ut.multi and len(L["members"]) == 1:
+                # a user NODE (a stage file that declares its images): several inputs, one image per wired output binding
+                from oracle import user_stage
+                node = L["members"][0]
+                srcs_c = [np.ascontiguousarray(a) for a in srcs]
+                outs = [np.empty_like(srcs_c[0]) for _ in ut.outputs]
+                params = og.synthesize(cfg)[node].params
+                user_stage.run(ut, params, srcs_c, outs)
+                by_name = {plan.resolve("%s:%s" % (node, nm)): o for nm, o in zip(ut.outputs, outs)}
+                for name in L["outputs"]:
+                    images[name][ghost + o0:ghost + o1] = by_name[name][o0 - row_lo:o1 - row_lo]
+                continue
             if cfg.type_of(L["members"][0]) == "combination" and len(L["members"]) == 1:
                 t = float(np.float32(float(cfg.params_of(L["members"][0])["mix"])))
                 res = pixel.mix(srcs[0], srcs[1], t)
@@ -131,6 +145,20 @@ CASES = [
     (util.SPLIT2, 2, True, False),       # a node with two output images, exchange and over-fetch
     (util.SPLIT2, 3, False, True),
 ]
+# user types: a node with two inputs and two outputs read (its own kernel), row stages fused with a gaussian
+USER_BOTH = """
+input -> blur -> um:blurred_image
+input -> um:input_image
+um -> mm:input_image0
+um:mask_image -> ee -> mm:input_image1
+mm -> nn -> output
+blur: gaussian5 { sigma: 1.0 }
+um: unsharp_mask { amount: 0.8, threshold: 0.05 }
+ee: edge_detect { scale: 1.5 }
+mm: combination { mix: 0.25 }
+nn: invert { enabled: true, strength: 0.6 }
+"""
+CASES += [(USER_BOTH, 2, True, True), (USER_BOTH, 3, False, False), (USER_BOTH, 2, False, True)]
 # graphs nobody wrote by hand (tests/util.py::random_graph), exchange and over-fetch schedules
 for _seed, _world, _xchg, _fused in ((3001, 2, True, True), (3002, 3, True, False), (3003, 2, False, True), (3004, 2, True, True)):
     CASES.append((util.random_graph(np.random.RandomState(_seed)), _world, _xchg, _fused))
@@ -143,7 +171,11 @@ def test_row_strips_reproduce_the_full_frame(tmp_path, text, world, exchange, fu
     port = _free_port()
     mp.spawn(_worker, args=(world, port, text, W, H, fmt, exchange, fused, str(tmp_path)), nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / ("strip%d.npy" % r)) for r in range(world)], axis=0)
-    want = util.run_oracle(text, pixel.fill_synthetic(W, H, fmt, 0x5EED0004))
+    old = util.register_user_types()
+    try:
+        want = util.run_oracle(text, pixel.fill_synthetic(W, H, fmt, 0x5EED0004))
+    finally:
+        rf.set_shader_path(old)
     util.assert_same(got, want, "row strips, world=%d exchange=%s fused=%s" % (world, exchange, fused))
 
 
