@@ -468,7 +468,7 @@ class GraphOracle:
                     raise ConfigError("node %s needs an image wired to %s" % (info.name, nm))
             srcs = [img(in_by[i]) for i in range(len(ut.inputs))]
             dsts = [img(out_by[b]) if b in out_by else None for b in ut.out_binding]
-            if not ut.multi and srcs[0] is dsts[0] and ut.radius > 0:
+            if ut.radius > 0 and any(d is not None and any(d is s_ for s_ in srcs) for d in dsts):
                 raise ConfigError("in-place execution of a stencil node")
             buf_in = buf_out = None
             if ut.buf_in:

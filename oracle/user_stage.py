@@ -12,7 +12,7 @@ aliasing, in-place writes, several outputs, storage-buffer edges, row strips -- 
 
 "Reflection" is restated here in Python (the product's is reforge_amd/csrc/rf_user.cpp): members of struct Params with their
 offsets, RADIUS, RF_INPUTS / RF_OUTPUTS (bindings: inputs 0.., outputs after them, a name on both sides shares its input's),
-RF_BUFFER_IN / RF_BUFFER_OUT (bindings after the images').  Ref: src/vulkan/shader.rs:106-160 (reflect_descriptors).
+RF_BUFFER_IN / RF_BUFFER_OUT (bindings after the images'), RADIUS > 0 in a node = inputs read through `Window::at`.  Ref: src/vulkan/shader.rs:106-160 (reflect_descriptors).
 """
 import ctypes as C
 import hashlib
@@ -32,6 +32,16 @@ _HARNESS = r'''
 #include <string.h>
 struct f4 { float x, y, z, w; };
 static inline f4 make_float4(float x, float y, float z, float w) { f4 r = {x, y, z, w}; return r; }
+struct Window {       /* RADIUS > 0 in a node: the neighbourhood of an input image, clamp-to-edge (rf_user_dev.h) */
+    const f4* img; int W, H, x, y;
+    f4 at(int dx, int dy) const
+    {
+        int xx = x + dx, yy = y + dy;
+        xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+        yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+        return img[(long)yy * W + xx];
+    }
+};
 #define RF_STAGE static inline
 #define RF_INPUTS(...) static_assert(true, "")
 #define RF_OUTPUTS(...) static_assert(true, "")
@@ -67,12 +77,18 @@ extern "C" void rf_run(const void* pp, const float* src, float* dst, int W, int 
         }
 }
 #else              /* a node: NI inputs, NO outputs, optionally a buffer read and a buffer filled */
-extern "C" void rf_node(const void* pp, const float* const* in, float* const* out, const float* buf, long n)
+extern "C" void rf_node(const void* pp, const float* const* in, float* const* out, const float* buf, int W, int H)
 {
     Params p; memcpy(&p, pp, sizeof(p));
-    for (long i = 0; i < n; ++i) {
-        f4 a[NI], o[NO];
+    for (long i = 0; i < (long)W * H; ++i) {
+        f4 o[NO];
+#if WINDOWS
+        Window a[NI];
+        for (int k = 0; k < NI; ++k) { Window w = {(const f4*)in[k], W, H, (int)(i %% W), (int)(i / W)}; a[k] = w; }
+#else
+        f4 a[NI];
         for (int k = 0; k < NI; ++k) a[k] = ((const f4*)in[k])[i];
+#endif
         for (int k = 0; k < NO; ++k) o[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 #if HAS_BUF_IN
         apply(p, a, o, buf);
@@ -127,7 +143,7 @@ class UserType:
         ins, outs = names("RF_INPUTS"), names("RF_OUTPUTS")
         self.buf_in = names("RF_BUFFER_IN")            # [type name, count]
         self.buf_out = names("RF_BUFFER_OUT")
-        self.multi = any(v is not None for v in (ins, outs, self.buf_in, self.buf_out))
+        self.multi = any(v is not None for v in (ins, outs, self.buf_in, self.buf_out)) or self.radius >= 2
         self.inputs = ins or ["input_image"]
         self.outputs = outs or ["output_image"]
         self.images, nxt = {}, len(self.inputs)
@@ -159,7 +175,7 @@ class UserType:
         if self._lib is None:
             form = 2 if self.multi else (1 if self.radius else 0)
             src = _HARNESS % {"name": self.name, "text": self.text, "psize": self.params_size}
-            flags = ["-DFORM=%d" % form, "-DNI=%d" % len(self.inputs), "-DNO=%d" % len(self.outputs), "-DHAS_BUF_IN=%d" % (1 if self.buf_in else 0),
+            flags = ["-DFORM=%d" % form, "-DNI=%d" % len(self.inputs), "-DNO=%d" % len(self.outputs), "-DHAS_BUF_IN=%d" % (1 if self.buf_in else 0), "-DWINDOWS=%d" % (1 if self.radius > 0 else 0),
                      "-DFILL=%d" % (int(self.buf_out[1]) if self.buf_out else 0)]
             key = hashlib.sha256((src + " ".join(flags)).encode()).hexdigest()[:20]
             os.makedirs(_BUILD, exist_ok=True)
@@ -223,7 +239,7 @@ def run(ut, params, srcs, dsts, buf_in=None, buf_out=None):
     outs = [np.empty((H, W, 4), np.float32) if d is not None else None for d in dsts]
     in_arr = (fp * len(ins))(*[a.ctypes.data_as(fp) for a in ins])
     out_arr = (fp * len(outs))(*[(a.ctypes.data_as(fp) if a is not None else fp()) for a in outs])
-    L.rf_node(blk, in_arr, out_arr, buf_in.ctypes.data_as(fp) if buf_in is not None else fp(), C.c_long(W * H))
+    L.rf_node(blk, in_arr, out_arr, buf_in.ctypes.data_as(fp) if buf_in is not None else fp(), C.c_int(W), C.c_int(H))
     for a, d in zip(outs, dsts):
         if d is not None:
             encode(a, d)

@@ -216,6 +216,8 @@ static hipError_t launch_user_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     A.y0 = geo.y0;
     A.y1 = geo.y1;
     A.grid_x = (geo.W + 255) / 256;
+    A.row_lo = geo.row_lo;
+    A.row_hi = geo.row_hi;
     static_assert(sizeof(A.params) == sizeof(op.user_params), "Params block");
     std::memcpy(A.params, op.user_params, sizeof(A.params));
     // storage buffers by block type name (shader.rs:144-147): the one it reads must be wired (build_launches), the one it fills

@@ -874,9 +874,12 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
             }
             bool all_point = true;
             std::vector<Op> ops = ops_of_members(plan, L.members, L.member_slot, nullptr);
-            for (const auto& o : ops) all_point = all_point && point_kind(o.kind);
+            for (const auto& o : ops) all_point = all_point && point_kind(o.kind) && !(o.kind == OP_USERN && o.radius > 0);
             L.radius = ops_radius(ops.data(), (int)ops.size());
-            if (kind0 != OP_MIX && L.src[0] == L.dst && !all_point) {
+            bool reads_what_it_writes = false;
+            for (const auto& sname : L.src)
+                for (const auto& d : L.dsts) reads_what_it_writes = reads_what_it_writes || sname == d;
+            if (kind0 == OP_USERN ? (reads_what_it_writes && !all_point) : (kind0 != OP_MIX && L.src[0] == L.dst && !all_point)) {
                 err = "node '" + unit + "' would run a stencil in place";
                 return false;
             }

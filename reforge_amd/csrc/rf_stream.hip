@@ -526,6 +526,7 @@ int ops_radius(const Op* ops, int n)
             case OP_GAUSSIAN: r += ops[i].radius; break;
             case OP_SHARPEN: r += 1; break;
             case OP_USER: r += ops[i].radius; break;
+            case OP_USERN: r += ops[i].radius; break;
             case OP_CONV2D: r += ops[i].radius; break;
             default: break;
         }

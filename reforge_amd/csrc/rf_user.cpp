@@ -72,7 +72,7 @@ bool parse_user_stage(const std::string& type, const std::string& text, UserStag
     size_t eq = t.find('=', r);
     if (eq == std::string::npos) { err = type + ".stage.hip: RADIUS has no value"; return false; }
     out.radius = std::atoi(t.c_str() + eq + 1);
-    if (out.radius != 0 && out.radius != 1) { err = type + ".stage.hip: RADIUS must be 0 (point op) or 1 (3x3 neighbourhood)"; return false; }
+    if (out.radius < 0 || out.radius > kMaxRadius) { err = type + ".stage.hip: RADIUS must be 0 (point op), 1 (3x3 neighbourhood) or 2.." + std::to_string(kMaxRadius) + " (a window read through Window::at)"; return false; }
     // struct Params { <type> <name>; ... };
     size_t sp = t.find("struct Params");
     if (sp == std::string::npos) { err = type + ".stage.hip: no `struct Params { ... };`"; return false; }
@@ -154,7 +154,11 @@ bool parse_user_stage(const std::string& type, const std::string& text, UserStag
         return false;
     }
     if (!out.buf_out.empty() && t.find("fill") == std::string::npos) { err = type + ".stage.hip: RF_BUFFER_OUT needs `RF_STAGE float fill(const Params&, int i)`"; return false; }
-    if (out.multi && out.radius != 0) { err = type + ".stage.hip: a node that declares its images (RF_INPUTS / RF_OUTPUTS) is a point op: RADIUS must be 0"; return false; }
+    if (out.radius >= 2) out.multi = true;            // no row stage of that radius: a node with a kernel of its own, its inputs read through windows
+    if (out.multi && out.radius > 0) {
+        for (const auto& o : out.outputs)
+            if (std::find(out.inputs.begin(), out.inputs.end(), o) != out.inputs.end()) { err = type + ".stage.hip: `" + o + "` is read through a window (RADIUS " + std::to_string(out.radius) + ") and cannot be written in place"; return false; }
+    }
     for (size_t i = 0; i < out.inputs.size(); ++i) out.in_binding.push_back((int)i);
     int next = (int)out.inputs.size();
     for (const auto& o : out.outputs) {
@@ -168,7 +172,7 @@ bool parse_user_stage(const std::string& type, const std::string& text, UserStag
 
 std::string UserStage::wrapper() const
 {
-    std::string w = "\nnamespace rfuser { namespace " + ident + " {\nusing rf::f4;\n#define RF_STAGE static __device__ __forceinline__\n"
+    std::string w = "\nnamespace rfuser { namespace " + ident + " {\nusing rf::f4;\nusing rf::Window;\n#define RF_STAGE static __device__ __forceinline__\n"
                     "#define RF_INPUTS(...) static_assert(true, \"\")\n#define RF_OUTPUTS(...) static_assert(true, \"\")\n"
                     "#define RF_BUFFER_IN(...) static_assert(true, \"\")\n#define RF_BUFFER_OUT(...) static_assert(true, \"\")\n#line 1 \"" +
                     type_name + ".stage.hip\"\n" + text + "\n#undef RF_STAGE\n#undef RF_INPUTS\n#undef RF_OUTPUTS\n#undef RF_BUFFER_IN\n#undef RF_BUFFER_OUT\nstruct Stage {\n    typedef Params P;\n    static constexpr int R = RADIUS;\n"
@@ -179,7 +183,7 @@ std::string UserStage::wrapper() const
     if (multi) {
         w += "    static constexpr int NI = " + std::to_string(inputs.size()) + ", NO = " + std::to_string(outputs.size()) +
              ", FILL = " + std::to_string(buf_out.empty() ? 0 : buf_out[0].count) + ";\n"
-             "    template <class Q> static __device__ __forceinline__ void node(const Q& p, const f4 (&in)[NI], f4 (&out)[NO], const float* buf) { apply(p, in, out" +
+             "    template <class Q, class In> static __device__ __forceinline__ void node(const Q& p, const In (&in)[NI], f4 (&out)[NO], const float* buf) { apply(p, in, out" +
              std::string(buf_in.empty() ? "" : ", buf") + "); }\n";
         if (!buf_out.empty()) w += "    template <class Q> static __device__ __forceinline__ float fill_at(const Q& p, int i) { return fill(p, i); }\n";
         w += "};\n} }\n";

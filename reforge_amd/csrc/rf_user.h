@@ -12,7 +12,10 @@
 // counterpart of a .comp file's `uniform image2D` variables, found by name (shader.rs:151-153; a config wires them with
 // `-> node:detail_image`).  Such a type is a NODE with up to 4 input and 4 output images and a kernel of its own
 // (rf_user_dev.h, user_node_kernel; a point op: RADIUS 0), `apply(const Params&, const f4 (&in)[NI], f4 (&out)[NO])`; a name
-// listed on both sides is ONE binding, i.e. written in place (pipeline_graph.rs:228,:402-406).  A node may also read one storage
+// listed on both sides is ONE binding, i.e. written in place (pipeline_graph.rs:228,:402-406).  With RADIUS R > 0 such a node reads
+// its inputs through WINDOWS -- `apply(const Params&, const Window (&in)[NI], f4 (&out)[NO])`, `in[k].at(dx, dy)` for |dx|, |dy| <= R,
+// clamp-to-edge -- the counterpart of a shader that calls imageLoad at neighbouring coordinates; RADIUS 2..15 always takes this form
+// (a file without declarations then has the one input and output every shader has, passthrough.comp:4-5).  A node may also read one storage
 // buffer and write one, found by the block's TYPE name like the reference's (shader.rs:144-147, vkutils.rs:165-170):
 // `RF_BUFFER_IN(ToneCurve, 256);` adds a `const float*` argument to apply(); `RF_BUFFER_OUT(ToneCurve, 256);` asks for
 // `RF_STAGE float fill(const Params&, int i)`, evaluated for i = 0..255 in front of the node's own kernel, every frame.

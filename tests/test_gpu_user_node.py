@@ -13,7 +13,7 @@ import reforge_amd as rf
 from tests import util
 from tests.golden import exact_eval as ex
 from tests.test_gpu_user_stage import from_img, to_img
-from tests.test_user_node import BOX_GRAPH, BOX_WEIGHTS, CURVE, TINT, TINT_GRAPH, UNSHARP, UNSHARP_BOTH
+from tests.test_user_node import BOX_GRAPH, BOX_WEIGHTS, CURVE, GUIDED, TINT, TINT_GRAPH, UNSHARP, UNSHARP_BOTH, WINDOW_GRAPH
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,9 +29,10 @@ def ctx():
 
 @pytest.fixture
 def stage_dir(tmp_path):
-    for f in ("unsharp_mask.stage.hip", "tone_curve.stage.hip", "apply_curve.stage.hip"):
+    for f in ("unsharp_mask.stage.hip", "tone_curve.stage.hip", "apply_curve.stage.hip", "local_contrast.stage.hip"):
         shutil.copy(os.path.join(SHADERS, f), tmp_path / f)
     (tmp_path / "box_weights.stage.hip").write_text(BOX_WEIGHTS)
+    (tmp_path / "guided.stage.hip").write_text(GUIDED)
     (tmp_path / "tint.stage.hip").write_text(TINT)
     old = rf.shader_path()
     rf.set_shader_path(str(tmp_path))
@@ -95,6 +96,45 @@ def want_curve(x, fmt, gamma, lift, strength):
     return from_img(ex.store(apply_curve(ex.load(through, fmt), tone_curve(gamma, lift), strength), fmt), x.dtype)
 
 
+def local_contrast(img, amount):
+    """shaders/local_contrast.stage.hip: RADIUS 2, the 5x5 mean accumulated row by row, left to right"""
+    amount, k = ex.f32(amount), ex.f32(0.04)
+    out = []
+    for y in range(len(img)):
+        row = []
+        for x in range(len(img[0])):
+            acc = [ex.ZERO] * 3
+            for dy in range(-2, 3):
+                for dx in range(-2, 3):
+                    t = ex.at(img, x + dx, y + dy)
+                    acc = [ex.fma(k, t[c], acc[c]) for c in range(3)]
+            c0 = img[y][x]
+            row.append([ex.fma(amount, ex.rn(c0[c] - acc[c]), c0[c]) for c in range(3)] + [c0[3]])
+        out.append(row)
+    return out
+
+
+def guided(base, guide, strength):
+    """the GUIDED file of tests/test_user_node.py: two inputs read through windows"""
+    s = ex.f32(strength)
+    out = []
+    for y in range(len(base)):
+        row = []
+        for x in range(len(base[0])):
+            c0, e, w, so, n = base[y][x], ex.at(guide, x + 1, y), ex.at(guide, x - 1, y), ex.at(guide, x, y + 1), ex.at(guide, x, y - 1)
+            row.append([ex.fma(s, ex.rn(ex.rn(e[c] - w[c]) + ex.rn(so[c] - n[c])), c0[c]) for c in range(3)] + [c0[3]])
+        out.append(row)
+    return out
+
+
+def want_window_graph(x, fmt):
+    xi = to_img(x)
+    gg = ex.node(ex.gaussian, fmt, [xi], 1.0, 2)
+    lc = ex.node(local_contrast, fmt, [gg], 0.8)
+    sh = ex.node(ex.sharpen, fmt, [xi], 0.4)
+    return from_img(ex.node(guided, fmt, [lc, sh], 0.25), x.dtype)
+
+
 def want_unsharp_both(x, fmt):
     xi = to_img(x)
     blur = ex.node(ex.gaussian, fmt, [xi], 1.0, 2)
@@ -152,7 +192,20 @@ def test_a_node_that_writes_its_first_input_in_place(ctx, stage_dir, fmt, tag):
         g.close()
 
 
-@pytest.mark.parametrize("text,world", [(UNSHARP_BOTH, 3), (TINT_GRAPH, 2)])
+@pytest.mark.parametrize("fmt,tag", [(util.F32, "f32"), (util.U8, "u8")])
+def test_nodes_that_read_through_windows_match_the_restatement(ctx, stage_dir, fmt, tag):
+    """RADIUS 2 (local_contrast: one input) and RADIUS 1 with two declared inputs (guided): clamp-to-edge at all four frame edges
+    (the frame is narrower than a workgroup and only 14 rows high), the interior / boundary split of an exchange-mode strip"""
+    W, H = 53, 14
+    x = util.synthetic(W, H, fmt, 71)
+    want = want_window_graph(x, tag)
+    for flags, ex_flags in ((0, 0), (rf.RF_GRAPH_NO_FUSION, 0), (rf.RF_GRAPH_HIPGRAPH, 0), (0, rf.RF_EXEC_FORCE_SPLIT), (0, rf.RF_EXEC_CONCURRENT_LAYERS)):
+        util.assert_same(util.run_hip(ctx, WINDOW_GRAPH, x, flags=flags, exec_flags=ex_flags), want, "window nodes %s flags=%d exec=%d" % (tag, flags, ex_flags))
+    alone = util.run_hip(ctx, "input -> lc -> output\nlc: local_contrast { amount: 1.5 }", x)
+    util.assert_same(alone, from_img(ex.store(local_contrast(ex.load(to_img(x), tag), 1.5), tag), x.dtype), "local_contrast alone")
+
+
+@pytest.mark.parametrize("text,world", [(UNSHARP_BOTH, 3), (TINT_GRAPH, 2), (WINDOW_GRAPH, 3), (WINDOW_GRAPH, 2)])
 def test_user_nodes_in_row_strips(stage_dir, ctx, text, world):
     """over-fetch row strips on one GPU standing in for N ranks: the user node produces the ghost rows its readers
     want like any point op; the stacked strips equal the whole frame"""

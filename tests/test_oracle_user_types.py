@@ -14,7 +14,7 @@ from oracle import graph as og
 from tests import util
 from tests import test_gpu_user_node as gu
 from tests import test_gpu_user_stage as gs
-from tests.test_user_node import CURVE, TINT, TINT_GRAPH, UNSHARP_BOTH
+from tests.test_user_node import CURVE, GUIDED, TINT, TINT_GRAPH, UNSHARP_BOTH, WINDOW_GRAPH
 
 
 @pytest.fixture
@@ -22,9 +22,12 @@ def user_types(tmp_path):
     old = util.register_user_types()
     (tmp_path / "tint.stage.hip").write_text(TINT)
     og.register_user_type("tint", str(tmp_path / "tint.stage.hip"))
+    (tmp_path / "guided.stage.hip").write_text(GUIDED)
+    og.register_user_type("guided", str(tmp_path / "guided.stage.hip"))
     yield
     rf.set_shader_path(old)
     og.NODE_TYPES.pop("tint", None)
+    og.NODE_TYPES.pop("guided", None)
 
 
 @pytest.mark.parametrize("fmt,tag", [(util.F32, "f32"), (util.U8, "u8")])
@@ -34,6 +37,7 @@ def test_host_build_of_the_stage_files_matches_the_exact_restatements(user_types
     util.assert_same(util.run_oracle(TINT_GRAPH, x), gu.want_tint(x, tag), "a node that writes its input in place")
     util.assert_same(util.run_oracle(CURVE, x), gu.want_curve(x, tag, 0.6, 0.05, 0.8), "tone_curve -> apply_curve over a buffer edge")
     util.assert_same(util.run_oracle(gs.CHAIN % ("0.75", "1.0"), x), gs.want_chain(x, tag, 0.75, 1.0), "gaussian5 -> edge_detect -> invert")
+    util.assert_same(util.run_oracle(WINDOW_GRAPH, x), gu.want_window_graph(x, tag), "nodes that read through windows (RADIUS 2; two inputs at RADIUS 1)")
 
 
 def test_generated_graphs_with_user_types_plan_like_the_restatement(user_types):

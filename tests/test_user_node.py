@@ -85,7 +85,7 @@ cv: conv2d { ksize: 5 }
 
 @pytest.fixture
 def stage_dir(tmp_path):
-    for f in ("unsharp_mask.stage.hip", "tone_curve.stage.hip", "apply_curve.stage.hip"):
+    for f in ("unsharp_mask.stage.hip", "tone_curve.stage.hip", "apply_curve.stage.hip", "local_contrast.stage.hip"):
         shutil.copy(os.path.join(SHADERS, f), tmp_path / f)
     (tmp_path / "box_weights.stage.hip").write_text(BOX_WEIGHTS)
     (tmp_path / "tint.stage.hip").write_text(TINT)
@@ -172,6 +172,46 @@ def test_wiring_errors_name_the_image_variable(stage_dir):
         assert want in str(e.value), (text, str(e.value))
 
 
+# a node that reads TWO inputs through windows (RADIUS 1 with declared images: not a row stage): a gradient of the guide added to the base
+GUIDED = """struct Params { float strength; };
+static constexpr int RADIUS = 1;
+RF_INPUTS(base_image, guide_image);
+RF_OUTPUTS(output_image);
+RF_STAGE void apply(const Params& p, const Window (&in)[2], f4 (&out)[1])
+{
+    const f4 c = in[0].at(0, 0), e = in[1].at(1, 0), w = in[1].at(-1, 0), s = in[1].at(0, 1), n = in[1].at(0, -1);
+    out[0] = make_float4(fmaf(p.strength, (e.x - w.x) + (s.x - n.x), c.x), fmaf(p.strength, (e.y - w.y) + (s.y - n.y), c.y),
+                         fmaf(p.strength, (e.z - w.z) + (s.z - n.z), c.z), c.w);
+}
+"""
+WINDOW_GRAPH = """
+input -> gg -> lc -> gd:base_image
+input -> sh -> gd:guide_image
+gd -> output
+gg: gaussian5 { sigma: 1.0 }
+lc: local_contrast { amount: 0.8 }
+sh: sharpen { amount: 0.4 }
+gd: guided { strength: 0.25 }
+"""
+
+
+def test_a_stage_of_radius_two_or_more_is_a_node_that_reads_through_windows(stage_dir):
+    (stage_dir / "guided.stage.hip").write_text(GUIDED)
+    p = rf.Plan(rf.Config(WINDOW_GRAPH))
+    info = {l["label"]: l for l in p.launch_info()}
+    assert set(info) == {"gg", "lc", "sh", "gd"}                            # window nodes keep launches of their own
+    assert info["lc"]["radius"] == 2 and info["gd"]["radius"] == 1 and len(info["gd"]["inputs"]) == 2
+    assert info["lc"]["inputs"] != info["lc"]["outputs"]                    # never planned in place: it reads its neighbours
+    # row strips: the ghost rows a window node reads are scheduled like any stencil's (over-fetch: cumulative; exchange: per launch)
+    labels = [l["label"] for l in p.launch_info()]
+    need_src, need_dst, need_input, ghost = p.halo_schedule(exchange=False)
+    assert need_input == 2 + 2 + 1 and ghost == 5 and need_src[labels.index("lc")] == 3 and need_dst[labels.index("lc")] == 1
+    xs, _xd, _ni, xg = p.halo_schedule(exchange=True)
+    assert xs[labels.index("lc")] == 2 and xs[labels.index("gd")] == 1 and xg == 2
+    if rf.lib().rf_jit_available():
+        assert p.jit_compile(rf.RF_FORMAT_RGBA32F) > 4096 and p.jit_compile(rf.RF_FORMAT_RGBA8) > 4096
+
+
 def test_storage_buffers_are_found_by_their_block_type_name(stage_dir):
     L = rf.lib()
     assert L.rf_registry_buffer_binding(b"tone_curve", b"ToneCurve") == 2 and L.rf_registry_buffer_binding(b"apply_curve", b"ToneCurve") == 2
@@ -200,7 +240,8 @@ def test_storage_buffers_are_found_by_their_block_type_name(stage_dir):
 def test_bad_declarations_are_refused_with_a_reason(stage_dir):
     body = "RF_STAGE void apply(const Params& p, const f4 (&in)[1], f4 (&out)[1]) { out[0] = in[0]; }"
     cases = {
-        "stencil": ("struct Params { };\nstatic constexpr int RADIUS = 1;\nRF_INPUTS(aa_image);\n" + body, "RADIUS must be 0"),
+        "inplacewin": ("struct Params { };\nstatic constexpr int RADIUS = 1;\nRF_INPUTS(image);\nRF_OUTPUTS(image);\n" + body, "cannot be written in place"),
+        "radius16": ("struct Params { };\nstatic constexpr int RADIUS = 16;\nRF_INPUTS(aa_image);\n" + body, "RADIUS must be"),
         "toomany": ("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_INPUTS(a1, a2, a3, a4, a5);\n" + body, "1 to 4 image names"),
         "twice": ("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_OUTPUTS(o1, o1);\n" + body, "lists `o1` twice"),
         "notaname": ("struct Params { };\nstatic constexpr int RADIUS = 0;\nRF_INPUTS(a b);\n" + body, "is not an image variable name"),

@@ -74,7 +74,7 @@ def test_bad_stage_files_are_refused_with_a_reason(stage_dir):
     cases = {
         "noradius": "struct Params { float a; };\nRF_STAGE f4 apply(const Params& p, f4 c) { return c; }",
         "badtype": "struct Params { double a; };\nstatic constexpr int RADIUS = 0;\nRF_STAGE f4 apply(const Params& p, f4 c) { return c; }",
-        "radius2": "struct Params { };\nstatic constexpr int RADIUS = 2;\nRF_STAGE f4 apply(const Params& p, f4 c) { return c; }",
+        "radius16": "struct Params { };\nstatic constexpr int RADIUS = 16;\nRF_STAGE f4 apply(const Params& p, f4 c) { return c; }",
         "noapply": "struct Params { };\nstatic constexpr int RADIUS = 0;\n",
     }
     for name, text in cases.items():

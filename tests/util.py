@@ -141,7 +141,7 @@ def random_graph(rng):
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHADERS = os.path.join(ROOT, "shaders")
-USER_TYPES = ("invert", "edge_detect", "unsharp_mask", "tone_curve", "apply_curve")
+USER_TYPES = ("invert", "edge_detect", "unsharp_mask", "tone_curve", "apply_curve", "local_contrast")
 
 
 def register_user_types():
@@ -158,7 +158,8 @@ def register_user_types():
 def random_dag(rng, split=False, user=False):
     """(split=True: some nodes are `split_luma`, a node with TWO output images, each of which later nodes may read.
     user=True: some nodes are USER types -- shaders/*.stage.hip: invert and edge_detect (row stages that fuse), unsharp_mask (two
-    inputs, up to two outputs read), tone_curve -> apply_curve (a storage-buffer edge); call register_user_types() first.)
+    inputs, up to two outputs read), tone_curve -> apply_curve (a storage-buffer edge), local_contrast (RADIUS 2, read through a window);
+    call register_user_types() first.)
     A wider generator than random_graph: up to 9 nodes, any earlier node's output (or the input)
     may feed a new node, `combination` joins appear anywhere, type aliases, large radii and kernels,
     in-place point ops anywhere.  The last node drives the output; dangling nodes are pruned by
@@ -185,11 +186,13 @@ def random_dag(rng, split=False, user=False):
                 outputs.append(sname + ":chroma_image")
             continue
         if user and rng.rand() < 0.3:
-            kind = ["invert", "edge_detect", "unsharp_mask", "curve"][rng.randint(4)]
+            kind = ["invert", "edge_detect", "unsharp_mask", "curve", "local_contrast"][rng.randint(5)]
             if kind == "invert":
                 decl.append("%s: invert { enabled: %s, strength: %.2f }" % (name, "true" if rng.rand() < 0.8 else "false", rng.uniform(0.0, 1.0)))
             elif kind == "edge_detect":
                 decl.append("%s: edge_detect { scale: %.2f }" % (name, rng.uniform(0.2, 3.0)))
+            elif kind == "local_contrast":          # RADIUS 2: a node of its own that reads its input through a window
+                decl.append("%s: local_contrast { amount: %.2f }" % (name, rng.uniform(0.0, 1.5)))
             elif kind == "unsharp_mask" and len(outputs) >= 2:
                 a, b = [outputs[k] for k in rng.choice(len(outputs), 2, replace=False)]
                 decl.append("%s: unsharp_mask { amount: %.2f, threshold: %.3f }" % (name, rng.uniform(0.0, 2.0), rng.uniform(0.0, 0.1)))
