@@ -316,3 +316,16 @@ def test_user_node_at_4k_and_the_rate_it_streams_at(ctx, stage_dir):
         assert gbps > 1500.0                                  # a point op that moved every byte twice, or ran one wave per row, would not
     finally:
         g.close()
+    # the window fallback (RADIUS 2: 25 cached loads per texel) for the record: one image in, one out
+    g = rf.Graph(ctx, rf.Config("input -> lc -> output\nlc: local_contrast { amount: 0.8 }"), W, H, util.F32)
+    try:
+        g.fill_synthetic(1)
+        g.execute(); g.wait()
+        ms = min(g.time_launch(0, 30) for _ in range(3))
+        print("user node local_contrast (RADIUS 2, window) 3840x2160 rgba32f: %.4f ms per launch, %.0f GB/s algorithmic" % (ms, 2 * W * H * 16 / (ms * 1e-3) / 1e9))
+        rec = json.load(open(os.path.join(ROOT, "gpurun_out", "user_node_rate.json")))
+        rec["local_contrast_radius2_window"] = {"ms_per_launch": round(ms, 5), "gbps_algorithmic": round(2 * W * H * 16 / (ms * 1e-3) / 1e9, 1)}
+        with open(os.path.join(ROOT, "gpurun_out", "user_node_rate.json"), "w") as f:
+            json.dump(rec, f)
+    finally:
+        g.close()
