@@ -76,7 +76,9 @@ static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo
     const int lo = h > 4 ? 2 * h : 8;
     // all-top-down walks share no halo rows through L2: each chunk fetches its own, so they are taller (16384^2 5-stage chain,
     // two texels per lane: 112-row chunks 1.87 ms, 256-row 1.81, 384-row 2.01)
-    const int hi = narrow ? (h == 0 ? 16 : (24 * h > 32 ? 24 * h : 32)) : (h <= 4 ? (8 * h > 8 ? 8 * h : 8) : (top_down ? 36 * h : 16 * h));   // 5-stage chain (h = 7) at 16384^2: 128-row 2.03 ms, 96-row 2.08, 84-row 2.12
+    // (round 3, with the non-temporal result stores: gaussian9 at 8K -- h = 4 -- takes 24-row chunks, never worse and 1.5-3 % better than
+    // 30 / 32 / 36 on four boxes, profiles/r03_rpc_rounds_ab.txt; the 3-stage chain -- h = 3 -- stays at 8 h = 24: 32-row chunks +2 %)
+    const int hi = narrow ? (h == 0 ? 16 : (24 * h > 32 ? 24 * h : 32)) : (h == 4 ? 24 : h < 4 ? (8 * h > 8 ? 8 * h : 8) : (top_down ? 36 * h : 16 * h));   // 5-stage chain (h = 7) at 16384^2: 128-row 2.03 ms, 96-row 2.08, 84-row 2.12
     // a frame that fits ONE round at up to twice the cap keeps the single round (4K 3-stage chain:
     // 36-row chunks = 1020 workgroups on 1024 slots, 194.6k Mpx/s; 24-row 191k; 44-row 180k)
     int rpc = (int)(fit < lo ? lo : (fit > 2 * hi ? hi : fit));
@@ -87,7 +89,7 @@ static int choose_rows_per_chunk(int rows, int strip_groups, int slots, int halo
     {
         const int chunks0 = (rows + rpc - 1) / rpc;
         const long rounds = ((long)chunks0 * strip_groups + slots - 1) / slots;
-        if (rounds >= 2 && rounds <= 8) {
+        if (rounds >= 2 && rounds <= (h <= 4 ? 5 : 8)) {      // light pipelines past five rounds: the tail of a round no longer shows (gaussian9 8K: 22-row = 24-row)
             const long chunks = rounds * slots / strip_groups;
             if (chunks > chunks0) {
                 int r2 = (int)((rows + chunks - 1) / chunks);
