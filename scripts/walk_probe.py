@@ -10,6 +10,7 @@ TEXTS = {"chain5": bench.CHAIN5, "chain3": bench.CHAIN3, "gauss9": bench.WORKLOA
          "sharpen": "input -> sh -> output\nsh: sharpen { amount: 0.5 }", "gauss5": "input -> blur -> output\nblur: gaussian5 { sigma: 1.0 }"}
 for r in range(16):
     TEXTS["gr%d" % r] = "input -> gg -> output\ngg: gaussian { sigma: 2.0, radius: %d }" % r
+TEXTS["diamond"] = bench.WORKLOADS["diamond_4k"]["text"]
 TEXTS["grade"] = "input -> gg -> output\ngg: colour_grade { slope: 1.1, offset: -0.02, saturation: 1.2 }"
 for sp in sys.argv[1:]:
     parts = sp.split(":")
