@@ -198,7 +198,15 @@ uint64_t    rf_plan_signature(const rf_plan* plan);
  * It becomes a row stage of the stream kernel -- user nodes fuse with the built-in ones -- compiled by hiprtc in
  * rf_graph_create; a file that does not parse or compile fails rf_plan_create / rf_graph_create with RF_ERR_GRAPH and the
  * compiler's message (the caller keeps the graph it has: render.rs:121-136).  shaders/edge_detect.stage.hip and
- * shaders/invert.stage.hip are the first two.  [host] process-wide, like Render's shader path (render.rs:537-588). */
+ * shaders/invert.stage.hip are the first two.
+ * A file may DECLARE what a .comp file declares (found by name, shader.rs:144-153): `RF_INPUTS(a, b); RF_OUTPUTS(c, d);` -- up to 4
+ * input and 4 output image variables, a name on both sides = one binding = written in place (pipeline_graph.rs:402-406) --
+ * `RF_BUFFER_IN(BlockType, floats);` / `RF_BUFFER_OUT(BlockType, floats);` -- one storage block read (a `const float*` argument),
+ * one filled (`RF_STAGE float fill(const Params&, int i)`).  Such a type is a node with a run-time compiled kernel of its own:
+ * `apply(const Params&, const f4 (&in)[NI], f4 (&out)[NO])`, or with RADIUS R in 1..15 `const Window (&in)[NI]` and
+ * `in[k].at(dx, dy)` (clamp-to-edge) -- every file with RADIUS >= 2 takes that form (shaders/unsharp_mask, tone_curve,
+ * apply_curve, local_contrast .stage.hip).
+ * [host] process-wide, like Render's shader path (render.rs:537-588). */
 rf_status   rf_set_shader_path(const char* dir);
 const char* rf_shader_path(void);
 /* [host] modification time (ns) of {shader_path}/{type}.stage.hip as last loaded, -1 if there is no such file: what a
