@@ -86,7 +86,19 @@ WORKLOADS = {
     "diamond_4k": dict(text=DIAMOND, W=3840, H=2160, fmt=F32, nodes=3, seed=0x5EED0006, radius=2, strong=False,
                        desc="fork/join graph of pipeline_graph.rs:462-468 (blur || sharpen -> combination), 3840x2160 rgba32f"),
 }
-SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "chain3_8k_u8", "gauss9_8k_u8", "diamond_4k"]
+# a graph whose filter types are FILES (shaders/*.stage.hip, compiled by hiprtc at graph creation): a row stage fused with a
+# built-in node, and a node with two input images and a kernel of its own
+USER_TYPES_4K = """
+input -> blur -> edges -> um:blurred_image
+input -> um:input_image
+um -> output
+blur:  gaussian5    { sigma: 1.0 }
+edges: edge_detect  { scale: 0.5 }
+um:    unsharp_mask { amount: 1.5, threshold: 0.02 }
+"""
+WORKLOADS["user_types_4k"] = dict(text=USER_TYPES_4K, W=3840, H=2160, fmt=F32, nodes=3, seed=0x5EED0007, radius=3, strong=False, user_types=("edge_detect", "unsharp_mask"),
+                                  desc="user filter types (files): gaussian5 + edge_detect fused, then unsharp_mask (two inputs, own kernel), 3840x2160 rgba32f")
+SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "chain3_8k_u8", "gauss9_8k_u8", "diamond_4k", "user_types_4k"]
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec)
 NO_POWER = False               # --no-power
@@ -375,6 +387,13 @@ def side_workload(rf, ctx, name, verify=True):
     stream, the dominant launch priced against its roofline, the result band-checked."""
     wl = WORKLOADS[name]
     out = {"workload": wl["desc"]}
+    if wl.get("user_types"):
+        # {shader_path} = shaders/ for the library; the checker compiles the same files for the host (oracle/user_stage.py)
+        rf.set_shader_path(os.path.join(ROOT, "shaders"))
+        if verify:
+            from oracle import graph as ograph
+            for t in wl["user_types"]:
+                ograph.register_user_type(t, os.path.join(ROOT, "shaders", t + ".stage.hip"))
     variants = CONV_PATHS if name == "conv31_8k" else (("", 0),)
     for vname, path in variants:
         g = rf.Graph(ctx, rf.Config(wl["text"]), wl["W"], wl["H"], wl["fmt"], conv_path=path)
@@ -519,6 +538,12 @@ def main():
         torch.cuda.synchronize()
 
     wl = WORKLOADS[args.workload]
+    if wl.get("user_types"):
+        rf.set_shader_path(os.path.join(ROOT, "shaders"))
+        if not args.skip_cpu_baseline:
+            from oracle import graph as ograph
+            for t in wl["user_types"]:
+                ograph.register_user_type(t, os.path.join(ROOT, "shaders", t + ".stage.hip"))
     text, W, Hper, fmt, n_nodes, seed, strong = wl["text"], wl["W"], wl["H"], wl["fmt"], wl["nodes"], wl["seed"], wl["strong"]
     H = Hper if (strong or world == 1) else Hper * world
     bpp = bpp_of(fmt)
