@@ -428,6 +428,18 @@ constexpr int PF_DEFAULT = RF_PF_DEFAULT;   // rows in flight per wave (8 was me
 #define RF_PF_T2 4
 #endif
 
+constexpr int kHeavyTaps = 24;      // multiply-adds per texel from which a pipeline counts as issue-bound (walk policy below, stream_kernel_code)
+// the same count the run-time StageList::taps() makes, at compile time: which catalogue entries need a non-temporal-store variant
+template <class S> struct StageTaps { static constexpr int value = 0; };
+template <int R> struct StageTaps<StHTap<R>> { static constexpr int value = 2 * R + 1; };
+template <int R> struct StageTaps<StVTap<R>> { static constexpr int value = 2 * R + 1; };
+template <> struct StageTaps<StGrade> { static constexpr int value = 3; };
+template <> struct StageTaps<StCross3> { static constexpr int value = 5; };
+template <class S> struct StageTaps<StSolo<S>> { static constexpr int value = StageTaps<S>::value; };
+template <int K, class S> struct StageTaps<StOn<K, S>> { static constexpr int value = StageTaps<S>::value; };
+template <class... S> struct SumTaps { static constexpr int value = 0; };
+template <class S, class... Rest> struct SumTaps<S, Rest...> { static constexpr int value = StageTaps<S>::value + SumTaps<Rest...>::value; };
+
 template <class... S> struct TL {};
 template <class A, class B> struct Concat;
 template <class... A, class... B> struct Concat<TL<A...>, TL<B...>> { typedef TL<A..., B...> type; };
@@ -447,11 +459,14 @@ template <int PF, class... S> static void add_to_catalogue(TL<S...>)
     AotEntry& e = catalogue()[key];
     e.fn[kFmtRGBA8][1] = &launch_aot<PxU8, PF, 1, S...>;
     e.fn[kFmtRGBA32F][1] = &launch_aot<PxF32, PF, 1, S...>;
-    e.fn[kPxF32Stream][1] = &launch_aot<PxF32NT, PF, 1, S...>;
+    // the non-temporal-store variant only where stream_kernel_code can ask for it (issue-bound lists never do: a third of the catalogue,
+    // and the slowest kernels to build)
+    constexpr bool kNt = SumTaps<S...>::value < kHeavyTaps;
+    if constexpr (kNt) e.fn[kPxF32Stream][1] = &launch_aot<PxF32NT, PF, 1, S...>;
     // two texels per lane: only where the doubled state still fits 256 VGPRs
     if constexpr (SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4 && MaxSlots<S...>::value == 1) e.fn[kFmtRGBA8][2] = &launch_aot<PxU8, (PF > 4 ? 4 : PF), 2, S...>;
     if constexpr (SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4 && MaxSlots<S...>::value == 1) e.fn[kFmtRGBA32F][2] = &launch_aot<PxF32, (PF > RF_PF_T2 ? RF_PF_T2 : (PF == PF_DEFAULT ? RF_PF_T2 : PF)), 2, S...>;
-    if constexpr (SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4 && MaxSlots<S...>::value == 1) e.fn[kPxF32Stream][2] = &launch_aot<PxF32NT, (PF > RF_PF_T2 ? RF_PF_T2 : (PF == PF_DEFAULT ? RF_PF_T2 : PF)), 2, S...>;
+    if constexpr (kNt && SumRH<S...>::value <= 7 && MaxRV<S...>::value <= 4 && MaxSlots<S...>::value == 1) e.fn[kPxF32Stream][2] = &launch_aot<PxF32NT, (PF > RF_PF_T2 ? RF_PF_T2 : (PF == PF_DEFAULT ? RF_PF_T2 : PF)), 2, S...>;
 }
 
 // The ahead-of-time catalogue: every node alone (gaussian radius 0..15), every ordered pair of
@@ -546,7 +561,6 @@ int ops_radius(const Op* ops, int n)
 //    42.2 us alternating, 43.4 top-down, 43.7 with two texels).
 // Two texels per lane are never used in place (the last strip overlaps its neighbour: see
 // stream_kernel), for rgba8 (its lanes would issue four 256-B DMAs per row) or for narrow frames.
-constexpr int kHeavyTaps = 24;
 constexpr long kTopDownMinPixels = 48L << 20;       // light rgba32f pipelines walk top-down from here up
 constexpr long kTwoTexelLightMinPixels = 200L << 20;   // ... and take two texels per lane from here up
 constexpr long kTwoTexelMinPixels = 24L << 20;   // two texels per lane from 8K frames up (5-stage chain at 4K: 64.4 us with one, 68.3 with two)
@@ -606,6 +620,7 @@ static hipError_t launch_stages(int fmt, const StageList& sl, const Op* ops, int
     if (it != built_catalogue().end()) {
         AotFn fn = it->second.fn[kc][texels];
         if (!fn) fn = it->second.fn[kc][1];
+        if (!fn) fn = it->second.fn[fmt][texels] ? it->second.fn[fmt][texels] : it->second.fn[fmt][1];      // (no such variant: the format's own kernel)
         return fn(src, dst, g, t, stream, pbytes, psize, halo);
     }
     // compiled at graph creation (rf_graph_create -> stream_prepare); never compiled here, on the frame path
