@@ -834,8 +834,8 @@ def main():
             for name in SIDE_WORKLOADS:
                 try:
                     out["workloads"][name] = side_workload(rf, ctx, name, verify=not args.skip_cpu_baseline)
-                except rf.RfError as e:
-                    out["workloads"][name] = {"error": str(e)}
+                except Exception as e:                      # noqa: BLE001 -- a side workload (or its checker) must never take the headline down
+                    out["workloads"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
             full = out["workloads"].get("chain5_16k", {}).get("ms_per_frame")
             if full:
                 try:
