@@ -263,7 +263,8 @@ static hipError_t launch_conv_mfma(int steps, dim3 grid, size_t lds, hipStream_t
 // (8 f4 accumulators) and slides a register window along the row: one ds_read_b128 (1 KiB per
 // wave = 8 LDS cycles) per 16 v_pk_fma_f32 (64 issue cycles), so the four SIMDs of a CU together
 // keep the LDS pipe half busy -- with 4 columns per lane the kernel was LDS-bound at half the
-// VALU rate.  Tap order is exactly the oracle's (dy outer, dx inner).
+// VALU rate.  The weights are SCALAR operands (s_load of the row through the scalar cache, see the tap loop): a packed FMA reads two
+// VGPR operands and one SGPR pair.  Tap order is exactly the oracle's (dy outer, dx inner).
 //
 // Workgroup = 8 waves = 128 output columns x 32 rows per step (lane = 16 column groups x
 // 4 rows; two waves per SIMD, which the VALU needs to issue every other cycle), walking down a
@@ -292,8 +293,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv2d_valu_kernel(const char* src
     constexpr int kLanesX = kCvStripW / CT, kLanesY = 64 / kLanesX, kSub = (kCvT * kCvSub) / CT, THREADS = 64 * WAVES;
     static_assert(kLanesY * WAVES == kCvStepRows, "a step is 32 output rows");
     constexpr int WN = CT + 4;                                  // register window: kCvT texels in use + 4 in flight
-    f4* wl = reinterpret_cast<f4*>(dyn_smem);                    // weights, [K][KQ] f4
-    f4* tile = wl + K * KQ;                                       // [ring][4][kCvSub]
+    f4* tile = reinterpret_cast<f4*>(dyn_smem);                  // [ring][4][kCvSub]
     constexpr int kRowTexels = kCvT * kCvSub;                     // 160 texels = 2560 B per ring row
     constexpr int r = K / 2;
     constexpr int xin = kCvStripW + 2 * r;
@@ -306,11 +306,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv2d_valu_kernel(const char* src
     const int cy1 = min(cy0 + rows_per_chunk, y1);
     if (cy0 >= cy1) return;
 
-    // weight rows into LDS (a per-tap scalar load from global would stall the wave on every tap)
-    for (int i = tid; i < K * KQ * 4; i += THREADS) {
-        const int dy = i / (KQ * 4), dx = i % (KQ * 4);
-        reinterpret_cast<float*>(wl)[i] = dx < K ? weights[dy * K + dx] : 0.0f;
-    }
     const int first_in = cy0 - r;
     auto fetch = [&](int rr, int c) {
         const int gy = min(max(rr, row_lo), row_hi);
@@ -343,15 +338,21 @@ __global__ __launch_bounds__(64 * WAVES) void conv2d_valu_kernel(const char* src
 #pragma unroll
         for (int t = 0; t < CT; ++t) acc[t] = f4_zero();
         int slot = ((ys - cy0) + kLanesY * wave + ly) % ring;   // ring slot of input row (ys + 4*wave + ly + dy - r)
+#pragma unroll 1      // one weight row at a time: unrolled (hipcc does it for K <= 7) every row's weights are fetched up front, ~50 SGPRs
+                     // and 256 VGPRs with a kilobyte of scratch (7x7 at 4K: 0.63 ms instead of 0.08)
         for (int dy = 0; dy < K; ++dy) {
             const f4* row = tile + slot * kRowTexels + lx;        // texel m of this lane's window: row[(m % T) * kCvSub + m / T]
-            const f4* wrow = wl + dy * KQ;                        // same address in every lane: LDS broadcast
+            // The K weights of this row come through the SCALAR cache into scalar registers (the address is wave-uniform; the
+            // constant address space is what lets hipcc pick s_load_dwordx16/x8/..): every v_pk_fma_f32 then takes its weight as
+            // an SGPR operand with op_sel_hi broadcasting it to both halves -- one VGPR operand read less per instruction and no
+            // LDS broadcast reads.  Round 3: 2.55-2.58 -> 2.32-2.35 ms at 31x31 8K on one box (98.8-100 -> 108.6-109.9 TF), the
+            // shader clock under the same package power 2.09 -> 2.23 GHz (profiles/r03_conv_scalar_weights_probe.txt).  Until then
+            // the row was read from an LDS copy of the weights: 8 broadcast ds_read_b128 per row and a VGPR per weight.
             float wv[KQ * 4];
+            typedef const float __attribute__((address_space(4))) * ScalarWeights;
+            const ScalarWeights wrow = (ScalarWeights)(weights + dy * K);
 #pragma unroll
-            for (int i = 0; i < KQ; ++i) {
-                const f4 q = wrow[i];
-                wv[4 * i] = q.x; wv[4 * i + 1] = q.y; wv[4 * i + 2] = q.z; wv[4 * i + 3] = q.w;
-            }
+            for (int i = 0; i < K; ++i) wv[i] = wrow[i];
             f4 win[WN];
 #pragma unroll
             for (int m = 0; m < WN; ++m) win[m] = row[(m % CT) * kSub + m / CT];
@@ -444,7 +445,7 @@ static hipError_t launch_conv2d_px(const Op& op, Image src, Image dst, const Geo
     const bool valu = !mfma && tune.conv_path != 1 && K >= 3 && (K >= 7 || tune.conv_path != 0);
     if (valu) {
         const int ring = kCvStepRows + 2 * op.radius;
-        const size_t lds = ((size_t)ring * kCvT * kCvSub + (size_t)K * ((K + 3) / 4)) * sizeof(f4);
+        const size_t lds = (size_t)ring * kCvT * kCvSub * sizeof(f4);
         const int strips = (g.W + kCvStripW - 1) / kCvStripW;
         int rpc = conv_rows_per_chunk(rows, strips, 256, kCvStepRows, 2 * kCvStepRows);   // one workgroup (up to 159 KiB of LDS) per CU
         if (tune.rows_per_chunk > 0) rpc = (tune.rows_per_chunk + kCvStepRows - 1) / kCvStepRows * kCvStepRows;
