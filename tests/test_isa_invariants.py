@@ -130,3 +130,38 @@ def test_fused_chain_steady_loop_is_lean(stream_asm):
         ops = [x.split()[0] for x in loop]
         assert ops.count("v_pk_fma_f32") >= 30
         assert len(ops) <= 130, len(ops)
+
+
+@pytest.fixture(scope="module")
+def conv_asm(tmp_path_factory):
+    kept = os.path.join(CSRC, "build", "rf_conv-hip-amdgcn-amd-amdhsa-gfx950.s")
+    deps = [os.path.join(CSRC, f) for f in ("rf_conv.hip", "rf_device.h", "rf_kernels.h")]
+    if os.path.exists(kept) and os.path.getmtime(kept) >= max(os.path.getmtime(d) for d in deps):
+        return open(kept).read().split("\n")
+    out = tmp_path_factory.mktemp("isa") / "rf_conv.s"
+    subprocess.check_call([HIPCC, "-S", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(CSRC, "rf_conv.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    return out.read_text().split("\n")
+
+
+def test_conv_valu_kernels_take_their_weights_as_scalar_operands(conv_asm):
+    """rf_conv.hip, conv2d_valu_kernel: the launch is bound by the package power, and what moved it (0.67-0.69 -> 0.70-0.75 of the f32
+    peak) was the weight operand of every packed FMA becoming a scalar register pair -- s_load of the weight row through the scalar
+    cache, `op_sel` broadcasting it -- instead of a VGPR filled from an LDS copy.  A compiler that loses that (a vector load of a
+    uniform address, or an unrolled weight-row loop that spills: hipcc did that for K <= 7 until the loop was pinned) costs 8 % to 8x
+    and no parity test would notice."""
+    text = "\n".join(conv_asm)
+    seen = 0
+    for px in ("5PxF32", "4PxU8"):
+        for K in range(7, 32, 2):
+            m = re.search(r"^(_ZN2rf18conv2d_valu_kernelINS_%sELi%dELi8ELi8E\w+):[^\n]*\n(.*?)s_endpgm" % (px, K), text, re.S | re.M)
+            assert m, (px, K)
+            body = [l.strip() for l in m.group(2).split("\n") if l.strip() and not l.strip().startswith((";", "."))]
+            assert not any(l.startswith("scratch_") for l in body), (px, K)
+            fmas = [l for l in body if l.startswith("v_pk_fma_f32")]
+            assert len(fmas) >= 2 * 8 * K and all(re.search(r", s\[\d+:\d+\]", l) for l in fmas), (px, K, len(fmas))       # K taps x 8 columns x 2 halves, each with an SGPR-pair operand
+            assert any(l.startswith("s_load_dword") for l in body)
+            # LDS: the register window only -- K + 7 texel reads per weight row, no weight reads
+            assert sum(l.startswith("ds_read_b128") for l in body) <= K + 7 + 2, (px, K)
+            seen += 1
+    assert seen == 26
