@@ -278,6 +278,10 @@ def main():
             assert re.search(r"uniform image2D image;", text)
         elif f == "split_luma.comp":
             assert re.search(r"binding = 0, rgba32f\) uniform readonly image2D input_image;", text), f
+        elif f == "unsharp_mask.comp":
+            # the twin of shaders/unsharp_mask.stage.hip: the bindings librfhip.so gives the declared names (inputs 0.., outputs after them)
+            for b, decl in enumerate(("readonly image2D input_image", "readonly image2D blurred_image", "writeonly image2D output_image", "writeonly image2D mask_image")):
+                assert re.search(r"binding = %d, rgba32f\) uniform %s;" % (b, decl), text), (f, decl)
         else:
             assert re.search(r"binding = 0, rgba32f\) uniform readonly image2D input_image;", text), f
             assert re.search(r"binding = 1, rgba32f\) uniform writeonly image2D output_image;", text), f

@@ -70,3 +70,21 @@ def test_explicit_weights_round_trip_through_the_config_parser():
         p = g.infos["gg"].params
         got = np.array([p["w%d" % i] for i in range(radius + 1)], np.float32)
         assert got.tobytes() == pixel.gaussian_weights(sigma, radius).tobytes(), (sigma, radius)
+
+
+def test_stage_files_and_their_glsl_twins_declare_the_same_interface():
+    """shaders/T.stage.hip is what librfhip.so compiles for a user type, shaders/T.comp what reforge itself would: the same image
+    variable names on the same bindings, the same uniform members (name, type, order) -- so one config drives both."""
+    import re
+    from oracle import user_stage
+    shaders = os.path.join(ROOT, "shaders")
+    twins = [f[:-10] for f in sorted(os.listdir(shaders)) if f.endswith(".stage.hip") and os.path.exists(os.path.join(shaders, f[:-10] + ".comp"))]
+    assert set(twins) >= {"edge_detect", "invert", "unsharp_mask", "local_contrast"}
+    for t in twins:
+        ut = user_stage.UserType(t, os.path.join(shaders, t + ".stage.hip"))
+        glsl = re.sub(r"//[^\n]*", "", open(os.path.join(shaders, t + ".comp")).read())
+        images = {m.group(2): int(m.group(1)) for m in re.finditer(r"binding = (\d+), rgba32f\) uniform (?:readonly |writeonly )?image2D (\w+);", glsl)}
+        assert images == ut.images, (t, images, ut.images)
+        block = re.search(r"uniform Params \{(.*?)\}", glsl, re.S)
+        members = [tuple(d.split()) for d in block.group(1).split(";") if d.split()] if block else []
+        assert members == [({"f32": "float", "i32": "int", "bool": "bool"}[ty], n) for n, ty, _ in ut.params], (t, members)
