@@ -31,6 +31,18 @@ typedef float4 f4;
 #endif
 
 RF_DEV f4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// SCALAR BASE OF A VECTOR-MEMORY INSTRUCTION WRITTEN IN ASM.  On gfx9 a vector-memory instruction that reads an SGPR needs five
+// wait states behind a VECTOR instruction that wrote it (v_readlane, v_readfirstlane, v_cmp): hipcc's hazard recogniser inserts
+// them for its own instructions and cannot see into an asm statement.  A kernel short of scalar registers keeps some in the
+// lanes of a VGPR and reloads them with v_readlane right in front of their use -- in front of the asm, as far as hipcc knows --
+// and the memory instruction then issues with the STALE register pair: a wild address.  (Round 4 found it as a memory fault of
+// the 27- and 31-tap gaussians, the kernels with such reloads, the moment their launches claimed walk words; round 3's abort of
+// the same kernel, gpurun_out/r03/xcc_tests.log, has the same signature: DESIGN.md section 6.1c.)  Every such asm therefore copies
+// its base with s_mov_b64 first: a scalar read of the register is interlocked, and a scalar WRITE followed by the
+// memory instruction has no hazard.  tests/test_isa_invariants.py and tests/test_jit_isa.py check every global_* instruction
+// of every kernel for it.
+#define RF_SBASE "s_mov_b64 %[sb], %[base]\n\t"
 // four fmaf as two v_pk_fma_f32 (each lane-pair fma is still one single-rounding fmaf): a VALU
 // instruction costs the same issue slot packed or not, and the kernels are issue-sensitive
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -130,7 +142,8 @@ struct PxF32 {
         // two wait states after it issues, and hipcc's hazard recogniser, which would keep a VALU write to them away, cannot
         // see into an asm statement (scripts/fuzz_graphs.py seeds 7054 / 7063 / 7113: a run-time compiled fork/join kernel
         // scheduled such a write right behind the store -- a few thousand wrong texels per frame, different ones each run).
-        asm volatile("global_store_dwordx4 %0, %1, %2" RF_STORE_MOD "\n\ts_nop 1" ::"v"(xoff), "v"(d), "s"(row) : "memory");
+        unsigned long long sb;
+        asm volatile(RF_SBASE "global_store_dwordx4 %[off], %[data], %[sb]" RF_STORE_MOD "\n\ts_nop 1" : [sb] "=&s"(sb) : [off] "v"(xoff), [data] "v"(d), [base] "s"(row) : "memory");
     }
     RF_DEV static f4 requant(f4 v) { return v; }
 };
@@ -145,7 +158,8 @@ struct PxF32NT : PxF32 {
     {
         typedef float v4f __attribute__((ext_vector_type(4)));
         const v4f d = {v.x, v.y, v.z, v.w};
-        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(xoff), "v"(d), "s"(row) : "memory");      // the s_nop: see PxF32::store_row
+        unsigned long long sb;
+        asm volatile(RF_SBASE "global_store_dwordx4 %[off], %[data], %[sb] nt\n\ts_nop 1" : [sb] "=&s"(sb) : [off] "v"(xoff), [data] "v"(d), [base] "s"(row) : "memory");      // the s_nop: see PxF32::store_row
     }
 };
 
@@ -177,7 +191,8 @@ struct PxU8 {
     RF_DEV static void store_row(char* row, unsigned xoff, f4 v)       // wave-uniform row address: see PxF32::store_row
     {
         const unsigned d = pack(v);
-        asm volatile("global_store_dword %0, %1, %2" RF_STORE_MOD ::"v"(xoff), "v"(d), "s"(row) : "memory");
+        unsigned long long sb;
+        asm volatile(RF_SBASE "global_store_dword %[off], %[data], %[sb]" RF_STORE_MOD : [sb] "=&s"(sb) : [off] "v"(xoff), [data] "v"(d), [base] "s"(row) : "memory");
     }
     // what a store followed by a load of the next node does to a value: decode(pack(v)) without
     // the trip through the integer byte (the code is the same number either way)

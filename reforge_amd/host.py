@@ -252,10 +252,10 @@ class Graph:
     """PipelineGraph + its per-frame resources (src/vulkan/pipeline_graph.rs:43-57)."""
 
     def __init__(self, ctx, config, width, height, fmt=_lib.RF_FORMAT_RGBA32F, num_frames=1, flags=0,
-                 rows_per_chunk=0, conv_path=0, exec_flags=0, texels_per_lane=0):
+                 rows_per_chunk=0, conv_path=0, exec_flags=0, texels_per_lane=0, walk_unit=0):
         self.ctx, self.width, self.height, self.format = ctx, width, height, fmt
         self._h = C.c_void_p()
-        opt = _lib.GraphOptions(width, height, fmt, num_frames, flags, rows_per_chunk or 0, conv_path, exec_flags, texels_per_lane)
+        opt = _lib.GraphOptions(width, height, fmt, num_frames, flags, rows_per_chunk or 0, conv_path, exec_flags, texels_per_lane, walk_unit)
         _check(lib().rf_graph_create(ctx.handle, config.handle, C.byref(opt), C.byref(self._h)), "rf_graph_create")
         y0, y1 = C.c_int(), C.c_int()
         _check(lib().rf_graph_strip(self._h, C.byref(y0), C.byref(y1)), "rf_graph_strip")
@@ -378,6 +378,12 @@ class Graph:
         ms = C.c_float()
         _check(lib().rf_graph_time_launch(self._h, launch, iters, C.byref(ms)), "rf_graph_time_launch")
         return ms.value
+
+    def walks_taken(self, slot=0):
+        """how often a wave that had finished its rows took over part of another wave's walk (dynamic stream launches)"""
+        n = C.c_uint64()
+        _check(lib().rf_graph_walks_taken(self._h, slot, C.byref(n)), "rf_graph_walks_taken")
+        return n.value
 
     def time_launches(self, iters):
         """[(label, average ms)] of every launch over `iters` frames, hipEvent pairs on the launch's stream."""

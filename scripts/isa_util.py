@@ -37,3 +37,23 @@ def innermost_loops(body):
             seq += b[2]
         out.append((label, [x.strip() for x in seq if x.strip() and not x.strip().startswith((";", "."))]))
     return out
+
+
+def scalar_base_violations(instrs):
+    """instrs: instruction texts of one kernel in layout order.  On gfx9 a vector-memory instruction that reads an SGPR needs five
+    wait states behind a VECTOR instruction that wrote it (v_readlane reloading a spilled scalar, v_readfirstlane, v_cmp); hipcc
+    cannot see the global_* instructions the kernels issue from asm statements, so every one of them must take its scalar base
+    from an s_mov_b64 a few instructions in front of it INSIDE the same asm (RF_SBASE, rf_device.h).  Returns the instructions
+    that do not."""
+    bad = []
+    for k, ins in enumerate(instrs):
+        if not ins.startswith("global_"):
+            continue
+        m = re.search(r"(s\[\d+:\d+\])", ins)
+        if not m:
+            bad.append(ins + "   (no scalar base)")
+            continue
+        pair = m.group(1)
+        if not any(p.startswith("s_mov_b64 " + pair + ",") for p in instrs[max(0, k - 6):k]):
+            bad.append(ins)
+    return bad

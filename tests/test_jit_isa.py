@@ -20,6 +20,7 @@ from tests import util
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import isa_obj  # noqa: E402
+import isa_util  # noqa: E402
 
 pytestmark = pytest.mark.skipif(not rf.lib().rf_jit_available(), reason="libhiprtc cannot be loaded")
 
@@ -86,6 +87,8 @@ def test_run_time_compiled_kernels_keep_the_counted_wait_contract(compiled):
         assert "s_barrier" not in ops, name
         assert not any(o.startswith("scratch_") for o in ops), name                    # no spills
         assert not any(o.startswith(("global_load_dword", "buffer_load", "flat_")) and not o.startswith("global_load_lds") for o in ops), name
+        bad = isa_util.scalar_base_violations([i.text for i in ins])      # RF_SBASE, rf_device.h
+        assert not bad, (name, bad[:3])
         for k, i in enumerate(ins):
             if i.op.startswith("global_load_lds"):
                 assert any(p.op == "s_waitcnt" and "lgkmcnt(0)" in p.text for p in ins[max(0, k - 5):k]), (name, i.text)
