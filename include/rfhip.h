@@ -115,6 +115,13 @@ int rf_abi_version(void);
 /* [host] config::parse            src/config/config.rs:98-205
  *        expects_input = an input image exists (has_input_image, render.rs:46) */
 rf_status rf_config_parse(const char* text, int expects_input, rf_config** out);
+/* [host] the generated parser alone: `config_grammar::ExprListParser::new().parse(contents)`, src/config/config.rs:105
+ *        (grammar: src/config/config_grammar.lalrpop:7-81) -- the syntax tree of `text` as JSON,
+ *          {"exprs": [["pipeline", name, type, [[key, value], ...]] | ["graph", [[name, descriptor | null], ...]] | ["comment", text]]}
+ *        (parameters in source order, duplicates kept), written NUL-terminated to buf[0..cap); *len = its length without the
+ *        NUL (also when cap is too small: RF_ERR_INVALID, call again).  RF_ERR_CONFIG + rf_last_error for a text the
+ *        grammar rejects.  None of config::parse's own checks (empty text, 'output' never used ...) is applied. */
+rf_status rf_config_syntax(const char* text, char* buf, size_t cap, size_t* len);
 /* [host] config::single_shader_parse  src/config/config.rs:77-90
  *        `type_name` = the shader's file stem */
 rf_status rf_config_single(const char* type_name, int expects_input, rf_config** out);

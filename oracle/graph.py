@@ -72,8 +72,9 @@ def _lex(text):
     return toks
 
 
-def _parse_exprs(toks):
-    """ExprList (config_grammar.lalrpop:7-28): returns [('graph', members) | ('pipeline', name, type, params)]."""
+def _parse_exprs(toks, syntax=False):
+    """ExprList (config_grammar.lalrpop:7-28): returns [('graph', members) | ('pipeline', name, type, params)];
+    syntax: comments are kept as ('comment', text) and a pipeline's parameters are the [key, value] pairs in source order."""
     out, i, n = [], 0, len(toks)
 
     def need(kind, at):
@@ -87,6 +88,8 @@ def _parse_exprs(toks):
     while i < n:
         kind, val = toks[i]
         if kind in ("LCOMMENT", "BCOMMENT"):
+            if syntax:
+                out.append(("comment", val))
             i += 1
             continue
         name = need("STR", i)
@@ -97,7 +100,7 @@ def _parse_exprs(toks):
             i += 2
             if i < n and toks[i][0] in ("{", "{}"):
                 # PipelineField  name : type { k: v, ... } | {}     (:44-51)
-                params = {}
+                params, fields = {}, []
                 if toks[i][0] == "{}":
                     i += 1
                 else:
@@ -108,6 +111,7 @@ def _parse_exprs(toks):
                         if i + 2 >= n or toks[i + 2][0] not in ("INT", "DEC", "true", "false"):
                             raise ConfigError("bad parameter value")
                         params[key] = toks[i + 2][1]       # HashMap insert: last one wins
+                        fields.append([key, toks[i + 2][1]])
                         i += 3
                         if i < n and toks[i][0] == ",":
                             i += 1
@@ -115,7 +119,7 @@ def _parse_exprs(toks):
                         need("}", i)
                         i += 1
                         break
-                out.append(("pipeline", name, second, params))
+                out.append(("pipeline", name, second, fields if syntax else params))
                 continue
             desc = second
         # GraphExpr: at least two members joined by "->"                  (:30-42)
@@ -131,6 +135,21 @@ def _parse_exprs(toks):
             members.append((mname, mdesc))
         out.append(("graph", members))
     return out
+
+
+def parse_syntax(text):
+    """The generated parser alone (config.rs:105): {"exprs": [["pipeline", name, type, [[key, value], ...]] |
+    ["graph", [[name, descriptor | None], ...]] | ["comment", text]]}; ConfigError for a text the grammar rejects.
+    tests/test_grammar_fixtures.py holds it to vectors derived from the reference's grammar file."""
+    exprs = []
+    for e in _parse_exprs(_lex(text), syntax=True):
+        if e[0] == "pipeline":
+            exprs.append(["pipeline", e[1], e[2], e[3]])
+        elif e[0] == "graph":
+            exprs.append(["graph", [[n, d] for n, d in e[1]]])
+        else:
+            exprs.append(["comment", e[1]])
+    return {"exprs": exprs}
 
 
 class Config:

@@ -57,6 +57,7 @@ SIGNATURES = {
     "rf_abi_version": (_i, []),
     "rf_config_parse": (_i, [_cp, _i, _pvp]),
     "rf_config_single": (_i, [_cp, _i, _pvp]),
+    "rf_config_syntax": (_i, [_cp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rf_config_destroy": (None, [_vp]),
     "rf_config_num_nodes": (_i, [_vp]),
     "rf_config_node_name": (_cp, [_vp, _i]),

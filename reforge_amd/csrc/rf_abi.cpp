@@ -51,6 +51,17 @@ extern "C" rf_status rf_config_parse(const char* text, int expects_input, rf_con
     return RF_OK;
 }
 
+extern "C" rf_status rf_config_syntax(const char* text, char* buf, size_t cap, size_t* len)
+{
+    if (!text || !len || (!buf && cap)) return fail(RF_ERR_INVALID, "rf_config_syntax: null argument");
+    std::string json, err;
+    if (!parse_syntax(text, json, err)) return fail(RF_ERR_CONFIG, err);
+    *len = json.size();
+    if (json.size() + 1 > cap) return fail(RF_ERR_INVALID, "rf_config_syntax: the buffer is too small");
+    std::memcpy(buf, json.c_str(), json.size() + 1);
+    return RF_OK;
+}
+
 extern "C" rf_status rf_config_single(const char* type_name, int expects_input, rf_config** out)
 {
     if (!type_name || !out) return fail(RF_ERR_INVALID, "rf_config_single: null argument");

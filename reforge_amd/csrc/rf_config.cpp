@@ -2,6 +2,7 @@
 #include "rf_config.h"
 
 #include <cctype>
+#include <cstdio>
 #include <cstring>
 
 namespace rf {
@@ -142,9 +143,12 @@ bool lex(const std::string& s, std::vector<Token>& out, std::string& err)
 struct AstPipeline {
     std::string name, pipeline_type;
     std::map<std::string, std::string> parameters;
+    std::vector<std::pair<std::string, std::string>> fields;   // the same in source order, duplicates kept (parse_syntax)
 };
 struct AstExpr {
     bool is_graph = false;
+    bool is_comment = false;                                  // Expr::Ignore: kept only when the parser is asked to (parse_syntax)
+    std::string comment;
     std::vector<std::pair<std::string, std::string>> graph;   // (name, descriptor); "" = None
     std::vector<bool> has_desc;
     AstPipeline pipeline;
@@ -155,6 +159,7 @@ struct Parser {
     const std::vector<Token>& t;
     size_t i = 0;
     std::string err;
+    bool keep_comments = false;
 
     bool fail_at(size_t at, const char* expected)
     {
@@ -180,7 +185,16 @@ struct Parser {
             return false;
         }
         while (i < t.size()) {
-            if (t[i].kind == T_LINE_COMMENT || t[i].kind == T_BLOCK_COMMENT) { ++i; continue; }   // Expr::Ignore
+            if (t[i].kind == T_LINE_COMMENT || t[i].kind == T_BLOCK_COMMENT) {   // Expr::Ignore
+                if (keep_comments) {
+                    AstExpr c;
+                    c.is_comment = true;
+                    c.comment = t[i].text;
+                    out.push_back(c);
+                }
+                ++i;
+                continue;
+            }
             if (!need(T_STR, i)) return false;
             std::string name = t[i].text;
             ++i;
@@ -204,6 +218,7 @@ struct Parser {
                             if (!(peek(T_INT, i + 2) || peek(T_DEC, i + 2) || peek(T_TRUE, i + 2) || peek(T_FALSE, i + 2)))
                                 return fail_at(i + 2, "'[0-9]+', '-?[0-9]+\\.[0-9]+', 'true', 'false'");
                             e.pipeline.parameters[t[i].text] = t[i + 2].text;   // HashMap::insert: the last one wins
+                            e.pipeline.fields.push_back({t[i].text, t[i + 2].text});
                             i += 3;
                             if (peek(T_COMMA, i)) { ++i; continue; }
                             if (!need(T_RBRACE, i)) return false;
@@ -308,6 +323,72 @@ bool parse_config(const std::string& text, bool expects_input, Config& config, s
         err = "'output' is never used in the pipeline configuration";
         return false;
     }
+    return true;
+}
+
+// The syntax tree of a config text as JSON -- what LALRPOP's parser hands config::parse (config.rs:105), before any of its
+// checks: {"exprs": [["pipeline", name, type, [[key, value], ...]] | ["graph", [[name, descriptor | null], ...]] |
+// ["comment", text]]}, parameters in source order with duplicates.  tests/test_grammar_fixtures.py holds it to vectors derived
+// from the reference's grammar file itself (tests/golden/make_grammar_fixtures.py).
+static void json_string(const std::string& s, std::string& out)
+{
+    out += '"';
+    for (unsigned char c : s) {
+        if (c == '"' || c == '\\') { out += '\\'; out += (char)c; }
+        else if (c < 0x20) { char b[8]; std::snprintf(b, sizeof(b), "\\u%04x", c); out += b; }
+        else out += (char)c;
+    }
+    out += '"';
+}
+
+bool parse_syntax(const std::string& text, std::string& json, std::string& err)
+{
+    std::vector<Token> toks;
+    if (!lex(text, toks, err)) return false;
+    std::vector<AstExpr> exprs;
+    Parser p{text, toks, 0, std::string(), true};
+    if (!p.parse(exprs)) {
+        err = p.err;
+        return false;
+    }
+    json = "{\"exprs\":[";
+    for (size_t k = 0; k < exprs.size(); ++k) {
+        const AstExpr& e = exprs[k];
+        if (k) json += ',';
+        if (e.is_comment) {
+            json += "[\"comment\",";
+            json_string(e.comment, json);
+            json += ']';
+        } else if (e.is_graph) {
+            json += "[\"graph\",[";
+            for (size_t m = 0; m < e.graph.size(); ++m) {
+                if (m) json += ',';
+                json += '[';
+                json_string(e.graph[m].first, json);
+                json += ',';
+                if (e.has_desc[m]) json_string(e.graph[m].second, json);
+                else json += "null";
+                json += ']';
+            }
+            json += "]]";
+        } else {
+            json += "[\"pipeline\",";
+            json_string(e.pipeline.name, json);
+            json += ',';
+            json_string(e.pipeline.pipeline_type, json);
+            json += ",[";
+            for (size_t m = 0; m < e.pipeline.fields.size(); ++m) {
+                if (m) json += ',';
+                json += '[';
+                json_string(e.pipeline.fields[m].first, json);
+                json += ',';
+                json_string(e.pipeline.fields[m].second, json);
+                json += ']';
+            }
+            json += "]]";
+        }
+    }
+    json += "]}";
     return true;
 }
 

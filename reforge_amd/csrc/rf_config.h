@@ -45,6 +45,9 @@ struct Config {
 // after a warnln!.
 bool parse_config(const std::string& text, bool expects_input, Config& out, std::string& err);
 
+// the syntax tree alone, as JSON (rf_config.cpp): what the generated parser returns at config.rs:105
+bool parse_syntax(const std::string& text, std::string& json, std::string& err);
+
 // config::single_shader_parse, config.rs:77-90
 bool single_node_config(const std::string& type_name, bool expects_input, Config& out, std::string& err);
 

@@ -59,6 +59,25 @@ def registry_binding(type_name, descriptor):
     return lib().rf_registry_binding(type_name.encode(), descriptor.encode())
 
 
+def config_syntax(text):
+    """The syntax tree of a config text ({"exprs": [...]}, see rf_config_syntax in include/rfhip.h) -- the generated parser
+    of src/config/config.rs:105 alone; raises RfError (status 2) for a text the grammar rejects."""
+    import json
+    if "\x00" in text:      # the C ABI takes NUL-terminated text; the grammar has no token for a NUL (the reference: InvalidToken)
+        raise ValueError("a config text cannot hold a NUL character")
+    raw = text.encode("utf-8")
+    cap = 4 * len(raw) + 256
+    while True:
+        buf = C.create_string_buffer(cap)
+        n = C.c_size_t()
+        st = lib().rf_config_syntax(raw, buf, cap, C.byref(n))
+        if st == 1 and n.value + 1 > cap:
+            cap = n.value + 1
+            continue
+        _check(st, "rf_config_syntax")
+        return json.loads(buf.raw[:n.value].decode("utf-8"))
+
+
 def set_shader_path(path):
     """Directory searched for {type}.stage.hip when a config names a type the built-in registry lacks (config.rs:59-75)."""
     _check(lib().rf_set_shader_path(os.fsencode(path) if path else b""), "rf_set_shader_path")
