@@ -559,6 +559,7 @@ def main():
         # a rehearsal (all ranks on one GPU) can only exchange through the RCCL test double (RF_RCCL_LIBRARY): over-fetch unless asked
         halo = args.halo or ("overfetch" if args.rehearse else "both")
         modes = {"both": ["overfetch", "exchange"], "overfetch": ["overfetch"], "exchange": ["exchange"]}[halo]
+    requested_modes = list(modes)
     comm_info = None
     ctx_plain = rf.Context(local_rank, rank, world, None) if world > 1 else rf.Context(local_rank)
     ctx_rccl, rccl_error = None, None
@@ -760,6 +761,8 @@ def main():
             out.update(comm_info)
         if rccl_error:
             out["rccl_error"] = rccl_error
+            if "exchange" in requested_modes and "exchange" not in legs:
+                out["halo"]["exchange"] = {"error": rccl_error}      # the mode that was asked for and did not work: never silently replaced
     g.close()
 
     # ---- N > 1: BASELINE configs[3], 16384^2 as N row strips (strong scaling) ---------------------
@@ -848,22 +851,30 @@ def main():
         if not args.skip_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
     if poisoned:
-        # do not tear down a communicator with a collective possibly stuck on it: print the line and leave at once
+        # An exchange was started and failed: the mode the caller asked for did NOT work, whatever substitute headline the
+        # line carries.  Say so in the line (`exchange_failed`, the error under halo.exchange), do not tear down a communicator
+        # with a collective possibly stuck on it, and leave with a status the launcher cannot mistake for success.
+        out["exchange_failed"] = True
         if rank == 0:
             print(json.dumps(out), flush=True)
         if dist is not None:
             dist.barrier()
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(3)
     if ctx_rccl is not None:
         ctx_rccl.close()
     ctx_plain.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    failed = world > 1 and bool(rccl_error) and "exchange" in requested_modes      # (no communicator: nothing can be stuck, the teardown above was safe)
+    if failed:
+        out["exchange_failed"] = True
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -124,7 +124,7 @@ def test_srgb_strips(fake_rccl_dir, tmp_path):
         assert got.tobytes() == ref.download_srgb8().tobytes()
 
 
-def _bench_rehearsal(fake_dir, port, fail):
+def _bench_rehearsal(fake_dir, port, fail, expect_rc=0):
     """bench.py as the driver launches it for N = 2, rehearsed on one GPU: both ranks on device 0, gloo for the bench's own
     collectives, the halo exchange through the RCCL test double (RF_RCCL_LIBRARY: torch has mapped its own librccl.so.1)."""
     env = dict(os.environ, RF_RCCL_LIBRARY=os.path.join(fake_dir, "librccl.so.1"), MASTER_ADDR="127.0.0.1")
@@ -133,7 +133,7 @@ def _bench_rehearsal(fake_dir, port, fail):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse", "--halo", "both", "--skip-cpu-baseline"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert (p.returncode == 0) if expect_rc == 0 else (p.returncode != 0), (p.returncode, p.stderr[-3000:])
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     return json.loads(lines[0])
@@ -149,8 +149,9 @@ def test_bench_two_ranks_times_both_halo_schedules(fake_rccl_dir):
 
 def test_bench_survives_a_failing_exchange(fake_rccl_dir):
     """The first real RCCL exchange between GPUs happens on the driver's node: if it fails, every rank must drop the exchange
-    leg together and the run must still print its line (the over-fetch number) and exit 0."""
-    out = _bench_rehearsal(fake_rccl_dir, 29542, fail=True)
-    assert out["n_gpus"] == 2 and out["halo"]["value_is"] == "overfetch" and "exchange" not in out["halo"]
-    assert out["rccl_error"], out
+    leg together and the run must still print its line (the over-fetch number) -- marked `exchange_failed`, the error under
+    halo.exchange -- and leave with a NON-ZERO status: the mode that was asked for did not work."""
+    out = _bench_rehearsal(fake_rccl_dir, 29542, fail=True, expect_rc=3)
+    assert out["n_gpus"] == 2 and out["halo"]["value_is"] == "overfetch"
+    assert out["exchange_failed"] is True and out["halo"]["exchange"]["error"] == out["rccl_error"] and out["rccl_error"], out
     assert out["value"] > 0 and "overfetch" in out["strong_16k"]
