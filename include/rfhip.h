@@ -312,6 +312,12 @@ rf_status rf_graph_create(rf_ctx* ctx, const rf_config* cfg, const rf_graph_opti
 void      rf_graph_destroy(rf_graph* g);
 /* [host view] the plan the graph was built from (owned by the graph) */
 const rf_plan* rf_graph_plan(const rf_graph* g);
+/* [host] what rf_graph_create has to say about a graph it ACCEPTED ("" = nothing): "catalogue-only fusion: <why>" when a fused
+ *        chain could not be compiled and the graph was planned again in pieces, "... spills N bytes per lane" for a user stage
+ *        whose apply() needs scratch memory (it runs -- the reference runs every shader that compiles, src/vulkan/shader.rs:29-93 --
+ *        only slower).  The reference's counterpart is a warnln! beside a graph that keeps running (src/render.rs:121-136).
+ *        Owned by the graph. */
+const char* rf_graph_note(const rf_graph* g);
 /* rows [y0,y1) of the frame this rank holds (whole frame when world == 1) */
 rf_status rf_graph_strip(const rf_graph* g, int* y0, int* y1);
 

@@ -150,6 +150,7 @@ SIGNATURES = {
     "rf_graph_time_launch": (_i, [_vp, _i, _i, _pf]),
     "rf_graph_time_launches": (_i, [_vp, _i, _pf, _i]),
     "rf_graph_walks_taken": (_i, [_vp, _i, C.POINTER(C.c_uint64)]),
+    "rf_graph_note": (C.c_char_p, [_vp]),
     "rf_comm_selftest": (_i, [_i, _sz]),
     "rf_ctx_copy_bandwidth": (_i, [_vp, _sz, _i, _pf]),
 }

@@ -281,8 +281,9 @@ constexpr int kCvLanesX = kCvStripW / kCvT;     // 16
 constexpr int kCvLanesY = 64 / kCvLanesX;       // 4 rows per wave (of the default <8 columns, 8 waves> shape)
 static_assert(kCvLanesY * 8 == 32, "eight waves cover a 32-row step");
 
-// CT output columns per lane, WAVES waves per workgroup: <8, 8> = 16 column groups x 4 rows per wave, two waves per SIMD (the
-// default); <4, 16> = 32 column groups x 2 rows per wave, FOUR waves per SIMD on the same 32-row step and the same ring (RF_CONV_PATH=4)
+// CT output columns per lane, WAVES waves per workgroup: <8, 8> = 16 column groups x 4 rows per wave, two waves per SIMD, is the
+// one shape instantiated.  (<4, 16> = 32 column groups x 2 rows per wave, FOUR waves per SIMD on the same 32-row step and the same
+// ring, was measured 7 % slower -- profiles/r03_conv_four_waves_probe.txt -- and is not built; conv_path takes 0..3 only.)
 template <class Px, int K, int CT = kCvT, int WAVES = 8>   // K is compile-time: the tap loop unrolls completely, the register window rotates by renaming
 __global__ __launch_bounds__(64 * WAVES) void conv2d_valu_kernel(const char* src, size_t src_pitch, char* dst, size_t dst_pitch,
                                                           int W, int row_lo, int row_hi, int y0, int y1, int rows_per_chunk,

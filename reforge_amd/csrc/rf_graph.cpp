@@ -544,6 +544,7 @@ static void read_tuning(rf_graph* g)
     g->force_split = (opt.exec_flags & RF_EXEC_FORCE_SPLIT) != 0;
     if (const char* e = std::getenv("RF_ROWS_PER_CHUNK")) g->tune.rows_per_chunk = std::atoi(e);
     if (const char* e = std::getenv("RF_CONV_PATH")) g->tune.conv_path = std::atoi(e);
+    if (g->tune.conv_path < 0 || g->tune.conv_path > 3) g->tune.conv_path = -1;      // refused by rf_graph_create (RF_ERR_INVALID): there is no such kernel
     if (const char* e = std::getenv("RF_TEXELS_PER_LANE")) g->tune.texels_per_lane = std::atoi(e);
     if (const char* e = std::getenv("RF_SYNC_LAUNCHES")) g->sync_launches = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_CONCURRENT_LAYERS")) g->concurrent_layers = std::atoi(e) != 0;
@@ -575,6 +576,7 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
     g->plan.index();
     HIP_TRY(hipSetDevice(ctx->device));
     read_tuning(g);
+    if (g->tune.conv_path < 0) return fail(RF_ERR_INVALID, "rf_graph_create: conv_path must be 0 (auto), 1 (LDS tile), 2 (MFMA band) or 3 (VALU)");
     // Kernels of fused chains the ahead-of-time catalogue lacks are compiled HERE, where the reference compiles its
     // shaders (PipelineGraph::new -> Pipeline::new_compute, pipeline_graph.rs:509-545), never on the frame path.  If a
     // chain cannot be compiled (no libhiprtc, or the compiler rejects it) the graph is planned again with
@@ -593,7 +595,9 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
                 continue;
             }
             if (user_only ? !has_user : (ops.size() < 2 && !has_user)) continue;      // single built-in nodes are in the catalogue
-            if (!stream_prepare(opt.format, ops.data(), (int)ops.size(), opt.width, Hs1 - Hs0, g->tune, d.result_only && g->nt_stores, jerr)) return false;
+            std::string note;
+            if (!stream_prepare(opt.format, ops.data(), (int)ops.size(), opt.width, Hs1 - Hs0, g->tune, d.result_only && g->nt_stores, jerr, &note)) return false;
+            if (!note.empty()) g->jit_note += (g->jit_note.empty() ? "" : "; ") + note;
         }
         return true;
     };
@@ -1288,6 +1292,8 @@ extern "C" rf_status rf_graph_time_each_frame(rf_graph* g, int iters, float* ms_
         if (e) (void)hipEventDestroy(e);
     return st;
 }
+
+extern "C" const char* rf_graph_note(const rf_graph* g) { return g ? g->jit_note.c_str() : ""; }
 
 extern "C" rf_status rf_graph_walks_taken(rf_graph* g, int frame_slot, uint64_t* count)
 {

@@ -394,13 +394,17 @@ const JitKernel* jit_lookup(int fmt, int pf, int texels, const StageList& sl)
 {
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_loaded.find(loaded_key(name_expression(fmt, pf, texels, sl)));
-    return it == g_loaded.end() ? nullptr : &it->second;
+    return it == g_loaded.end() || it->second.disabled ? nullptr : &it->second;
 }
 
+// The entry STAYS (g_loaded never erases: jit_lookup hands out pointers into it, and an erased entry would be compiled and its
+// module loaded again by the next graph that plans the same chain -- one leaked module per graph creation in a live-reload loop);
+// it is only marked, jit_lookup no longer returns it and load_expr finds it present.
 void jit_forget(int fmt, int pf, int texels, const StageList& sl)
 {
     std::lock_guard<std::mutex> lock(g_mu);
-    g_loaded.erase(loaded_key(name_expression(fmt, pf, texels, sl)));      // the module stays loaded; the kernel is simply never looked up again
+    auto it = g_loaded.find(loaded_key(name_expression(fmt, pf, texels, sl)));
+    if (it != g_loaded.end()) it->second.disabled = true;
 }
 
 hipError_t jit_launch(const JitKernel& k, unsigned grid, unsigned block, void* args, size_t size, hipStream_t stream)

@@ -19,6 +19,7 @@ struct JitKernel {
     int texels = 1;
     int resident_workgroups = 512;    // workgroups of this kernel the chip holds at once (occupancy query)
     int vgprs = 0, scratch_bytes = 0;
+    bool disabled = false;            // jit_forget: an optional variant that turned out to spill -- kept loaded, never looked up again
 };
 
 // libhiprtc can be loaded and RF_NO_JIT is not set (host only: no device needed to ask, nor to compile)

@@ -119,7 +119,8 @@ bool stream_jit_admissible(const StageList& sl);
 // (allow_jit) it can be compiled when the graph is created
 bool stream_supported(const Op* ops, int n, bool allow_jit);
 // rf_graph_create: make the kernel of a fused launch available (compiles it if the catalogue lacks it); false + err if it cannot
-bool stream_prepare(int fmt, const Op* ops, int n, int W, int rows, const StreamTuning& tune, bool nt_store, std::string& err);
+// (*note: something worth telling the caller about a kernel that WAS accepted -- a single user stage that spills)
+bool stream_prepare(int fmt, const Op* ops, int n, int W, int rows, const StreamTuning& tune, bool nt_store, std::string& err, std::string* note = nullptr);
 // horizontal / vertical halo a fused pipeline reads beyond its output
 int  ops_radius(const Op* ops, int n);
 

@@ -398,6 +398,11 @@ class Graph:
         _check(lib().rf_graph_time_launch(self._h, launch, iters, C.byref(ms)), "rf_graph_time_launch")
         return ms.value
 
+    @property
+    def note(self):
+        """what rf_graph_create had to say about this graph ("" = nothing): catalogue-only fusion, a user stage that spills"""
+        return _s(lib().rf_graph_note(self._h))
+
     def walks_taken(self, slot=0):
         """how often a wave that had finished its rows took over part of another wave's walk (dynamic stream launches)"""
         n = C.c_uint64()

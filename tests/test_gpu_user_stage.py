@@ -165,3 +165,57 @@ def test_user_stage_on_a_large_frame_as_strips_of_chunks(ctx, stage_dir):
     a = util.run_hip(ctx, text, x)
     b = util.run_hip(ctx, text, x, flags=rf.RF_GRAPH_NO_FUSION)
     util.assert_same(a, b, "fused vs unfused at 1080p")
+
+
+LUT_STAGE = """// a point op that indexes a LOCAL ARRAY with a value only the run knows: the array cannot live in registers
+struct Params { float gain; int shift; };
+static constexpr int RADIUS = 0;
+RF_STAGE f4 apply(const Params& p, f4 c)
+{
+    float t[64];
+    for (int i = 0; i < 64; ++i) t[i] = (c.x * (float)i) * p.gain;
+    const int k = ((int)(c.y * 63.0f) + p.shift) & 63;
+    return make_float4(t[k], c.y, c.z, c.w);
+}
+"""
+
+
+def test_a_user_stage_that_needs_scratch_memory_still_runs(ctx, stage_dir):
+    """stream_prepare refused every run-time compiled kernel with scratch, so a valid stage file whose apply() indexes
+    a local array at run time made rf_graph_create fail -- the reference runs every shader that compiles (shader.rs:29-93).  A
+    launch that is ONE user stage is now kept whatever it spills (rf_graph_note says so); only fused chains are cut on a spill."""
+    (stage_dir / "lut.stage.hip").write_text(LUT_STAGE)
+    text = "input -> lut -> output\nlut: lut { gain: 0.5, shift: 3 }"
+    W, H = 211, 37
+    x = util.synthetic(W, H, util.F32, seed=41)
+    g = rf.Graph(ctx, rf.Config(text), W, H, util.F32)
+    try:
+        assert g.note == "" or "spills" in g.note, g.note
+        g.upload_raw(x)
+        g.execute()
+        g.wait()
+        got = g.download_raw()
+    finally:
+        g.close()
+    k = (((x[..., 1] * np.float32(63.0)).astype(np.int32) + 3) & 63).astype(np.float32)
+    want = x.copy()
+    want[..., 0] = (x[..., 0] * k) * np.float32(0.5)
+    util.assert_same(got, want, "lut stage")
+    # fused behind a built-in node the chain is either one launch or, when the fused kernel spills, cut -- the result is the same
+    text2 = "input -> gg -> lut -> output\ngg: colour_grade { slope: 1.0, offset: 0.0, saturation: 1.0 }\nlut: lut { gain: 0.5, shift: 3 }"
+    g = rf.Graph(ctx, rf.Config(text2), W, H, util.F32)
+    try:
+        g.upload_raw(x)
+        g.execute()
+        g.wait()
+        got2 = g.download_raw()
+    finally:
+        g.close()
+    ref = rf.Graph(ctx, rf.Config(text2), W, H, util.F32, flags=rf.RF_GRAPH_NO_FUSION)
+    try:
+        ref.upload_raw(x)
+        ref.execute()
+        ref.wait()
+        util.assert_same(got2, ref.download_raw(), "lut stage fused vs unfused")
+    finally:
+        ref.close()
