@@ -78,11 +78,6 @@ typedef struct rf_graph  rf_graph;   /* PipelineGraph + its frames  pipeline_gra
                                            exchange (how the multi-rank split is tested on one GPU) */
 #define RF_EXEC_NO_ALTERNATE      0x8u  /* every chunk walks top-down (default: chosen per launch)      */
 #define RF_EXEC_ALTERNATE         0x20u /* odd chunks walk bottom-up (halo rows shared through L2)      */
-#define RF_EXEC_STATIC_WALKS      0x40u /* stream launches keep the static schedule: every wave walks the
-                                           chunk its workgroup index names and leaves (env RF_STEAL=0)  */
-#define RF_EXEC_DYNAMIC_WALKS     0x80u /* every stream launch runs with walk words -- waves whose walk is
-                                           over take the far half of the longest unfinished one -- not only
-                                           the launches large enough to gain by it (env RF_STEAL=2)     */
 
 typedef struct rf_graph_options {
     int       width;        /* RenderInfo.width   src/render.rs:40 */
@@ -96,9 +91,6 @@ typedef struct rf_graph_options {
     uint32_t  exec_flags;     /* RF_EXEC_* */
     int       texels_per_lane;/* stream kernels, rgba32f: 0 auto, 1 = 64-wide strips, 2 = 128-wide
                                  (env RF_TEXELS_PER_LANE)                                         */
-    /* RF_ABI_VERSION >= 3 */
-    int       walk_unit;      /* rows per unit of a dynamic walk, >= 8 (env RF_STEAL_UNIT); 0 = max(8, twice
-                                 the launch's vertical halo)                                      */
 } rf_graph_options;
 
 /* ------------------------------------------------------------------------- */
@@ -386,11 +378,6 @@ rf_status rf_graph_time_launches(rf_graph* g, int iters, float* avg_ms, int n);
  * milliseconds of frame i (SURVEY.md 8d asks for median and min next to the mean; the
  * marker packets cost ~2 us per frame, so the mean of these is above rf_graph_time_frames) */
 rf_status rf_graph_time_each_frame(rf_graph* g, int iters, float* ms_each);
-/* dynamic walks (RF_EXEC_DYNAMIC_WALKS and the library's own choice for large launches; no reference counterpart): how many
- * times, since the graph was created, a wave of a stream launch of frame slot `frame_slot` that had finished its rows took
- * over the far half of another wave's unfinished walk.  Synchronises the slot.  Tests use it to show that the schedule they
- * ran was really dynamic; bench.py reports it per workload. */
-rf_status rf_graph_walks_taken(rf_graph* g, int frame_slot, uint64_t* count);
 /* one-rank RCCL round trip (communicator of world 1, grouped send+recv to self of
  * `bytes` bytes on `device`): librccl loads and is called with the right ABI */
 rf_status rf_comm_selftest(int device, size_t bytes);

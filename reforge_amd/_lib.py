@@ -35,8 +35,6 @@ RF_EXEC_CONCURRENT_LAYERS = 0x2
 RF_EXEC_FORCE_SPLIT = 0x4
 RF_EXEC_NO_ALTERNATE = 0x8
 RF_EXEC_ALTERNATE = 0x20
-RF_EXEC_STATIC_WALKS = 0x40
-RF_EXEC_DYNAMIC_WALKS = 0x80
 
 RF_CONV_AUTO, RF_CONV_TILE, RF_CONV_MFMA, RF_CONV_VALU = 0, 1, 2, 3
 
@@ -45,7 +43,7 @@ class GraphOptions(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("format", C.c_int),
                 ("num_frames", C.c_int), ("flags", C.c_uint32),
                 ("rows_per_chunk", C.c_int), ("conv_path", C.c_int), ("exec_flags", C.c_uint32),
-                ("texels_per_lane", C.c_int), ("walk_unit", C.c_int)]
+                ("texels_per_lane", C.c_int)]
 
 
 _vp, _cp, _i, _sz, _u32, _f = C.c_void_p, C.c_char_p, C.c_int, C.c_size_t, C.c_uint32, C.c_float
@@ -149,7 +147,6 @@ SIGNATURES = {
     "rf_graph_time_each_frame": (_i, [_vp, _i, _pf]),
     "rf_graph_time_launch": (_i, [_vp, _i, _i, _pf]),
     "rf_graph_time_launches": (_i, [_vp, _i, _pf, _i]),
-    "rf_graph_walks_taken": (_i, [_vp, _i, C.POINTER(C.c_uint64)]),
     "rf_graph_note": (C.c_char_p, [_vp]),
     "rf_comm_selftest": (_i, [_i, _sz]),
     "rf_ctx_copy_bandwidth": (_i, [_vp, _sz, _i, _pf]),

@@ -37,12 +37,13 @@ RF_DEV f4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 // them for its own instructions and cannot see into an asm statement.  A kernel short of scalar registers keeps some in the
 // lanes of a VGPR and reloads them with v_readlane right in front of their use -- in front of the asm, as far as hipcc knows --
 // and the memory instruction then issues with the STALE register pair: a wild address.  (Round 4 found it as a memory fault of
-// the 27- and 31-tap gaussians, the kernels with such reloads, the moment their launches claimed walk words; round 3's abort of
-// the same kernel, gpurun_out/r03/xcc_tests.log, has the same signature: DESIGN.md section 6.1c.)  Every such asm therefore copies
-// its base with s_mov_b64 first: a scalar read of the register is interlocked, and a scalar WRITE followed by the
-// memory instruction has no hazard.  tests/test_isa_invariants.py and tests/test_jit_isa.py check every global_* instruction
-// of every kernel for it.
-#define RF_SBASE "s_mov_b64 %[sb], %[base]\n\t"
+// the 27- and 31-tap gaussians, the kernels with such reloads, as soon as their walk carried more scalar state; round 3's abort
+// of the same kernel, gpurun_out/r03/xcc_tests.log, has the same signature: DESIGN.md 6.1c, profiles/r04_sgpr_hazard_repro.txt.)
+// Every such asm therefore copies its base into VCC first and addresses through VCC: a SCALAR read of the register is
+// interlocked, a scalar write followed by the memory instruction has no hazard, and VCC costs no register (a pair of the
+// kernel's own, tried first, cost the 16384^2 5-stage launch 1.4 %: profiles/r04_static_path_ab.txt).
+// tests/test_isa_invariants.py and tests/test_jit_isa.py check every global_* instruction of every kernel for it.
+#define RF_SBASE "s_mov_b64 vcc, %[base]\n\t"
 // four fmaf as two v_pk_fma_f32 (each lane-pair fma is still one single-rounding fmaf): a VALU
 // instruction costs the same issue slot packed or not, and the kernels are issue-sensitive
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -142,8 +143,7 @@ struct PxF32 {
         // two wait states after it issues, and hipcc's hazard recogniser, which would keep a VALU write to them away, cannot
         // see into an asm statement (scripts/fuzz_graphs.py seeds 7054 / 7063 / 7113: a run-time compiled fork/join kernel
         // scheduled such a write right behind the store -- a few thousand wrong texels per frame, different ones each run).
-        unsigned long long sb;
-        asm volatile(RF_SBASE "global_store_dwordx4 %[off], %[data], %[sb]" RF_STORE_MOD "\n\ts_nop 1" : [sb] "=&s"(sb) : [off] "v"(xoff), [data] "v"(d), [base] "s"(row) : "memory");
+        asm volatile(RF_SBASE "global_store_dwordx4 %[off], %[data], vcc" RF_STORE_MOD "\n\ts_nop 1" ::[off] "v"(xoff), [data] "v"(d), [base] "s"(row) : "memory", "vcc");
     }
     RF_DEV static f4 requant(f4 v) { return v; }
 };
@@ -158,8 +158,7 @@ struct PxF32NT : PxF32 {
     {
         typedef float v4f __attribute__((ext_vector_type(4)));
         const v4f d = {v.x, v.y, v.z, v.w};
-        unsigned long long sb;
-        asm volatile(RF_SBASE "global_store_dwordx4 %[off], %[data], %[sb] nt\n\ts_nop 1" : [sb] "=&s"(sb) : [off] "v"(xoff), [data] "v"(d), [base] "s"(row) : "memory");      // the s_nop: see PxF32::store_row
+        asm volatile(RF_SBASE "global_store_dwordx4 %[off], %[data], vcc nt\n\ts_nop 1" ::[off] "v"(xoff), [data] "v"(d), [base] "s"(row) : "memory", "vcc");      // the s_nop: see PxF32::store_row
     }
 };
 
@@ -191,8 +190,7 @@ struct PxU8 {
     RF_DEV static void store_row(char* row, unsigned xoff, f4 v)       // wave-uniform row address: see PxF32::store_row
     {
         const unsigned d = pack(v);
-        unsigned long long sb;
-        asm volatile(RF_SBASE "global_store_dword %[off], %[data], %[sb]" RF_STORE_MOD : [sb] "=&s"(sb) : [off] "v"(xoff), [data] "v"(d), [base] "s"(row) : "memory");
+        asm volatile(RF_SBASE "global_store_dword %[off], %[data], vcc" RF_STORE_MOD ::[off] "v"(xoff), [data] "v"(d), [base] "s"(row) : "memory", "vcc");
     }
     // what a store followed by a load of the next node does to a value: decode(pack(v)) without
     // the trip through the integer byte (the code is the same number either way)

@@ -105,10 +105,6 @@ rf_status fail(rf_status st, const std::string& msg)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// walk words of one stream launch in one frame slot (rf_stream_dev.h, "Walk words"): a 128-byte line per (workgroup, wave) --
-// 8 188 workgroups; a launch that would need more keeps the static schedule
-constexpr size_t kWalkWordBytes = (size_t)4 << 20;
-
 // Row pitch of a device image.  EXPERIMENT (RF_PITCH_PAD = bytes added to every row): how the pitch maps rows onto the HBM
 // channels decides how well a column-strip walk streams (scripts/walk_probe.py, profiles/r03_pitch_*).
 size_t image_pitch(size_t row_bytes)
@@ -245,7 +241,7 @@ static hipError_t launch_user_node(rf_graph* g, const Launch& L, FrameSlot& f, c
 }
 
 // the kernel(s) of one launch over output rows [y0, y1) of `geo`
-rf_status launch_rows(rf_graph* g, FrameSlot& f, const Launch& L, Geom geo, int y0, int y1, hipStream_t stream, bool main_part = true)
+rf_status launch_rows(rf_graph* g, FrameSlot& f, const Launch& L, Geom geo, int y0, int y1, hipStream_t stream)
 {
     if (y1 <= y0) return RF_OK;
     geo.y0 = y0;
@@ -262,16 +258,8 @@ rf_status launch_rows(rf_graph* g, FrameSlot& f, const Launch& L, Geom geo, int 
         HIP_TRY(launch_mix(g->opt.format, f.images.at(L.src[0]).view(), f.images.at(L.src[1]).view(), dst.view(), geo,
                            L.ops[0].slope, stream));
     } else {
-        // the walk words of this launch in this frame slot (rf_stream_dev.h, "Walk words"): the launch's main part only -- the
-        // boundary slivers of a split launch are a few rows, and two kernels must never share the words
-        StreamTuning tune = g->tune;
-        const size_t li = (size_t)(&L - g->launches.data());
-        if (main_part && li < f.walk_words.size() && f.walk_words[li]) {
-            tune.steal_ws = f.walk_words[li];
-            tune.steal_ws_bytes = kWalkWordBytes;
-        }
         HIP_TRY(launch_ops(g->opt.format, L.ops.data(), (int)L.ops.size(), f.images.at(L.src[0]).view(), dst.view(), geo,
-                           tune, stream));
+                           g->tune, stream));
     }
     return RF_OK;
 }
@@ -316,14 +304,14 @@ rf_status run_launch(rf_graph* g, FrameSlot& f, size_t li, hipStream_t stream, b
         // most of the chip idle, and each launch costs its start-up and its drain), two launches for the kernels of their own
         const bool own_kernel = L.ops.size() == 1 && own_kernel_kind(L.ops[0].kind);
         if (own_kernel) {
-            st = launch_rows(g, f, L, geo, geo.y0, geo.y0 + r, stream, false);
+            st = launch_rows(g, f, L, geo, geo.y0, geo.y0 + r, stream);
             if (st != RF_OK) return st;
-            st = launch_rows(g, f, L, geo, geo.y1 - r, geo.y1, stream, false);
+            st = launch_rows(g, f, L, geo, geo.y1 - r, geo.y1, stream);
         } else {
             Geom two = geo;
             two.yb0 = geo.y1 - r;
             two.yb1 = geo.y1;
-            st = launch_rows(g, f, L, two, geo.y0, geo.y0 + r, stream, false);
+            st = launch_rows(g, f, L, two, geo.y0, geo.y0 + r, stream);
         }
         if (st != RF_OK) return st;
     }
@@ -551,15 +539,6 @@ static void read_tuning(rf_graph* g)
     if (const char* e = std::getenv("RF_FORCE_SPLIT")) g->force_split = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_NT_STORE")) g->nt_stores = std::atoi(e) != 0;
     if (const char* e = std::getenv("RF_NO_ALTERNATE")) g->tune.walk = std::atoi(e) ? 2 : 1;
-    // (the library's own choice is still the static schedule: dynamic walks are bit-exact and measured, and do not pay yet -- DESIGN.md 6.1c)
-    g->tune.steal = (opt.exec_flags & RF_EXEC_DYNAMIC_WALKS) ? 1 : -1;
-    g->tune.steal_unit = opt.walk_unit;
-    if (const char* e = std::getenv("RF_STEAL")) {      // 0: never, 1: launches large enough to gain, 2: every launch (RF_EXEC_STATIC_WALKS still wins: A/B runs)
-        const int v = std::atoi(e);
-        if (!(opt.exec_flags & RF_EXEC_STATIC_WALKS)) g->tune.steal = v <= 0 ? -1 : (v == 1 ? 0 : 1);
-    }
-    if (const char* e = std::getenv("RF_STEAL_ROUNDS")) g->tune.steal_rounds = std::atoi(e);
-    if (const char* e = std::getenv("RF_STEAL_UNIT")) g->tune.steal_unit = std::atoi(e);
     // Exchange mode shares ONE comm stream and one src_ready/halo_ready event pair per slot: two
     // stencils of a layer reading the same source would each re-exchange its ghost rows while the
     // other's boundary kernels may still read them.  Plan order on one stream keeps it ordered.
@@ -734,16 +713,6 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
             f.join.push_back(e);
         }
         HIP_TRY(hipEventCreateWithFlags(&f.fork, hipEventDisableTiming));
-        // walk words: one block per stream launch of the frame (never shared: the launches of a layer may run side by side)
-        for (const auto& L : g->launches) {
-            unsigned long long* ws = nullptr;
-            const bool own = L.ops.size() == 1 && (own_kernel_kind(L.ops[0].kind));
-            if (!own && g->tune.steal >= 0) {      // (read_tuning: from the flags / RF_STEAL)
-                HIP_TRY(hipMalloc((void**)&ws, kWalkWordBytes));
-                HIP_TRY(hipMemset(ws, 0, kWalkWordBytes));
-            }
-            f.walk_words.push_back(ws);
-        }
         if (exchange_mode(g) || g->force_split) {
             HIP_TRY(hipStreamCreateWithFlags(&f.comm, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&f.src_ready, hipEventDisableTiming));
@@ -761,7 +730,7 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
             }
         }
     }
-    // the fills above (walk words, storage buffers) ran on the null stream; the frames run on non-blocking streams of their own
+    // the fills above (storage buffers) ran on the null stream; the frames run on non-blocking streams of their own
     HIP_TRY(hipDeviceSynchronize());
     return RF_OK;
 }
@@ -800,7 +769,6 @@ extern "C" void rf_graph_destroy(rf_graph* g)
         for (auto e : f.t1) (void)hipEventDestroy(e);
         for (auto e : f.join) (void)hipEventDestroy(e);
         if (f.fork) (void)hipEventDestroy(f.fork);
-        for (unsigned long long* ws : f.walk_words) if (ws) (void)hipFree(ws);
         if (f.src_ready) (void)hipEventDestroy(f.src_ready);
         if (f.halo_ready) (void)hipEventDestroy(f.halo_ready);
         if (f.comm) (void)hipStreamDestroy(f.comm);
@@ -1294,24 +1262,6 @@ extern "C" rf_status rf_graph_time_each_frame(rf_graph* g, int iters, float* ms_
 }
 
 extern "C" const char* rf_graph_note(const rf_graph* g) { return g ? g->jit_note.c_str() : ""; }
-
-extern "C" rf_status rf_graph_walks_taken(rf_graph* g, int frame_slot, uint64_t* count)
-{
-    FrameSlot* f = nullptr;
-    rf_status st = slot_of(g, frame_slot, &f, "rf_graph_walks_taken");
-    if (st != RF_OK) return st;
-    if (!count) return fail(RF_ERR_INVALID, "rf_graph_walks_taken: null count");
-    HIP_TRY(hipStreamSynchronize(f->stream));
-    uint64_t total = 0;
-    for (unsigned long long* ws : f->walk_words) {
-        if (!ws) continue;
-        unsigned long long n = 0;
-        HIP_TRY(hipMemcpy(&n, ws + kWalkWordBytes / sizeof(unsigned long long) - 1, sizeof(n), hipMemcpyDeviceToHost));
-        total += n;
-    }
-    *count = total;
-    return RF_OK;
-}
 
 extern "C" rf_status rf_graph_time_launch(rf_graph* g, int launch, int iters, float* avg_ms)
 {

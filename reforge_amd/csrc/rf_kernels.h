@@ -83,13 +83,6 @@ struct StreamTuning {
     int walk = 0;             // chunk walk direction: 0 auto, 1 odd chunks bottom-up (halo rows shared through L2), 2 all top-down
     int texels_per_lane = 0;  // RF_TEXELS_PER_LANE: 0 auto, 1 or 2 (rgba32f stream kernels)
     int conv_path = 0;        // RF_CONV_PATH: 0 = register-blocked VALU kernel, 1 = 16x16 LDS tile, 2 = MFMA (K >= 9), 3 = VALU
-    // Dynamic tail of a stream launch (rf_stream_dev.h, "Walk words"): the walk words of THIS launch in THIS frame slot (zeroed
-    // once; every launch leaves them empty) and their size; null = the static schedule.
-    unsigned long long* steal_ws = nullptr;
-    size_t steal_ws_bytes = 0;
-    int steal = 0;            // RF_STEAL: 0 auto (launches of at least most of a round of resident workgroups), 1 always, -1 never
-    int steal_rounds = 0;     // RF_STEAL_ROUNDS: rounds of resident workgroups a dynamic launch is cut into (0 = 1)
-    int steal_unit = 0;       // RF_STEAL_UNIT: rows per unit (0 = max(8, twice the vertical halo))
 };
 
 // Row stages of a streaming launch (rf_stream_dev.h): the run-time description that selects -- or, for a list the

@@ -79,7 +79,6 @@ struct FrameSlot {
 
     std::vector<hipEvent_t> t0, t1;          // GpuTimer query pairs, one per launch
     bool timed_once = false;
-    std::vector<unsigned long long*> walk_words;   // per launch: the walk words of its stream kernel (rf_stream_dev.h "Walk words"; zeroed once, every launch leaves them empty), null for kernels of their own
     hipGraphExec_t graph_exec = nullptr;
     hipGraph_t graph = nullptr;
 };

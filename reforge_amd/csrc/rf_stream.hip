@@ -350,55 +350,19 @@ static bool launch_shape(Image src, Image dst, const Geom& g, const StreamTuning
     const int rows = rows_a + rows_b;
     if (rows <= 0 || g.W <= 0) return false;
     const int groups = (A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int rows_split = rows_b > 0 ? std::max(rows_a, rows_b) : rows;
-    A.rows_per_chunk = choose_rows_per_chunk(rows_split, groups, resident, halo_rows, bpp, tune, tune.walk == 2);
-    // DYNAMIC TAIL (rf_stream_dev.h, "Walk words").  With walk words the waves even out what a static schedule leaves uneven, so
-    // the launch can take the geometry a static schedule cannot afford: `rounds` rounds of resident workgroups, every chunk as tall
-    // as that allows -- few halo rows, and no tail, because the walks that would form it are split while they run.  Taken by
-    // launches that fill most of a round anyway (a small frame is bound by the LENGTH of its walks: short static chunks stay) and
-    // whose chunks then hold several units; an explicit chunk height (tests, sweeps) is kept and merely made divisible.
-    A.unit = 0;
-    A.dbg = 0;
-    if (const char* e = std::getenv("RF_DEBUG_WALK")) A.dbg = std::atoi(e);
-    A.ws = nullptr;
-    A.steal_window = 0;
-    A.stat_word = 0;
-    A.min_rows = 0;
-    A.pad_ = 0;
-    if (tune.steal_ws && tune.steal >= 0) {
-        const int unit = tune.steal_unit > 0 ? std::max(kMinUnit, tune.steal_unit) : std::max(kMinUnit, (2 * halo_rows + 3) & ~3);
-        int rpc = A.rows_per_chunk;
-        if (tune.rows_per_chunk <= 0) {
-            const long static_work = (long)((rows_split + rpc - 1) / rpc) * groups;
-            const int rounds = tune.steal_rounds > 0 ? tune.steal_rounds : 1;
-            const long chunks = std::max<long>(1, (long)rounds * resident / groups);
-            const int tall = (int)((rows_split + chunks - 1) / chunks);
-            if ((tune.steal > 0 || 4 * static_work >= 3L * resident) && tall >= 3 * unit && tall > rpc) rpc = tall;
-        }
-        const long n_chunks = (rows_a + rpc - 1) / rpc + (rows_b + rpc - 1) / rpc;
-        const size_t need = (size_t)n_chunks * groups * kWavesPerBlock * kWordStride + 2048;      // the words, a probe's over-read, the count of walks taken over
-        if (n_chunks <= 65535 && A.n_strips <= 32767 && rpc / unit < 65534 && need <= tune.steal_ws_bytes) {
-            A.rows_per_chunk = rpc;
-            A.unit = unit;
-            A.ws = tune.steal_ws;
-            A.stat_word = (int)(tune.steal_ws_bytes / sizeof(unsigned long long)) - 1;      // the block's last word
-            A.min_rows = 4 * halo_rows + 16;
-            if (const char* e = std::getenv("RF_STEAL_MIN_ROWS")) A.min_rows = std::atoi(e);
-        }
-    }
+    A.rows_per_chunk = choose_rows_per_chunk(rows_b > 0 ? std::max(rows_a, rows_b) : rows, groups, resident, halo_rows, bpp, tune, tune.walk == 2);
     A.chunks_a = (rows_a + A.rows_per_chunk - 1) / A.rows_per_chunk;
     A.yb0 = g.yb0;
     A.yb1 = g.yb0 + rows_b;
     const int chunks = A.chunks_a + (rows_b + A.rows_per_chunk - 1) / A.rows_per_chunk;
     A.alternate = tune.walk == 2 ? 0 : 1;
+    A.reserved = 0;
     A.n_work = groups * chunks;
     out.grid = (unsigned)((A.n_work + 7) / 8 * 8);   // 1-D, a multiple of the 8 XCDs (see the kernel's block order)
-    if (A.ws) A.steal_window = (int)std::min<long>((long)out.grid, ((long)resident + 7) / 8 * 8);
-    if (const char* e = std::getenv("RF_DEBUG_STEAL_WINDOW")) A.steal_window = std::atoi(e);      // diagnostics: 0 = waves claim their units, nobody takes walks over
     static const bool trace = std::getenv("RF_TRACE_SHAPE") != nullptr;      // diagnostics: the launch geometry, to stderr
     if (trace)
-        std::fprintf(stderr, "rf shape: %dx%d rows, bpp %d, texels %d, walk %d: %d strips in %d groups, %d-row chunks, %d workgroups on %d resident (%d CUs), %d-row units, window %d\n",
-                     g.W, rows, bpp, texels, tune.walk, A.n_strips, groups, A.rows_per_chunk, A.n_work, resident, device_cus(), A.unit, A.steal_window);
+        std::fprintf(stderr, "rf shape: %dx%d rows, bpp %d, texels %d, walk %d: %d strips in %d groups, %d-row chunks, %d workgroups on %d resident (%d CUs)\n",
+                     g.W, rows, bpp, texels, tune.walk, A.n_strips, groups, A.rows_per_chunk, A.n_work, resident, device_cus());
     return true;
 }
 

@@ -107,13 +107,13 @@ template <class Px, int PF, int T> struct Source {
         for (int j = 0; j < T; ++j) {
             const unsigned dst = dst0 + (unsigned)(j * 64 * Px::BPP);
             unsigned keep;
-            unsigned long long sb;      // RF_SBASE (rf_device.h): the row address may have been reloaded by a vector instruction just in front
+            // RF_SBASE (rf_device.h): the row address may have been reloaded by a vector instruction right in front of the asm
             if constexpr (Px::BPP == 16)
-                asm volatile("s_waitcnt lgkmcnt(0)\n\t" RF_SBASE "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[off], %[sb]" RF_LOAD_MOD "\n\ts_mov_b32 m0, %[keep]"
-                             : [keep] "=&s"(keep), [sb] "=&s"(sb) : [off] "v"(xoff[j]), [lds] "s"(dst), [base] "s"(g) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)\n\t" RF_SBASE "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[off], vcc" RF_LOAD_MOD "\n\ts_mov_b32 m0, %[keep]"
+                             : [keep] "=&s"(keep) : [off] "v"(xoff[j]), [lds] "s"(dst), [base] "s"(g) : "memory", "vcc");
             else
-                asm volatile("s_waitcnt lgkmcnt(0)\n\t" RF_SBASE "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dword %[off], %[sb]" RF_LOAD_MOD "\n\ts_mov_b32 m0, %[keep]"
-                             : [keep] "=&s"(keep), [sb] "=&s"(sb) : [off] "v"(xoff[j]), [lds] "s"(dst), [base] "s"(g) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)\n\t" RF_SBASE "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dword %[off], vcc" RF_LOAD_MOD "\n\ts_mov_b32 m0, %[keep]"
+                             : [keep] "=&s"(keep) : [off] "v"(xoff[j]), [lds] "s"(dst), [base] "s"(g) : "memory", "vcc");
         }
     }
     RF_DEV void prologue() const
@@ -816,101 +816,22 @@ struct alignas(8) StreamHdr {
     // a second range of output rows [yb0, yb1) served by the chunks from index `chunks_a` on (Geom::yb0: the two boundary
     // slivers of a row strip as one launch); a launch with one range has chunks_a = its chunk count and an empty second range
     int chunks_a, yb0, yb1;
-    // DYNAMIC TAIL ("Walk words" below).  unit: rows per unit, 0 = the static schedule; ws: one 64-bit walk word per (work item,
-    // wave), a 128-byte line each, + 1 KiB of padding, all EMPTY between launches; steal_window: the waves of the last `steal_window` workgroups of the
-    // grid (a multiple of 8) look for more work when their walk ends, among the walks of those workgroups
-    int unit;
-    int dbg;            // EXPERIMENT bits (RF_DEBUG_WALK): 1 no claim atomic, 2 no read-back, 4 read-back at L2 scope (sc0), 8 claim atomic returns nothing but is L2-scope
-    unsigned long long* ws;
-    int steal_window;
-    int min_rows;       // rows a wave must gain to take a walk over
-    int stat_word;      // index (in 64-bit words) of the count of walks taken over, kept for tests and the bench; 0 = none
-    int pad_;
+    int reserved;
 };
 template <class... S> struct StreamArgs : StreamHdr {
-    ParamPack<S...> params;      // at offset sizeof(StreamHdr) = 112
+    ParamPack<S...> params;      // at offset sizeof(StreamHdr) = 88
 };
-static_assert(sizeof(StreamHdr) == 112, "the host assembles kernel arguments as bytes: header, then the parameter slots");
+static_assert(sizeof(StreamHdr) == 88, "the host assembles kernel arguments as bytes: header, then the parameter slots");
 
 #ifndef RF_WAVES_PER_BLOCK
 #define RF_WAVES_PER_BLOCK 4
 #endif
 constexpr int kWavesPerBlock = RF_WAVES_PER_BLOCK;
 
-// ---------------------------------------------------------------------------------
-// Walk words: the dynamic tail of a stream launch.
-//
-// A static schedule -- every wave walks the chunk its workgroup index names -- ends with the chip draining: workgroups of one
-// launch take 114-214 us for the same number of rows (profiles/r03_workgroup_timestamps.txt), so the last tenth of a launch runs
-// at falling concurrency, and the only static remedy, shorter chunks, pays a fresh halo per chunk.  Here a walk is divided into
-// UNITS of `unit` output rows (the chunk's last unit takes the remainder and is at least unit + PF + halo rows, so that every
-// unit boundary lies where the pipeline streams) and the part of it nobody has started is public: one 64-bit word per (work
-// item, wave),
-//       bits  0-15  next   first unit the walker has NOT claimed          bits 32-47  chunk
-//       bits 16-31  end    one past the walk's last unit                  bits 48-62  strip,  bit 63  walks bottom-up
-// (units count from the walk's first row IN WALK ORDER; an empty word -- next >= end, e.g. 0 -- is a walk with nothing to give).
-//   * The WALKER claims one unit ahead: entering unit k it adds 1 to `next` (claiming k+1; a non-returning atomic) and fetches
-//     the word back by LDS-DMA; entering k+1 it reads `end` from that copy.  Both are ordinary vector-memory operations in the
-//     wave's in-order stream: they retire behind the row DMAs and stores around them, and the counted vmcnt waits only ever
-//     become stricter by them; a unit (>= 8 rows) later they have long landed.  A walker that finds `end` lowered stops AT that
-//     unit boundary -- every row it owed is stored, the rows it prefetched beyond are dropped.
-//   * A wave whose walk is over (and whose workgroup is among the last `steal_window` of the grid: earlier ones make room for
-//     workgroups not yet started) looks at 64 walk words of those workgroups with ONE LDS-DMA (into a 1 KiB landing row of its own), picks the walk with the most
-//     unclaimed units and takes the far half of them with a compare-and-swap on the word: end := mid.  It never takes unit
-//     `next` itself, which is why the walker's claim needs no answer: whatever a thief does, before or after the add, the unit
-//     the walker claims stays the walker's.  The thief re-primes its pipeline at `mid` (the halo rows of a fresh chunk), publishes
-//     the stolen walk as its own word and may be stolen from in turn.
-// Every row is written exactly once (in-place point ops depend on it); which wave writes it is all that varies, so results are
-// bit-identical to the static schedule.  Every wave leaves after a bounded number of probes; the words are empty again when the
-// last walk ends.  Nothing here is a barrier, a spin or a persistent loop on a flag.
-// ---------------------------------------------------------------------------------
-constexpr int kStealTries = 4;           // probes (of 64 words each) a wave makes before it leaves
-constexpr unsigned kWordStride = 128;    // bytes between walk words: a 128-byte line each.  (Adjacent words -- 16 walkers' claims and read-backs on one
-                                         // line -- cost gaussian9 at 8K +56 % with 8-row units, +9 % with 32-row ones; a line each: within the noise,
-                                         // profiles/r04_claim_cost.txt)
-constexpr int kMinUnit = 8;              // rows: a claim and its answer are a unit apart, a unit is longer than the prefetch ring
-
-RF_DEV int walk_units(int rows, int unit, int pad) { const int u = unit > 0 ? (rows - pad) / unit : 1; return u > 1 ? u : 1; }
-
-// claim the next unit of this wave's own walk (next += 1) and fetch the word back into the wave's landing row
-RF_DEV void walk_claim(const unsigned long long* ws, unsigned slot, unsigned landing_lds, int lane, int dbg = 0)
-{
-    if (lane == 0 && !(dbg & 1)) {
-        unsigned long long one = 1ull, sb;
-        asm volatile(RF_SBASE "global_atomic_add_x2 %[off], %[data], %[sb]" : [sb] "=&s"(sb) : [off] "v"(slot * kWordStride), [data] "v"(one), [base] "s"(ws) : "memory");
-    }
-    unsigned keep;
-    unsigned long long sb;
-    if (dbg & 2) return;
-    if (dbg & 4)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\t" RF_SBASE "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dword %[off], %[sb] sc0\n\ts_mov_b32 m0, %[keep]"
-                     : [keep] "=&s"(keep), [sb] "=&s"(sb) : [off] "v"(slot * kWordStride + 4u * (unsigned)lane), [lds] "s"(landing_lds), [base] "s"(ws) : "memory");
-    else
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t" RF_SBASE "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dword %[off], %[sb] sc1\n\ts_mov_b32 m0, %[keep]"
-                 : [keep] "=&s"(keep), [sb] "=&s"(sb) : [off] "v"(slot * kWordStride + 4u * (unsigned)lane), [lds] "s"(landing_lds), [base] "s"(ws) : "memory");
-}
-// `end` of the word as the last walk_claim fetched it (wave-uniform)
-typedef const volatile __attribute__((address_space(3))) unsigned* LdsWords;      // a wave's landing row, read with ds_read whatever the optimiser can or cannot infer
-RF_DEV int walk_end_seen(LdsWords landing)
-{
-    const unsigned lo = landing[0];
-    return (int)((unsigned)__builtin_amdgcn_readfirstlane((int)lo) >> 16);
-}
-RF_DEV void walk_publish(unsigned long long* ws, unsigned slot, unsigned lo, unsigned hi, int lane)
-{
-    if (lane == 0) {
-        const unsigned long long w = (unsigned long long)lo | ((unsigned long long)hi << 32);
-        unsigned long long sb;
-        asm volatile(RF_SBASE "global_store_dwordx2 %[off], %[data], %[sb] sc1" : [sb] "=&s"(sb) : [off] "v"(slot * kWordStride), [data] "v"(w), [base] "s"(ws) : "memory");
-    }
-}
-
 // One wave's walk over rows [y0, y1) of its strip.  REV = bottom-up: rows are addressed with
 // negated pitches and mirrored bounds, so the schedule code sees an ordinary top-down walk.
-// nu > 1: the walk is `nu` units long and public (A.ws[slot], units k0 .. k0 + nu - 1 of its chunk): see "Walk words".
 template <class Px, int PF, int T, bool REV, class... S>
-RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane<T>& L, int wave, char* ring_wave, unsigned ring_lds, int y0, int y1,
-                        unsigned slot, int k0, int nu, unsigned word_hi, LdsWords landing, unsigned landing_lds)
+RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane<T>& L, int wave, char* ring_wave, unsigned ring_lds, int y0, int y1)
 {
     constexpr int RH = SumRH<S...>::value;
     typedef Source<Px, PF, T> Src;
@@ -947,15 +868,7 @@ RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane<T>& L, int wave, c
     src.pitch = REV ? -(ptrdiff_t)A.src_pitch : (ptrdiff_t)A.src_pitch;
     src.ring = ring_wave;
     src.lds_base = ring_lds;
-    // A public walk: the word is published by a store nobody waits for, and unit 1 is claimed BEHIND the first rows' DMAs, so that
-    // the round trips to the memory side overlap with the rows' instead of standing in front of them (in front, and with the store
-    // waited for, a 36-row walk at 4K paid 12 %); unit 0 is the walker's by publication, the answer to the claim of unit 1 is read
-    // when unit 1 is entered.
-    if (nu > 1) walk_publish(A.ws, slot, (unsigned)(k0 + 1) | ((unsigned)(k0 + nu) << 16), word_hi, L.lane);
     src.prologue();
-    if (nu > 1) {
-        walk_claim(A.ws, slot, landing_lds, L.lane, A.dbg);
-    }
     Feed feed;
     src.wait_row(0, k);
     feed.fetch(src, 0, L);
@@ -973,123 +886,11 @@ RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane<T>& L, int wave, c
     if (k.first_store >= 0) {
         const int steady_end = src.n0 - PF;                      // iterations with a row left to issue
         const int warm_end = min(k.first_store + PF, steady_end);
-        // Unit j of the walk is emitted by iterations [first_store + j U, first_store + (j + 1) U): the streaming phases run
-        // unit by unit.  mine: the units this walker may run (shrinks when a thief lowers the word's `end`; then the walk is CUT:
-        // it stops at the boundary, where every row it owes has been stored -- a walk that reaches the end it started with
-        // finishes as ever, tail and flush).  A walk of one unit (every walk of the static schedule) is one pass of the loop.
-        static_assert(kMinUnit > PF, "the warm-up iterations end before the first unit boundary");
         for (; it < warm_end; ++it) chain.template step_first<1>(true, feed, src, it, L, k, A.params);
-        int mine = nu, unit = 1;
-        bool cut = false;
-        for (;;) {
-            const bool more = unit < mine;
-            const int stop = (more || cut) ? min(k.first_store + unit * A.unit, steady_end) : steady_end;
-            for (; it < stop; ++it) chain.template step_first<2>(true, feed, src, it, L, k, A.params);
-            if (!more) {
-                if (!cut) break;
-                wait_vmcnt<0>();           // cut: the rows prefetched beyond the boundary land in the ring and are dropped
-                return;
-            }
-            // entering unit `unit`: the word as fetched one unit ago (the claim of this unit went with that fetch)
-            const int seen = (A.dbg & 2) ? mine : walk_end_seen(landing) - k0;
-            if (seen < mine) { mine = seen; cut = true; }
-            if (unit >= mine) {
-                wait_vmcnt<0>();
-                return;
-            }
-            if (unit + 1 < mine) walk_claim(A.ws, slot, landing_lds, L.lane, A.dbg);
-            ++unit;
-        }
+        for (; it < steady_end; ++it) chain.template step_first<2>(true, feed, src, it, L, k, A.params);
         for (; it < src.n0; ++it) chain.template step_first<3>(true, feed, src, it, L, k, A.params);
     }
     for (; it < total; ++it) chain.template step_first<0>(it < src.n0, feed, src, it, L, k, A.params);
-}
-
-// what a wave walks next
-struct Walk {
-    int strip, chunk, rev;
-    int k0, nu;          // units [k0, k0 + nu) of the chunk, in walk order
-};
-
-// A wave without a walk looks for one (see "Walk words").  Wave-uniform result.
-typedef const __attribute__((address_space(4))) StreamHdr* HdrPtr;      // the kernel's argument block, read with scalar loads
-
-RF_DEV bool walk_steal(HdrPtr H, unsigned my_slot, int pad, LdsWords landing, unsigned landing_lds, int lane, Walk& out)
-{
-    const struct { int n_work, n_strips, steal_window, chunks_a, yb0, yb1, y0, y1, rows_per_chunk, unit, min_rows; unsigned long long* ws; } A = {
-        H->n_work, H->n_strips, H->steal_window, H->chunks_a, H->yb0, H->yb1, H->y0, H->y1, H->rows_per_chunk, H->unit, H->min_rows, H->ws};
-    const int n_chunks = A.n_work / ((A.n_strips + kWavesPerBlock - 1) / kWavesPerBlock);
-    const unsigned grid = gridDim.x, per_xcd = grid >> 3;
-    const unsigned window = (unsigned)A.steal_window < grid ? (unsigned)A.steal_window : grid;     // a multiple of 8, like the grid
-    if (window < 8) return false;
-    const unsigned b0 = grid - window;
-#pragma unroll 1
-    for (int t = 0; t < kStealTries; ++t) {
-        // this lane's candidate: a pair of adjacent waves of one workgroup of the window.  The first probes stay on the thief's
-        // own XCD (workgroup index = its own mod 8: the victim's halo rows and neighbour strips then sit in the same L2).
-        unsigned h = (my_slot * 0x9E3779B1u) ^ ((unsigned)(t + 1) * 0x85EBCA6Bu) ^ ((unsigned)(lane + 1) * 0xC2B2AE35u);
-        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
-        const unsigned b = t < 2 ? b0 + 8u * ((h >> 4) % (window >> 3)) + (blockIdx.x & 7u) : b0 + (h >> 4) % window;
-        const unsigned q = (b & 7u) * per_xcd + (b >> 3);
-        const bool valid = q < (unsigned)A.n_work;
-        const unsigned s = (valid ? q : (my_slot / kWavesPerBlock)) * kWavesPerBlock + h % kWavesPerBlock;
-        unsigned keep;
-        unsigned long long sb;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\t" RF_SBASE "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[off], %[sb] sc1\n\ts_mov_b32 m0, %[keep]\n\ts_waitcnt vmcnt(0)"
-                     : [keep] "=&s"(keep), [sb] "=&s"(sb) : [off] "v"(s * kWordStride), [lds] "s"(landing_lds), [base] "s"(A.ws) : "memory");
-        typedef unsigned v4u __attribute__((ext_vector_type(4)));
-        const v4u w = *reinterpret_cast<const volatile __attribute__((address_space(3))) v4u*>(landing + 4 * lane);
-        // unclaimed units of the two walks (none: an empty word, this wave's own, or a word that does not describe a walk of
-        // THIS launch -- never followed)
-        auto spare = [&](unsigned lo, unsigned hi, unsigned slot) -> unsigned {
-            const unsigned next = lo & 0xffffu, end = lo >> 16, chunk = hi & 0xffffu, strip = (hi >> 16) & 0x7fffu;
-            if (!valid || slot == my_slot || next >= end || next == 0u) return 0u;
-            if (strip >= (unsigned)A.n_strips || chunk >= (unsigned)n_chunks) return 0u;
-            return end - next;
-        };
-        const unsigned best = spare(w.x, w.y, s);          // (the 16 bytes a lane fetched: its candidate's word, then padding)
-        unsigned long long alive = __builtin_amdgcn_ballot_w64(best >= 2u);
-        if (alive == 0ull) continue;
-        for (int bit = 15; bit >= 0; --bit) {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(((alive >> lane) & 1ull) != 0ull && ((best >> bit) & 1u) != 0u);
-            if (m != 0ull) alive = m;
-        }
-        const int win = (int)__builtin_ctzll(alive);
-        const unsigned vlo = (unsigned)__builtin_amdgcn_readlane((int)w.x, win);
-        const unsigned vhi = (unsigned)__builtin_amdgcn_readlane((int)w.y, win);
-        const unsigned vslot = (unsigned)__builtin_amdgcn_readlane((int)s, win);
-        const unsigned next = vlo & 0xffffu, end = vlo >> 16;
-        const unsigned mid = end - (end - next) / 2u;                 // the victim keeps [next, mid): at least unit `next`
-        // a walk taken over starts with a fresh halo: not for a handful of rows
-        if ((int)((end - mid) * (unsigned)A.unit) < A.min_rows) continue;
-        // the chunk's unit count bounds `end` (a word of this launch always satisfies it)
-        const int chunk = (int)(vhi & 0xffffu);
-        const bool second_range = chunk >= A.chunks_a;
-        const int cy0 = second_range ? A.yb0 + (chunk - A.chunks_a) * A.rows_per_chunk : A.y0 + chunk * A.rows_per_chunk;
-        const int cy1 = min(cy0 + A.rows_per_chunk, second_range ? A.yb1 : A.y1);
-        if ((int)end > walk_units(cy1 - cy0, A.unit, pad) || mid <= next) continue;
-        const v4u swap = {next | (mid << 16), vhi, vlo, vhi};        // new value, then the value expected
-        unsigned long long old = 0ull;
-        if (lane == 0) {
-            unsigned long long sb;
-            asm volatile(RF_SBASE "global_atomic_cmpswap_x2 %[old], %[off], %[data], %[sb] sc0\n\ts_waitcnt vmcnt(0)"
-                         : [old] "=&v"(old), [sb] "=&s"(sb) : [off] "v"(vslot * kWordStride), [data] "v"(swap), [base] "s"(A.ws) : "memory");
-        }
-        const unsigned olo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old);
-        const unsigned ohi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(old >> 32));
-        if (olo != vlo || ohi != vhi) continue;                      // the walker moved on, or another thief was first
-        if (lane == 0 && H->stat_word > 0) {
-            unsigned long long one = 1ull, sb;
-            asm volatile(RF_SBASE "global_atomic_add_x2 %[off], %[data], %[sb]" : [sb] "=&s"(sb) : [off] "v"(8u * (unsigned)H->stat_word), [data] "v"(one), [base] "s"(A.ws) : "memory");      // (a byte offset of 8-byte words, not of walk words)
-        }
-        out.strip = (int)((vhi >> 16) & 0x7fffu);
-        out.chunk = chunk;
-        out.rev = (int)(vhi >> 31);
-        out.k0 = (int)mid;
-        out.nu = (int)(end - mid);
-        return true;
-    }
-    return false;
 }
 
 template <class Px, int PF, int T, class... S>
@@ -1098,17 +899,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, T > 1 ? 2 : 1) void stream_ker
     constexpr int RH = SumRH<S...>::value;
     constexpr int VALID = 64 * T - 2 * RH;
     constexpr int LDSR = SumLDS<S...>::value;
-    constexpr int PAD = PF + SumRV<S...>::value;      // rows the last unit of a chunk has on top of a unit: every unit boundary then lies in the streaming phases
     typedef Source<Px, PF, T> Src;
-        __shared__ f4 smem[kWavesPerBlock][(LDSR > 0 ? LDSR : 1) * 64 * T];
+    __shared__ f4 smem[kWavesPerBlock][(LDSR > 0 ? LDSR : 1) * 64 * T];
     __shared__ __attribute__((aligned(16))) char ring[kWavesPerBlock][Src::SLOTS * Src::SLOT_BYTES];
-    __shared__ __attribute__((aligned(16))) unsigned landing[kWavesPerBlock][256];     // where walk words land: a walker's own (walk_claim, 256 B), a thief's probe (1 KiB)
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(
-        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&ring[0][0]) + (unsigned)wave * (unsigned)(Src::SLOTS * Src::SLOT_BYTES));
-    const unsigned landing_lds = __builtin_amdgcn_readfirstlane(
-        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&landing[0][0]) + (unsigned)wave * 1024u);
     // XCD-aware block order (guide T1): blocks are dealt round-robin over the 8 XCDs, so block
     // b and b+8 share an L2.  Give each XCD a CONTIGUOUS range of work items (strip groups
     // fastest, then chunks): workgroups that share halo columns or halo rows then share an L2.
@@ -1120,73 +915,39 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, T > 1 ? 2 : 1) void stream_ker
     const int per_xcd = (int)gridDim.x >> 3;
     const int q = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (q >= A.n_work) return;
+    const int strip = (q % gx) * kWavesPerBlock + wave;
+    if (strip >= A.n_strips) return;                 // wave-uniform; no barriers below
+    const int chunk = q / gx;
+    const bool second = chunk >= A.chunks_a;          // wave-uniform
+    const int y0 = second ? A.yb0 + (chunk - A.chunks_a) * A.rows_per_chunk : A.y0 + chunk * A.rows_per_chunk;
+    const int y1 = min(y0 + A.rows_per_chunk, second ? A.yb1 : A.y1);
+    if (y0 >= y1) return;
+
+    Lane<T> L;
+    L.lane = (int)(threadIdx.x & 63);
+    L.x0 = strip * VALID - RH;
+    // T > 1: every one of the T stores of a row must have an active lane (the counted vmcnt waits
+    // assume T stores are really issued; hipcc branches around a store whose exec mask is empty).
+    // The last strip is therefore moved left until it ends at the frame edge -- it recomputes a
+    // few columns of its neighbour and writes the same values (the host launches T > 1 only when
+    // W >= 64 T and the launch is not in place).
+    if constexpr (T > 1) {
+        if (L.x0 + 64 * T - RH > A.W) L.x0 = A.W - 64 * T + RH;
+    }
+    L.W = A.W;
+    L.lds = smem[wave];
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&ring[0][0]) + (unsigned)wave * (unsigned)(Src::SLOTS * Src::SLOT_BYTES));
 
     // Odd chunks walk bottom-up: a chunk and its neighbour then read the halo rows they
     // share at the same moment (both at their start, or both at their end), so the second
     // read is served by the XCD's L2 instead of the fabric.  Stencil-free pipelines have no
     // halo and always walk top-down.
     constexpr bool kHasHalo = SumRV<S...>::value > 0;
-    Walk w;
-    w.strip = (q % gx) * kWavesPerBlock + wave;
-    w.chunk = q / gx;
-    w.rev = (kHasHalo && A.alternate && (w.chunk & 1)) ? 1 : 0;
-    w.k0 = 0;
-    w.nu = 0;                                         // 0: the whole chunk (its unit count follows from its rows, below)
-    bool have = w.strip < A.n_strips;                 // wave-uniform; no barriers anywhere
-    for (;;) {
-        // the launch geometry is read from the argument block again on every pass (scalar loads through a pointer the
-        // optimiser cannot see through) instead of living in scalar registers across a walk, where the stage parameters need them
-        HdrPtr H = (HdrPtr)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(H));
-        int ln = (int)(threadIdx.x & 63);
-        asm volatile("" : "+v"(ln));
-        const unsigned slot = ((unsigned)(((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3)) * kWavesPerBlock + (unsigned)wave);
-        const bool dynamic = H->ws != nullptr && H->unit >= kMinUnit;
-        if (have) {
-            const int rpc = H->rows_per_chunk, ca = H->chunks_a, un = H->unit;
-            const bool second = w.chunk >= ca;          // wave-uniform
-            const int cy0 = second ? H->yb0 + (w.chunk - ca) * rpc : H->y0 + w.chunk * rpc;
-            const int cy1 = min(cy0 + rpc, second ? H->yb1 : H->y1);
-            const int units = dynamic ? walk_units(cy1 - cy0, un, PAD) : 1;
-            if (w.nu == 0) w.nu = units;
-            // rows of units [k0, k0 + nu) in walk order; the chunk's last unit ends where the chunk ends
-            const int a = w.k0 * un, b = (w.k0 + w.nu) * un;
-            int y0, y1;
-            if (w.rev) {
-                y1 = cy1 - a;
-                y0 = w.k0 + w.nu >= units ? cy0 : cy1 - b;
-            } else {
-                y0 = cy0 + a;
-                y1 = w.k0 + w.nu >= units ? cy1 : cy0 + b;
-            }
-            if (y0 < y1) {
-                const unsigned word_hi = (unsigned)w.chunk | ((unsigned)w.strip << 16) | ((unsigned)w.rev << 31);
-                Lane<T> L;
-                L.lane = ln;
-                L.x0 = w.strip * VALID - RH;
-                // T > 1: every one of the T stores of a row must have an active lane (the counted vmcnt waits
-                // assume T stores are really issued; hipcc branches around a store whose exec mask is empty).
-                // The last strip is therefore moved left until it ends at the frame edge -- it recomputes a
-                // few columns of its neighbour and writes the same values (the host launches T > 1 only when
-                // W >= 64 T and the launch is not in place).
-                if constexpr (T > 1) {
-                    if (L.x0 + 64 * T - RH > H->W) L.x0 = H->W - 64 * T + RH;
-                }
-                L.W = H->W;
-                L.lds = smem[wave];
-                if (kHasHalo && w.rev)
-                    stream_wave<Px, PF, T, true, S...>(A, L, wave, ring[wave], ring_lds, y0, y1, slot, w.k0, w.nu, word_hi, (LdsWords)&landing[wave][0], landing_lds);
-                else
-                    stream_wave<Px, PF, T, false, S...>(A, L, wave, ring[wave], ring_lds, y0, y1, slot, w.k0, w.nu, word_hi, (LdsWords)&landing[wave][0], landing_lds);
-            }
-        }
-        // a wave looks for more work when its workgroup is among the last of the grid: earlier ones make room for workgroups
-        // that have not started yet, whose chunks cost no fresh halo
-        if (!dynamic || (int)blockIdx.x + H->steal_window < (int)gridDim.x) break;
-        wait_vmcnt<0>();
-        have = walk_steal(H, slot, PAD, (LdsWords)&landing[wave][0], landing_lds, ln, w);
-        if (!have) break;
-    }
+    if (kHasHalo && A.alternate && (chunk & 1))
+        stream_wave<Px, PF, T, true, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
+    else
+        stream_wave<Px, PF, T, false, S...>(A, L, wave, ring[wave], ring_lds, y0, y1);
 }
 
 }  // namespace rf

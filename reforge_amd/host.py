@@ -271,10 +271,10 @@ class Graph:
     """PipelineGraph + its per-frame resources (src/vulkan/pipeline_graph.rs:43-57)."""
 
     def __init__(self, ctx, config, width, height, fmt=_lib.RF_FORMAT_RGBA32F, num_frames=1, flags=0,
-                 rows_per_chunk=0, conv_path=0, exec_flags=0, texels_per_lane=0, walk_unit=0):
+                 rows_per_chunk=0, conv_path=0, exec_flags=0, texels_per_lane=0):
         self.ctx, self.width, self.height, self.format = ctx, width, height, fmt
         self._h = C.c_void_p()
-        opt = _lib.GraphOptions(width, height, fmt, num_frames, flags, rows_per_chunk or 0, conv_path, exec_flags, texels_per_lane, walk_unit)
+        opt = _lib.GraphOptions(width, height, fmt, num_frames, flags, rows_per_chunk or 0, conv_path, exec_flags, texels_per_lane)
         _check(lib().rf_graph_create(ctx.handle, config.handle, C.byref(opt), C.byref(self._h)), "rf_graph_create")
         y0, y1 = C.c_int(), C.c_int()
         _check(lib().rf_graph_strip(self._h, C.byref(y0), C.byref(y1)), "rf_graph_strip")
@@ -402,12 +402,6 @@ class Graph:
     def note(self):
         """what rf_graph_create had to say about this graph ("" = nothing): catalogue-only fusion, a user stage that spills"""
         return _s(lib().rf_graph_note(self._h))
-
-    def walks_taken(self, slot=0):
-        """how often a wave that had finished its rows took over part of another wave's walk (dynamic stream launches)"""
-        n = C.c_uint64()
-        _check(lib().rf_graph_walks_taken(self._h, slot, C.byref(n)), "rf_graph_walks_taken")
-        return n.value
 
     def time_launches(self, iters):
         """[(label, average ms)] of every launch over `iters` frames, hipEvent pairs on the launch's stream."""

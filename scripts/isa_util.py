@@ -42,18 +42,16 @@ def innermost_loops(body):
 def scalar_base_violations(instrs):
     """instrs: instruction texts of one kernel in layout order.  On gfx9 a vector-memory instruction that reads an SGPR needs five
     wait states behind a VECTOR instruction that wrote it (v_readlane reloading a spilled scalar, v_readfirstlane, v_cmp); hipcc
-    cannot see the global_* instructions the kernels issue from asm statements, so every one of them must take its scalar base
-    from an s_mov_b64 a few instructions in front of it INSIDE the same asm (RF_SBASE, rf_device.h).  Returns the instructions
-    that do not."""
+    cannot see the global_* instructions the kernels issue from asm statements, so every one of them must address through VCC,
+    loaded by an s_mov_b64 a few instructions in front of it INSIDE the same asm (RF_SBASE, rf_device.h): a scalar read of the
+    reloaded pair is interlocked, a scalar write followed by the memory instruction has no hazard.  Returns the instructions that
+    do not."""
     bad = []
     for k, ins in enumerate(instrs):
         if not ins.startswith("global_"):
             continue
-        m = re.search(r"(s\[\d+:\d+\])", ins)
-        if not m:
-            bad.append(ins + "   (no scalar base)")
-            continue
-        pair = m.group(1)
-        if not any(p.startswith("s_mov_b64 " + pair + ",") for p in instrs[max(0, k - 6):k]):
+        ops = [o.strip() for o in ins.split(None, 1)[1].split(",")] if " " in ins else []
+        base = ops[-1].split()[0] if ops else ""
+        if base != "vcc" or not any(p.startswith("s_mov_b64 vcc, s[") for p in instrs[max(0, k - 6):k]):
             bad.append(ins)
     return bad

@@ -16,7 +16,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 keep = []
 times = []
 for r in range(reps):
-    g = rf.Graph(ctx, rf.Config(TEXTS[name]), W, H, rf.RF_FORMAT_RGBA32F, exec_flags=rf.RF_EXEC_STATIC_WALKS)
+    g = rf.Graph(ctx, rf.Config(TEXTS[name]), W, H, rf.RF_FORMAT_RGBA32F)
     g.fill_synthetic(1)
     g.execute()
     g.wait()

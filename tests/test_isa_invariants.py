@@ -100,20 +100,7 @@ def test_stream_kernels_keep_the_counted_wait_contract(stream_asm):
                 assert instrs[i + 1].split()[:2] == ["s_nop", "1"], (name, instrs[i:i + 3])
         # the non-temporal hint is carried by every row store of the PxF32NT variants (launches whose result no launch reads)
         # and by nothing else -- not by rgba8 stores, not by any row load (halo rows are re-used through L2)
-        stores = [x for x in instrs if x.startswith("global_store_dword") and not x.startswith("global_store_dwordx2")]
-        # walk words (the dynamic tail, rf_stream_dev.h): published with ONE agent-scope 8-byte store, claimed with non-returning
-        # 64-bit adds, stolen with one compare-and-swap that is waited for on the spot; their loads are LDS-DMAs like the rows'
-        # (agent scope: sc1), so no vector-memory instruction of the kernel returns into a register asynchronously
-        words = [x for x in instrs if x.startswith("global_store_dwordx2")]
-        assert len(words) >= 1 and all(x.split()[-1] == "sc1" for x in words), (name, words)
-        atomics = [x for x in instrs if x.startswith("global_atomic")]
-        assert atomics and all(x.startswith(("global_atomic_add_x2", "global_atomic_cmpswap_x2")) for x in atomics), (name, atomics)
-        assert sum(x.startswith("global_atomic_cmpswap_x2") for x in atomics) == 1, (name, atomics)
-        assert all(" sc0" not in x for x in atomics if x.startswith("global_atomic_add_x2")), name      # the claim has no answer to wait for
-        for i, ins in enumerate(instrs):
-            if ins.startswith("global_atomic_cmpswap_x2"):
-                assert ins.split()[-1] == "sc0" and instrs[i + 1].startswith("s_waitcnt") and "vmcnt(0)" in instrs[i + 1], (name, instrs[i:i + 2])
-        assert sum(x.split()[-1] == "sc1" for x in instrs if x.startswith("global_load_lds")) >= 2, name     # a walker's own word, a thief's probe
+        stores = [x for x in instrs if x.startswith("global_store_dword")]
         if "7PxF32NT" in name:
             assert stores and all(x.split()[-1] == "nt" for x in stores), (name, stores[:2])
         else:

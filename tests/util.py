@@ -63,10 +63,10 @@ def run_oracle(text, img, weights=None):
     return g.download_raw()
 
 
-def run_hip(ctx, text, img, flags=0, weights=None, rows_per_chunk=None, num_frames=1, slot=0, conv_path=0, exec_flags=0, texels_per_lane=0, walk_unit=0):
+def run_hip(ctx, text, img, flags=0, weights=None, rows_per_chunk=None, num_frames=1, slot=0, conv_path=0, exec_flags=0, texels_per_lane=0):
     H, W, _ = img.shape
     g = rf.Graph(ctx, rf.Config(text), W, H, pixel.fmt_of(img), num_frames=num_frames, flags=flags,
-                 rows_per_chunk=rows_per_chunk or 0, conv_path=conv_path, exec_flags=exec_flags, texels_per_lane=texels_per_lane, walk_unit=walk_unit)
+                 rows_per_chunk=rows_per_chunk or 0, conv_path=conv_path, exec_flags=exec_flags, texels_per_lane=texels_per_lane)
     try:
         for node, w in (weights or {}).items():
             g.set_weights(node, w)
