@@ -236,6 +236,14 @@ static hipError_t launch_user_node(rf_graph* g, const Launch& L, FrameSlot& f, c
         if (e != hipSuccess) return e;
     }
     const int rows = geo.y1 - geo.y0;
+    // a node that reads through windows: one workgroup per 64 x TH tile of the output, its inputs staged in LDS (rf_user_dev.h,
+    // UserTile); the grid a multiple of the 8 XCDs (the kernel gives each a contiguous range of tiles)
+    const UserTile tile = user_tile((int)bytes_per_pixel(fmt), u->radius, (int)u->inputs.size());
+    if (u->radius > 0 && tile.lds) {
+        A.grid_x = (geo.W + 63) / 64;
+        const long tiles = (long)A.grid_x * ((rows + tile.th - 1) / tile.th);
+        return jit_launch(*k, (unsigned)((tiles + 7) / 8 * 8), 256, &A, sizeof(A), stream);
+    }
     const unsigned gy = (unsigned)(rows > 1024 ? 1024 : rows);
     return jit_launch(*k, (unsigned)A.grid_x * gy, 256, &A, sizeof(A), stream);
 }

@@ -219,9 +219,13 @@ const Compiled* compile_expr(const std::string& expr, const std::vector<int>& us
     int rc = r->CreateProgram(&prog, source, "rf_stream_jit.hip", 0, nullptr, nullptr);
     if (rc != 0) { err = std::string("hiprtcCreateProgram: ") + r->GetErrorString(rc); return nullptr; }
     // the flags of the ahead-of-time build (Makefile): explicit fmaf only, no contraction -- bit-identical to the oracle
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", wpb.c_str()};
+    // A user NODE reads its neighbourhood through Window::at inside loops of the file's own (rf_user_dev.h): with small radii the
+    // window is a register copy, which only pays when those loops are unrolled -- a 5 x 5 tap loop over an inlined body is beyond
+    // the compiler's default threshold, so it is raised for these kernels (their bodies are a few hundred instructions).
+    const bool node = expr.find("user_node_kernel") != std::string::npos;
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", wpb.c_str(), "-mllvm", "-unroll-threshold=6000"};
     rc = r->AddNameExpression(prog, expr.c_str());
-    if (rc == 0) rc = r->CompileProgram(prog, 5, opts);
+    if (rc == 0) rc = r->CompileProgram(prog, node ? 7 : 5, opts);
     if (rc != 0) {
         size_t ls = 0;
         r->GetProgramLogSize(prog, &ls);

@@ -33,16 +33,51 @@ struct UserNodeArgs {
 };
 static_assert(sizeof(UserNodeArgs) == 4 * 8 * kUserNodeImages + 16 + 16 + 8 + 56, "UserNodeArgs is passed as a byte block");
 
+// RADIUS > 0: the workgroup's TILE.  64 x TH output texels per workgroup (256 threads = 64 columns x 4 thread rows, TY = TH / 4
+// outputs each, stacked vertically); the (64 + 2R) x (TH + 2R) texels they read are staged in LDS once -- raw, as the image holds
+// them; clamp-to-edge is resolved while the tile is filled -- and Window::at is an LDS read at a constant offset.  Sized so that
+// the tiles of all inputs fit the 64 KiB a workgroup may declare; a node too large for that (radius 15 with three rgba32f
+// inputs) keeps reading its windows where they lie.  Shared with the host, which sizes the grid.
+struct UserTile {
+    int th, ty;          // output rows per workgroup, per thread
+    bool lds;            // the tiles fit: the LDS kernel
+};
+constexpr int kUserRegWindowRadius = 2;      // up to this radius a thread ALSO keeps its window in registers and slides it down its outputs
+inline __host__ __device__ constexpr UserTile user_tile(int bpp, int radius, int n_inputs)
+{
+    for (int ty = radius <= kUserRegWindowRadius ? 8 : (radius <= 8 ? 4 : 2); ty >= 1; --ty) {
+        const long bytes = (long)n_inputs * (64 + 2 * radius) * (4 * ty + 2 * radius) * bpp;
+        if (bytes <= 64 * 1024) return UserTile{4 * ty, ty, true};
+    }
+    return UserTile{4, 1, false};
+}
+
 #ifdef __HIPCC_RTC__
-// RADIUS > 0: what apply() sees of an input image -- the texel's neighbourhood, read where it lies (L1 / L2 serve the re-use:
-// a texel is asked for by up to (2R+1)^2 lanes of neighbouring rows and columns); clamp-to-edge like every stencil of the library.
-// `bpp` is a constant of the instantiation: the format branch folds away.
+// RADIUS > 0: what apply() sees of an input image -- the texel's neighbourhood, clamp-to-edge like every stencil of the library.
+// Backed by the workgroup's LDS tile (`lds` = the LDS byte address of the texel itself, `lpitch` the tile's row pitch: dx and dy
+// are constants of the caller's unrolled loops, so a tap is one ds_read at an immediate offset; the outputs a thread stacks
+// vertically share most of their taps, which the compiler reads once), or, for a node whose tiles do not fit, by the image where
+// it lies (L1 / L2 serve the re-use).  `bpp` and the backing are constants of the instantiation: the branches fold away.
 struct Window {
     const char* base;
     unsigned long long pitch;
     int x, y, W, row_lo, row_hi, bpp;
+    unsigned lds, lpitch;
+    int rr;              // > 0: `w` holds a (2 rr + 1)^2 copy of the neighbourhood in registers (small radii)
+    f4 w[(2 * kUserRegWindowRadius + 1) * (2 * kUserRegWindowRadius + 1)];
     RF_DEV f4 at(int dx, int dy) const
     {
+        // small radii: the register copy the thread slides down its stack of outputs (2r+1 LDS reads per output instead of
+        // (2r+1)^2).  The offsets of a caller's unrolled loops are constants and pick registers; offsets only the run knows make
+        // the compiler index the copy in memory -- correct, slow: such a stage is better written with RADIUS >= 3 taps it needs.
+        if (rr > 0) return w[(dy + rr) * (2 * rr + 1) + dx + rr];
+        if (lds != 0u) {
+            const unsigned a = lds + (unsigned)(dy * (int)lpitch + dx * bpp);
+            if (bpp == 4) return PxU8::decode(*reinterpret_cast<const __attribute__((address_space(3))) unsigned*>(a));
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f t = *reinterpret_cast<const __attribute__((address_space(3))) v4f*>(a);
+            return make_float4(t.x, t.y, t.z, t.w);
+        }
         int xx = x + dx, yy = y + dy;
         xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
         yy = yy < row_lo ? row_lo : (yy > row_hi ? row_hi : yy);
@@ -52,13 +87,102 @@ struct Window {
 };
 
 template <class Px, class U>
-__global__ __launch_bounds__(256) void user_node_kernel(UserNodeArgs A)
+__global__ __launch_bounds__(256, 2) void user_node_kernel(UserNodeArgs A)
 {
+    typename U::P p;
+    __builtin_memcpy(&p, A.params, sizeof(p));
+    if constexpr (U::R > 0 && user_tile(Px::BPP, U::R, U::NI).lds) {
+        constexpr UserTile kT = user_tile(Px::BPP, U::R, U::NI);
+        constexpr int R = U::R, RW = 64 + 2 * R, RH = kT.th + 2 * R;
+        __shared__ __attribute__((aligned(16))) typename Px::Raw tile[U::NI][RH][RW];
+        // XCD-aware order (as the stream kernels'): workgroups are dealt round-robin over the 8 XCDs, so every XCD takes a
+        // contiguous range of tiles in raster order -- tiles that share halo columns and rows then share an L2
+        const int per_xcd = (int)gridDim.x >> 3;
+        const int q = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+        const int tiles_y = (A.y1 - A.y0 + kT.th - 1) / kT.th;
+        if (q >= A.grid_x * tiles_y) return;                                  // workgroup-uniform: in front of the barrier
+        const int tx0 = (q % A.grid_x) * 64, ty0 = A.y0 + (q / A.grid_x) * kT.th;
+        for (int i = (int)threadIdx.x; i < RW * RH; i += 256) {
+            const int r = i / RW, c = i - r * RW;
+            int gx = tx0 - R + c, gy = ty0 - R + r;
+            gx = gx < 0 ? 0 : (gx > A.W - 1 ? A.W - 1 : gx);
+            gy = gy < A.row_lo ? A.row_lo : (gy > A.row_hi ? A.row_hi : gy);
+#pragma unroll
+            for (int k = 0; k < U::NI; ++k)
+                tile[k][r][c] = Px::load(A.src[k] + (long long)gy * (long long)A.src_pitch[k], (unsigned)gx * (unsigned)Px::BPP);
+        }
+        __syncthreads();
+        const int lx = (int)(threadIdx.x & 63), ly = (int)(threadIdx.x >> 6) * kT.ty;
+        const int x = tx0 + lx;
+        const unsigned tile0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&tile[0][0][0]);
+        const unsigned lpitch = (unsigned)(RW * (int)sizeof(typename Px::Raw));
+        const bool col_ok = x < A.W;
+        const unsigned xoff = (unsigned)(col_ok ? x : 0) * (unsigned)Px::BPP;
+        auto lds_of = [&](int k, int row) { return tile0 + (unsigned)(((k * RH + row + R) * RW + lx + R) * (int)sizeof(typename Px::Raw)); };
+        auto emit = [&](int j, const f4 (&out)[U::NO]) {
+            const int y = ty0 + ly + j;
+            if (col_ok && y < A.y1) {
+#pragma unroll
+                for (int o = 0; o < U::NO; ++o)
+                    if (A.dst[o]) Px::store(A.dst[o] + (long long)y * (long long)A.dst_pitch[o], xoff, out[o]);
+            }
+        };
+        // every output of the thread is computed -- texels beyond the frame's edges are clamped copies in the tile -- and only
+        // the stores are masked
+        if constexpr (R <= kUserRegWindowRadius) {
+            // the neighbourhood in registers, slid down the thread's stack of outputs: a new bottom row per output
+            constexpr int D = 2 * R + 1;
+            Window in[U::NI];
+#pragma unroll
+            for (int k = 0; k < U::NI; ++k) {
+                in[k].base = nullptr; in[k].pitch = 0ull; in[k].x = x; in[k].W = A.W; in[k].row_lo = A.row_lo; in[k].row_hi = A.row_hi;
+                in[k].bpp = Px::BPP; in[k].lpitch = lpitch; in[k].rr = R;
+#pragma unroll
+                for (int r = 0; r < D - 1; ++r)
+#pragma unroll
+                    for (int c = 0; c < D; ++c)
+                        in[k].w[(r + 1) * D + c] = Px::decode(*reinterpret_cast<const __attribute__((address_space(3))) typename Px::Raw*>(
+                            lds_of(k, ly + r - R) + (unsigned)((c - R) * (int)sizeof(typename Px::Raw))));
+            }
+#pragma unroll
+            for (int j = 0; j < kT.ty; ++j) {
+#pragma unroll
+                for (int k = 0; k < U::NI; ++k) {
+#pragma unroll
+                    for (int i = 0; i < D * (D - 1); ++i) in[k].w[i] = in[k].w[i + D];      // (renaming: the loop is unrolled)
+#pragma unroll
+                    for (int c = 0; c < D; ++c)
+                        in[k].w[(D - 1) * D + c] = Px::decode(*reinterpret_cast<const __attribute__((address_space(3))) typename Px::Raw*>(
+                            lds_of(k, ly + j + R) + (unsigned)((c - R) * (int)sizeof(typename Px::Raw))));
+                    in[k].y = ty0 + ly + j;
+                    in[k].lds = lds_of(k, ly + j);
+                }
+                f4 out[U::NO];
+#pragma unroll
+                for (int o = 0; o < U::NO; ++o) out[o] = f4_zero();
+                U::node(p, in, out, A.buf_in);
+                emit(j, out);
+                __builtin_amdgcn_sched_barrier(0);      // one output at a time: the rows of the next are not fetched before this one is done
+            }
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < kT.ty; ++j) {
+                Window in[U::NI];
+#pragma unroll
+                for (int k = 0; k < U::NI; ++k)
+                    in[k] = Window{nullptr, 0ull, x, ty0 + ly + j, A.W, A.row_lo, A.row_hi, Px::BPP, lds_of(k, ly + j), lpitch, 0, {}};
+                f4 out[U::NO];
+#pragma unroll
+                for (int o = 0; o < U::NO; ++o) out[o] = f4_zero();
+                U::node(p, in, out, A.buf_in);
+                emit(j, out);
+            }
+        }
+        return;
+    } else {
     const unsigned bx = blockIdx.x % (unsigned)A.grid_x, by = blockIdx.x / (unsigned)A.grid_x, gy = gridDim.x / (unsigned)A.grid_x;
     const int x = (int)(bx * 256u + threadIdx.x);
     if (x >= A.W) return;
-    typename U::P p;
-    __builtin_memcpy(&p, A.params, sizeof(p));
     const unsigned xoff = (unsigned)x * (unsigned)Px::BPP;
     for (int y = A.y0 + (int)by; y < A.y1; y += (int)gy) {
         f4 out[U::NO];
@@ -67,7 +191,7 @@ __global__ __launch_bounds__(256) void user_node_kernel(UserNodeArgs A)
         if constexpr (U::R > 0) {
             Window in[U::NI];
 #pragma unroll
-            for (int i = 0; i < U::NI; ++i) in[i] = Window{A.src[i], A.src_pitch[i], x, y, A.W, A.row_lo, A.row_hi, Px::BPP};
+            for (int i = 0; i < U::NI; ++i) in[i] = Window{A.src[i], A.src_pitch[i], x, y, A.W, A.row_lo, A.row_hi, Px::BPP, 0u, 0u, 0, {}};
             U::node(p, in, out, A.buf_in);
         } else {
             f4 in[U::NI];
@@ -79,6 +203,7 @@ __global__ __launch_bounds__(256) void user_node_kernel(UserNodeArgs A)
 #pragma unroll
         for (int o = 0; o < U::NO; ++o)
             if (A.dst[o]) Px::store(A.dst[o] + (long long)y * (long long)A.dst_pitch[o], xoff, out[o]);
+    }
     }
 }
 
