@@ -98,7 +98,10 @@ um:    unsharp_mask { amount: 1.5, threshold: 0.02 }
 """
 WORKLOADS["user_types_4k"] = dict(text=USER_TYPES_4K, W=3840, H=2160, fmt=F32, nodes=3, seed=0x5EED0007, radius=3, strong=False, user_types=("edge_detect", "unsharp_mask"),
                                   desc="user filter types (files): gaussian5 + edge_detect fused, then unsharp_mask (two inputs, own kernel), 3840x2160 rgba32f")
-SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "chain3_8k_u8", "gauss9_8k_u8", "diamond_4k", "user_types_4k"]
+# a user type that reads a NEIGHBOURHOOD (RADIUS 2, Window::at): the LDS-tiled kernel of rf_user_dev.h
+WORKLOADS["user_window_4k"] = dict(text="input -> lc -> output\nlc: local_contrast { amount: 0.8 }", W=3840, H=2160, fmt=F32, nodes=1, seed=0x5EED0008, radius=2, strong=False,
+                                   user_types=("local_contrast",), desc="user filter type reading a 5x5 window (local_contrast.stage.hip, LDS-tiled kernel), 3840x2160 rgba32f")
+SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "chain3_8k_u8", "gauss9_8k_u8", "diamond_4k", "user_types_4k", "user_window_4k"]
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec)
 NO_POWER = False               # --no-power
@@ -116,7 +119,7 @@ def bpp_of(fmt):
 def kernel_sources_sha16():
     """Identity of the kernel sources the committed PMC traffic figures were measured on."""
     h = hashlib.sha256()
-    for f in ("rf_stream.hip", "rf_stream_dev.h", "rf_conv.hip", "rf_misc.hip", "rf_device.h"):
+    for f in ("rf_stream.hip", "rf_stream_dev.h", "rf_conv.hip", "rf_misc.hip", "rf_device.h", "rf_user_dev.h"):
         with open(os.path.join(ROOT, "reforge_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -318,6 +321,37 @@ def launch_roofline(g, wl, launches, rows, n_ev, traffic_key=None):
 
 
 COLD_SLOTS = 5
+_COPY_MS = {}
+
+
+def stream_copy_ms(rf, ctx, W, H, fmt):
+    """ms per frame of the passthrough launch on a W x H frame of this format: the SAME stream-kernel structure with no
+    arithmetic and no halo, i.e. what a launch of this design can reach on THIS box today (boxes of the pool differ by up to
+    10 %, and so do two placements of the same images on one box: profiles/r04_placement.txt).  Call it BEFORE the workload's
+    graph is created: its two images are freed again, and hipMalloc hands the workload the same blocks, so the yardstick and
+    the workload stream through the same memory."""
+    key = (W, H, fmt)
+    if key not in _COPY_MS:
+        gp = rf.Graph(ctx, rf.Config("input -> passthrough -> output"), W, H, fmt)
+        try:
+            gp.fill_synthetic(1)
+            gp.execute(); gp.wait()
+            t1 = max(gp.time_frames(3) / 3, 1e-3)
+            n = int(max(5, min(20000, 150.0 / t1)))
+            _COPY_MS[key] = min(gp.time_frames(n) / n for _ in range(2))
+        finally:
+            gp.close()
+    return _COPY_MS[key]
+
+
+def against_stream_copy(roof, copy_ms, n_images):
+    """the dominant launch beside the same-structure copy of as many images as it moves: frac_of_stream_copy = 1 means the
+    stencil launch streams as fast as a plain copy does on this box (variants are compared on THIS figure, not on frac)"""
+    if roof.get("bound") != "hbm" or not copy_ms:
+        return
+    same_bytes_ms = copy_ms * n_images / 2.0
+    roof["stream_copy_ms"] = round(same_bytes_ms, 5)
+    roof["frac_of_stream_copy"] = round(same_bytes_ms / roof["launch_ms"], 4)
 
 
 def cold_leg(rf, ctx, wl, launches, flags, verify=True, in_flight=True):
@@ -395,6 +429,7 @@ def side_workload(rf, ctx, name, verify=True):
             for t in wl["user_types"]:
                 ograph.register_user_type(t, os.path.join(ROOT, "shaders", t + ".stage.hip"))
     variants = CONV_PATHS if name == "conv31_8k" else (("", 0),)
+    copy_ms = None if name == "conv31_8k" else stream_copy_ms(rf, ctx, wl["W"], wl["H"], wl["fmt"])      # before the graph: same blocks
     for vname, path in variants:
         g = rf.Graph(ctx, rf.Config(wl["text"]), wl["W"], wl["H"], wl["fmt"], conv_path=path)
         g.fill_synthetic(wl["seed"])
@@ -404,6 +439,8 @@ def side_workload(rf, ctx, name, verify=True):
         n = int(max(5, min(20000, 300.0 / t1)))                    # ~0.3 s of frames (a 12 ms window read the 4K rgba8 chain 20 % slow: clock ramp)
         frame_ms = g.time_frames(n) / n
         per_launch, roof = launch_roofline(g, wl, launches, g.rows, int(max(5, min(n, 150.0 / t1))), traffic_key=name if not vname else name + "_" + vname)
+        dom = max(range(len(per_launch)), key=lambda i: per_launch[i][1])
+        against_stream_copy(roof, copy_ms, len(launches[dom]["inputs"]) + 1)
         res = {"ms_per_frame": round(frame_ms, 5), "mpx_per_s": round(wl["W"] * wl["H"] / frame_ms / 1e3, 1), "frames_timed": n,
                "launches": [l["label"] for l in launches], "launch_ms": {k: round(v, 5) for k, v in per_launch}, "roofline": roof}
         if roof["bound"] == "hbm":
@@ -605,6 +642,14 @@ def main():
         return ctx, g
 
     # ---- the headline: K timed steps per halo schedule -------------------------------------------
+    # the same-structure copy of the headline's frame, BEFORE its graph exists (stream_copy_ms: the same blocks of memory);
+    # not in a profiling pass, whose kernel trace it would join
+    head_copy_ms = None
+    if world == 1 and not args.skip_workloads and not args.cold_only:
+        try:
+            head_copy_ms = stream_copy_ms(rf, ctx_plain, wl["W"], H, wl["fmt"])
+        except rf.RfError:
+            head_copy_ms = None
     legs = {}
     fps = args.frames_per_step
     poisoned = False                                   # an exchange that failed may have left a collective stuck on its stream
@@ -686,6 +731,9 @@ def main():
     n_ev = max(20, min(args.steps * fps, 400))
     per_launch, roofline = launch_roofline(g, wl, launches, rows, n_ev,
                                            traffic_key=args.workload + ("_unfused" if args.no_fusion else ""))
+    if head_copy_ms:
+        dom_i = max(range(len(per_launch)), key=lambda i: per_launch[i][1])
+        against_stream_copy(roofline, head_copy_ms, len(launches[dom_i]["inputs"]) + 1)
     each = sorted(g.time_each_frame(max(20, min(args.steps * fps, 200))))     # median and min per frame
     frame_events = {"median_ms": round(each[len(each) // 2], 5), "min_ms": round(each[0], 5), "frames": len(each),
                     "note": "hipEvent pair per frame on the frame's stream (adds a marker packet per frame)"}
@@ -812,24 +860,15 @@ def main():
 
     # ---- N = 1: the other BASELINE configs, the copy rate of the box, the CPU baseline -------------
     if rank == 0 and world == 1:
-        try:
-            out["copy_gbps"] = round(ctx.copy_bandwidth(256 << 20, 20), 1)
-        except rf.RfError:
-            out["copy_gbps"] = None
-        out["roofline"]["copy_gbps"] = out["copy_gbps"]
-        # a better yardstick than the float4 grid-stride copy above (which reads ~5.1 TB/s): the SAME stream-kernel structure with no
-        # arithmetic and no halo -- the passthrough node -- beyond the Infinity Cache (7680x4320) and inside it (3840x2160).  What a
-        # stencil launch of this design can hope for is this rate, not 8 TB/s.
+        # The yardstick: the SAME stream-kernel structure with no arithmetic and no halo -- the passthrough launch -- beyond the
+        # Infinity Cache (7680x4320) and inside it (3840x2160).  What a stencil launch of this design can hope for is this rate,
+        # not 8 TB/s; every workload carries its own (`roofline.frac_of_stream_copy`, measured on the workload's own frame size
+        # right before the workload, through the same blocks of memory).  (`copy_gbps`, a float4 grid-stride loop that read 16 %
+        # under the guide's own copy, is gone: rf_ctx_copy_bandwidth now runs the passthrough launch too.)
         try:
             yard = {}
             for key, (w_, h_) in (() if args.skip_workloads else (("8k", (7680, 4320)), ("4k", (3840, 2160)))):      # not in a profiling pass: its launches would drown the workload's
-                gp = rf.Graph(ctx, rf.Config("input -> passthrough -> output"), w_, h_, F32)
-                gp.fill_synthetic(1)
-                gp.execute(); gp.wait()
-                t1 = max(gp.time_frames(3) / 3, 1e-3)
-                n_ = int(max(5, min(20000, 200.0 / t1)))
-                ms_ = min(gp.time_frames(n_) / n_ for _ in range(2))
-                gp.close()
+                ms_ = stream_copy_ms(rf, ctx, w_, h_, F32)
                 yard[key] = {"ms_per_frame": round(ms_, 5), "gbps": round(2 * w_ * h_ * 16 / (ms_ * 1e-3) / 1e9, 1)}
             if yard:
                 out["roofline"]["stream_copy"] = yard

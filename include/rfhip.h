@@ -381,8 +381,10 @@ rf_status rf_graph_time_each_frame(rf_graph* g, int iters, float* ms_each);
 /* one-rank RCCL round trip (communicator of world 1, grouped send+recv to self of
  * `bytes` bytes on `device`): librccl loads and is called with the right ABI */
 rf_status rf_comm_selftest(int device, size_t bytes);
-/* float4 copy of `bytes` device bytes, `iters` times: achieved GB/s (the
- * practical HBM ceiling on this box) */
+/* copy of `bytes` device bytes (rounded down to whole 7680-texel rgba32f rows), `iters` times, by the library's own
+ * passthrough launch -- the stream kernel with no arithmetic and no halo: achieved GB/s (read + written), what a launch of
+ * this design can reach on this box beyond the Infinity Cache.  (Until round 4 this was a float4 grid-stride loop that read
+ * 5.1-5.3 TB/s where the passthrough launch itself reaches 6.0: a yardstick below what it measures.) */
 rf_status rf_ctx_copy_bandwidth(rf_ctx* ctx, size_t bytes, int iters, float* gbps);
 
 #ifdef __cplusplus

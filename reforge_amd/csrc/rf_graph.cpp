@@ -494,21 +494,33 @@ extern "C" const char* rf_ctx_device_arch(const rf_ctx* ctx) { return ctx ? ctx-
 
 extern "C" rf_status rf_ctx_copy_bandwidth(rf_ctx* ctx, size_t bytes, int iters, float* gbps)
 {
-    if (!ctx || !gbps || iters < 1 || bytes < 16) return fail(RF_ERR_INVALID, "rf_ctx_copy_bandwidth: bad argument");
+    if (!ctx || !gbps || iters < 1) return fail(RF_ERR_INVALID, "rf_ctx_copy_bandwidth: bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
+    const int W = 7680;
+    const size_t pitch = image_pitch((size_t)W * 16);
+    const int rows = (int)std::min<size_t>(bytes / pitch, 1u << 20);
+    if (rows < 1) return fail(RF_ERR_INVALID, "rf_ctx_copy_bandwidth: fewer bytes than one row");
     void *a = nullptr, *b = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     rf_status st = RF_OK;
     float ms = 0.f;
     auto body = [&]() -> rf_status {
-        HIP_TRY(hipMalloc(&a, bytes));
-        HIP_TRY(hipMalloc(&b, bytes));
-        HIP_TRY(hipMemsetAsync(a, 0x3c, bytes, ctx->util_stream));
+        HIP_TRY(hipMalloc(&a, (size_t)rows * pitch));
+        HIP_TRY(hipMalloc(&b, (size_t)rows * pitch));
+        HIP_TRY(hipMemsetAsync(a, 0x3c, (size_t)rows * pitch, ctx->util_stream));
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
-        for (int i = 0; i < 3; ++i) HIP_TRY(launch_copy(a, b, bytes, ctx->util_stream));
+        Op pass;
+        Geom geo;
+        geo.W = W;
+        geo.row_lo = 0;
+        geo.row_hi = rows - 1;
+        geo.y0 = 0;
+        geo.y1 = rows;
+        const StreamTuning tune;
+        for (int i = 0; i < 3; ++i) HIP_TRY(launch_ops(kFmtRGBA32F, &pass, 1, Image{a, pitch}, Image{b, pitch}, geo, tune, ctx->util_stream));
         HIP_TRY(hipEventRecord(e0, ctx->util_stream));
-        for (int i = 0; i < iters; ++i) HIP_TRY(launch_copy(a, b, bytes, ctx->util_stream));
+        for (int i = 0; i < iters; ++i) HIP_TRY(launch_ops(kFmtRGBA32F, &pass, 1, Image{a, pitch}, Image{b, pitch}, geo, tune, ctx->util_stream));
         HIP_TRY(hipEventRecord(e1, ctx->util_stream));
         HIP_TRY(hipEventSynchronize(e1));
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
@@ -520,7 +532,7 @@ extern "C" rf_status rf_ctx_copy_bandwidth(rf_ctx* ctx, size_t bytes, int iters,
     if (a) (void)hipFree(a);
     if (b) (void)hipFree(b);
     if (st != RF_OK) return st;
-    *gbps = (float)(2.0 * (double)(bytes / 16 * 16) * iters / ((double)ms * 1e-3) / 1e9);
+    *gbps = (float)(2.0 * (double)W * 16.0 * (double)rows * iters / ((double)ms * 1e-3) / 1e9);
     return RF_OK;
 }
 

@@ -141,9 +141,6 @@ hipError_t launch_upload_srgb8(int fmt, const uint8_t* rgba, size_t stride, Imag
 hipError_t launch_download_srgb8(int fmt, Image src, uint8_t* rgba, size_t stride, int W, int rows,
                                  const float* tables, hipStream_t stream);
 
-// float4 grid-stride copy (bandwidth probe)
-hipError_t launch_copy(const void* src, void* dst, size_t bytes, hipStream_t stream);
-
 // host-side parameter derivation shared with nothing else (the oracle has its own)
 void gaussian_weights(float sigma, int radius, float* w);          // w[0..radius]
 void sharpen_weights(float amount, float* centre, float* side);

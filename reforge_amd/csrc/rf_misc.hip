@@ -147,13 +147,6 @@ __global__ __launch_bounds__(256) void split_luma_kernel(const char* src, size_t
     }
 }
 
-__global__ __launch_bounds__(256) void copy_kernel(const f4* __restrict__ src, f4* __restrict__ dst, size_t n)
-{
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t step = (size_t)gridDim.x * 256;
-    for (; i < n; i += step) dst[i] = src[i];
-}
-
 static dim3 fill_grid(int W, int rows)
 {
     unsigned gy = (unsigned)(rows < 1 ? 1 : (rows > 1024 ? 1024 : rows));
@@ -236,17 +229,6 @@ hipError_t launch_split_luma(int fmt, Image src, Image luma, Image chroma, const
         hipLaunchKernelGGL((split_luma_kernel<PxU8>), grid, dim3(256), 0, stream, ps, src.pitch, pl, luma.pitch, pc, chroma.pitch, g.W, g.y0, g.y1);
     else
         hipLaunchKernelGGL((split_luma_kernel<PxF32>), grid, dim3(256), 0, stream, ps, src.pitch, pl, luma.pitch, pc, chroma.pitch, g.W, g.y0, g.y1);
-    return hipGetLastError();
-}
-
-hipError_t launch_copy(const void* src, void* dst, size_t bytes, hipStream_t stream)
-{
-    size_t n = bytes / sizeof(f4);
-    if (n == 0) return hipSuccess;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const f4*>(src),
-                       static_cast<f4*>(dst), n);
     return hipGetLastError();
 }
 

@@ -70,7 +70,9 @@ struct Window {
         // small radii: the register copy the thread slides down its stack of outputs (2r+1 LDS reads per output instead of
         // (2r+1)^2).  The offsets of a caller's unrolled loops are constants and pick registers; offsets only the run knows make
         // the compiler index the copy in memory -- correct, slow: such a stage is better written with RADIUS >= 3 taps it needs.
-        if (rr > 0) return w[(dy + rr) * (2 * rr + 1) + dx + rr];
+        // (indexed about the centre of the 5 x 5 storage whatever the radius, with constants only: the copy must become registers
+        // under every compiler build a process may get -- PyTorch bundles an older one -- and an index through `rr` did not)
+        if (rr > 0) return w[(dy + kUserRegWindowRadius) * (2 * kUserRegWindowRadius + 1) + dx + kUserRegWindowRadius];
         if (lds != 0u) {
             const unsigned a = lds + (unsigned)(dy * (int)lpitch + dx * bpp);
             if (bpp == 4) return PxU8::decode(*reinterpret_cast<const __attribute__((address_space(3))) unsigned*>(a));
@@ -131,29 +133,31 @@ __global__ __launch_bounds__(256, 2) void user_node_kernel(UserNodeArgs A)
         // the stores are masked
         if constexpr (R <= kUserRegWindowRadius) {
             // the neighbourhood in registers, slid down the thread's stack of outputs: a new bottom row per output
-            constexpr int D = 2 * R + 1;
+            constexpr int C = kUserRegWindowRadius, S = 2 * C + 1;      // storage: S x S about its centre (C, C); rows / columns -R .. R are in use
             Window in[U::NI];
 #pragma unroll
             for (int k = 0; k < U::NI; ++k) {
                 in[k].base = nullptr; in[k].pitch = 0ull; in[k].x = x; in[k].W = A.W; in[k].row_lo = A.row_lo; in[k].row_hi = A.row_hi;
                 in[k].bpp = Px::BPP; in[k].lpitch = lpitch; in[k].rr = R;
 #pragma unroll
-                for (int r = 0; r < D - 1; ++r)
+                for (int r = -R + 1; r <= R; ++r)          // the window of output -1: its rows -R+1 .. R are the rows -R .. R-1 of output 0
 #pragma unroll
-                    for (int c = 0; c < D; ++c)
-                        in[k].w[(r + 1) * D + c] = Px::decode(*reinterpret_cast<const __attribute__((address_space(3))) typename Px::Raw*>(
-                            lds_of(k, ly + r - R) + (unsigned)((c - R) * (int)sizeof(typename Px::Raw))));
+                    for (int c = -R; c <= R; ++c)
+                        in[k].w[(r + C) * S + c + C] = Px::decode(*reinterpret_cast<const __attribute__((address_space(3))) typename Px::Raw*>(
+                            lds_of(k, ly + r - 1) + (unsigned)(c * (int)sizeof(typename Px::Raw))));
             }
 #pragma unroll
             for (int j = 0; j < kT.ty; ++j) {
 #pragma unroll
                 for (int k = 0; k < U::NI; ++k) {
 #pragma unroll
-                    for (int i = 0; i < D * (D - 1); ++i) in[k].w[i] = in[k].w[i + D];      // (renaming: the loop is unrolled)
+                    for (int r = -R; r < R; ++r)
 #pragma unroll
-                    for (int c = 0; c < D; ++c)
-                        in[k].w[(D - 1) * D + c] = Px::decode(*reinterpret_cast<const __attribute__((address_space(3))) typename Px::Raw*>(
-                            lds_of(k, ly + j + R) + (unsigned)((c - R) * (int)sizeof(typename Px::Raw))));
+                        for (int c = -R; c <= R; ++c) in[k].w[(r + C) * S + c + C] = in[k].w[(r + 1 + C) * S + c + C];      // (renaming: the loops are unrolled)
+#pragma unroll
+                    for (int c = -R; c <= R; ++c)
+                        in[k].w[(R + C) * S + c + C] = Px::decode(*reinterpret_cast<const __attribute__((address_space(3))) typename Px::Raw*>(
+                            lds_of(k, ly + j + R) + (unsigned)(c * (int)sizeof(typename Px::Raw))));
                     in[k].y = ty0 + ly + j;
                     in[k].lds = lds_of(k, ly + j);
                 }
