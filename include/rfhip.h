@@ -181,11 +181,9 @@ const char* rf_plan_launch_output(const rf_plan* plan, int i);
  * built-in `split_luma` has luma_image and chroma_image): all of them, in binding order */
 int         rf_plan_launch_num_outputs(const rf_plan* plan, int i);
 const char* rf_plan_launch_output_at(const rf_plan* plan, int i, int k);
-/* rows a launch reads above/below the rows it writes: the sum of its members' stencil radii.  For a fused fork/join launch
- * this is pre + a + b + post, not pre + max(a, b) + post: the two branches run one behind the other inside the kernel (the
- * other branch's row rides a delay line), so the launch READS -- and a row strip exchanges / over-fetches -- a + b rows for
- * the pair although the arithmetic of an output row reaches only max(a, b).  Results are unaffected; the cost is min(a, b)
- * extra halo rows per side and an earlier "strip height smaller than the halo" limit at N > 1. */
+/* rows a launch reads above/below the rows it writes: the sum of its members' stencil radii; for a fused fork/join launch
+ * pre + max(a, b) + post -- its two branches run side by side inside the kernel (the shorter one ends in a delay line), so this
+ * is also what a row strip exchanges or over-fetches for it */
 int         rf_plan_launch_radius(const rf_plan* plan, int i);
 /* 1 if the launch's layer runs in plan order on one stream: one of its launches writes an image
  * another launch of the layer reads or writes (an in-place point op beside a second consumer).

@@ -87,7 +87,8 @@ struct StreamTuning {
 
 // Row stages of a streaming launch (rf_stream_dev.h): the run-time description that selects -- or, for a list the
 // ahead-of-time catalogue lacks, GENERATES -- the kernel, and lays out its parameter block.
-enum StageKind : int { ST_NODE_END = 0, ST_HTAP = 1, ST_VTAP = 2, ST_GRADE = 3, ST_CROSS3 = 4, ST_DUP = 5, ST_MIX = 6, ST_USER = 7 };
+enum StageKind : int { ST_NODE_END = 0, ST_HTAP = 1, ST_VTAP = 2, ST_GRADE = 3, ST_CROSS3 = 4, ST_DUP = 5, ST_MIX = 6, ST_USER = 7,
+                       ST_DELAY = 8 };     // r rows of delay at the end of the fork/join branch with the smaller vertical radius (StDelay)
 enum StageSlot : int { SLOT_PLAIN = 0, SLOT_SOLO = 1, SLOT_ON0 = 2, SLOT_ON1 = 3 };   // wrapper of a stage in a fork/join (pair) pipeline
 struct StageList {
     static constexpr int kMax = 3 * kMaxFusedOps + 4;

@@ -141,6 +141,7 @@ static std::string stage_letter(int kind, int r, int user = -1)
         case ST_CROSS3: return "C";
         case ST_DUP: return "D";
         case ST_MIX: return "M";
+        case ST_DELAY: return "L" + std::to_string(r);
         default: return "E";
     }
 }
@@ -171,7 +172,8 @@ std::string StageList::type_list() const
     std::string t;
     for (int i = 0; i < n; ++i) {
         const std::string base = stage_type(st[i].kind, st[i].r, st[i].user);
-        if (st[i].kind == ST_DUP || st[i].kind == ST_MIX || st[i].slot == SLOT_PLAIN) t += base;
+        if (st[i].kind == ST_DELAY) t += std::string("rf::StDelay<") + (st[i].slot == SLOT_ON0 ? "0" : "1") + ", " + std::to_string(st[i].r) + ">";
+        else if (st[i].kind == ST_DUP || st[i].kind == ST_MIX || st[i].slot == SLOT_PLAIN) t += base;
         else if (st[i].slot == SLOT_SOLO) t += "rf::StSolo<" + base + ">";
         else t += std::string("rf::StOn<") + (st[i].slot == SLOT_ON0 ? "0" : "1") + ", " + base + ">";
         if (i + 1 < n) t += ", ";
@@ -180,8 +182,21 @@ std::string StageList::type_list() const
 }
 
 static int stage_rv(int kind, int r) { return kind == ST_VTAP || kind == ST_USER ? r : (kind == ST_CROSS3 ? 1 : 0); }
-int StageList::sum_rh() const { int v = 0; for (int i = 0; i < n; ++i) v += (st[i].kind == ST_HTAP || st[i].kind == ST_USER) ? st[i].r : (st[i].kind == ST_CROSS3 ? 1 : 0); return v; }
-int StageList::sum_rv() const { int v = 0; for (int i = 0; i < n; ++i) v += stage_rv(st[i].kind, st[i].r); return v; }
+static int stage_rh(int kind, int r) { return (kind == ST_HTAP || kind == ST_USER) ? r : (kind == ST_CROSS3 ? 1 : 0); }
+// reach of a list (SumRH / SumRV of rf_stream_dev.h): the stages outside the branches of a fork/join add up, of the two branches --
+// which run side by side -- the larger counts
+static int reach(const StageList& sl, int (*radius)(int, int))
+{
+    int solo = 0, on[2] = {0, 0};
+    for (int i = 0; i < sl.n; ++i) {
+        const int v = radius(sl.st[i].kind, sl.st[i].r);
+        if (sl.st[i].slot == SLOT_ON0 || sl.st[i].slot == SLOT_ON1) on[sl.st[i].slot == SLOT_ON1] += v;
+        else solo += v;
+    }
+    return solo + std::max(on[0], on[1]);
+}
+int StageList::sum_rh() const { return reach(*this, stage_rh); }
+int StageList::sum_rv() const { return reach(*this, stage_rv); }
 int StageList::max_rv() const { int v = 0; for (int i = 0; i < n; ++i) v = std::max(v, stage_rv(st[i].kind, st[i].r)); return v; }
 int StageList::taps() const
 {
@@ -199,7 +214,7 @@ int StageList::vgpr_estimate(int texels) const
         if (st[i].kind == ST_CROSS3) v += 16 * texels;
         if (st[i].kind == ST_USER && st[i].r > 0) v += 24 * texels + 12;      // two rows of (west, centre, east) + the neighbourhood handed to apply()
         if (st[i].kind == ST_HTAP) v += (i == 0 && texels == 1 && st[i].r <= 7 && !pair()) ? 4 * (2 * st[i].r + 1) : 0;
-        if (st[i].slot == SLOT_ON0 || st[i].slot == SLOT_ON1) v += 4 * texels * stage_rv(st[i].kind, st[i].r);     // the other slot's delay line
+        if (st[i].kind == ST_DELAY) v += 4 * texels * st[i].r;     // the delay line of the shorter branch
     }
     int transient = 0;
     for (int i = 0; i < n; ++i)
@@ -271,10 +286,16 @@ bool ops_to_stages(const Op* ops, int n, StageList& out)
     if (!run(0, first_branch, 0, SLOT_SOLO)) return false;
     if (out.n > 0 && !last_is_end(SLOT_SOLO) && !push(ST_NODE_END, 0, SLOT_SOLO, -1)) return false;   // the forked image is stored and loaded
     if (!push(ST_DUP, 0, SLOT_SOLO, -1)) return false;
+    int branch_rv[2] = {0, 0};
+    for (int i = first_branch; i < mix; ++i)
+        if (ops[i].slot == 1 || ops[i].slot == 2) branch_rv[ops[i].slot - 1] += (ops[i].kind == OP_GAUSSIAN || ops[i].kind == OP_USER) ? ops[i].radius : (ops[i].kind == OP_SHARPEN ? 1 : 0);
     for (int b = 0; b < 2; ++b) {
         const int before = out.n, slot = b == 0 ? SLOT_ON0 : SLOT_ON1;
         if (!run(first_branch, mix, b + 1, slot)) return false;
         if (out.n > before && !last_is_end(slot) && !push(ST_NODE_END, 0, slot, -1)) return false;    // the branch result is stored and loaded by the join
+        // the branches run side by side: the one of the smaller vertical radius ends in a delay line, so that both reach the join
+        // with the same frame row (rf_stream_dev.h, StDelay)
+        if (branch_rv[b] < branch_rv[1 - b] && !push(ST_DELAY, branch_rv[1 - b] - branch_rv[b], slot, -1)) return false;
     }
     if (!push(ST_MIX, 0, SLOT_SOLO, mix)) return false;
     const int after = out.n;
@@ -419,6 +440,7 @@ template <> struct StageKey<StDup> { static std::string get() { return "sD "; } 
 template <> struct StageKey<StMix> { static std::string get() { return "sM "; } };
 template <class S> struct StageKey<StSolo<S>> { static std::string get() { return "s" + StageKey<S>::get(); } };
 template <int K, class S> struct StageKey<StOn<K, S>> { static std::string get() { return (K == 0 ? "a" : "b") + StageKey<S>::get(); } };
+template <int K, int D> struct StageKey<StDelay<K, D>> { static std::string get() { return std::string(K == 0 ? "a" : "b") + "L" + std::to_string(D) + " "; } };
 
 #ifndef RF_PF_DEFAULT
 #define RF_PF_DEFAULT 4
@@ -513,7 +535,7 @@ static const std::map<std::string, AotEntry>& built_catalogue()
         typedef typename Join<NodeTL<1>::type, NodeTL<2>::type>::type Tail;
         add_to_catalogue<PF_DEFAULT>(typename Join<Head, Tail>::type{});      // gaussian5 -> grade -> sharpen -> gaussian9 -> grade
         // the fork/join example of pipeline_graph.rs:462-468 (gaussian5 || sharpen -> combination) as ONE launch
-        add_to_catalogue<PF_DEFAULT>(TL<StDup, StOn<0, StHTap<2>>, StOn<0, StVTap<2>>, StOn<0, StNodeEnd>, StOn<1, StCross3>, StOn<1, StNodeEnd>, StMix>{});
+        add_to_catalogue<PF_DEFAULT>(TL<StDup, StOn<0, StHTap<2>>, StOn<0, StVTap<2>>, StOn<0, StNodeEnd>, StOn<1, StCross3>, StOn<1, StNodeEnd>, StDelay<1, 1>, StMix>{});
     }
     return catalogue();
 }
@@ -537,18 +559,21 @@ bool stream_supported(const Op* ops, int n, bool allow_jit)
 
 int ops_radius(const Op* ops, int n)
 {
-    int r = 0;
+    // a fused fork/join launch (ops of slot 1 / 2 = its two branches) runs the branches side by side: pre + max(a, b) + post
+    int r[3] = {0, 0, 0};
     for (int i = 0; i < n; ++i) {
+        int v = 0;
         switch (ops[i].kind) {
-            case OP_GAUSSIAN: r += ops[i].radius; break;
-            case OP_SHARPEN: r += 1; break;
-            case OP_USER: r += ops[i].radius; break;
-            case OP_USERN: r += ops[i].radius; break;
-            case OP_CONV2D: r += ops[i].radius; break;
+            case OP_GAUSSIAN: v = ops[i].radius; break;
+            case OP_SHARPEN: v = 1; break;
+            case OP_USER: v = ops[i].radius; break;
+            case OP_USERN: v = ops[i].radius; break;
+            case OP_CONV2D: v = ops[i].radius; break;
             default: break;
         }
+        r[ops[i].slot >= 0 && ops[i].slot <= 2 ? ops[i].slot : 0] += v;
     }
-    return r;
+    return r[0] + std::max(r[1], r[2]);
 }
 
 // Walk policy of a launch (measured with scripts/walk_probe.py on MI355X):

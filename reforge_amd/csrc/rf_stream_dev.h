@@ -523,10 +523,14 @@ template <class U> struct StUser {
 // Fork / join in ONE launch (the diamond of src/vulkan/pipeline_graph.rs:462-468: two branches read one image
 // and a `combination` node joins them).  Between the fork and the join the value that travels down the stage
 // chain is a PAIR of rows -- slot 0 = texels [0, T) of a Tex<2T>, slot 1 = [T, 2T) -- and the two branches are
-// laid end to end: a stage of branch K works on slot K while the other slot rides a delay line of the stage's
-// vertical radius, so both slots always hold the SAME frame row and the per-stage schedule of the linear chain
-// (first / flush / emit) needs no change.  The source rows cross the fabric once for both branches and neither
-// branch result is ever stored: the 4K diamond moves 2 image passes instead of 7.
+// laid end to end in the stage list, but they run SIDE BY SIDE: a stage of branch K works on slot K and leaves the
+// other slot alone, every stage keeps the schedule of ITS slot's rows (Chain: has-bits, needs and last-emission
+// iterations are per slot), the fork hands each slot the rows that slot needs, and the branch of the smaller
+// vertical radius ends in a delay line (StDelay) so that both slots reach the join with the same frame row.  The
+// launch therefore reads pre + max(a, b) + post halo rows -- what a row strip exchanges or over-fetches -- and loses
+// pre + max(a, b) + post halo lanes per side.  (Until round 4 the branches ran one BEHIND the other, the idle slot
+// riding a delay line per stage: a + b.)  The source rows cross the fabric once for both branches and neither branch
+// result is ever stored: the 4K diamond moves 2 image passes instead of 7.
 // ---------------------------------------------------------------------------------
 template <class S> struct SlotsOf { static constexpr int value = 1; };
 
@@ -558,7 +562,7 @@ template <class S> struct StSolo {
 };
 template <class S> struct SlotsOf<StSolo<S>> { static constexpr int value = 2; };
 
-// the fork: both branches start from the same row
+// the fork: both branches start from the same row (Chain gives each slot the rows IT needs: see Chain::fork_bits)
 struct StDup {
     static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
     struct Params {};
@@ -572,38 +576,38 @@ struct StDup {
 };
 template <> struct SlotsOf<StDup> { static constexpr int value = 2; };
 
-// stage S on slot K; the other slot is delayed by S::RV rows (a stage of vertical radius R emits the row that
-// arrived R iterations ago: the delay line hands out that same row of the other slot).  On flush ticks (rows
-// repeated below the frame) the line keeps shifting: the rows it still owes are real ones that arrived earlier.
+// stage S on slot K; the other slot passes (Chain copies it through whether or not this stage has a row this iteration)
 template <int K, class S> struct StOn {
     static constexpr int RV = S::RV, RH = S::RH, LDS_ROWS = S::LDS_ROWS;
     typedef typename S::Params Params;
-    template <class Px, int T> struct State {
-        typename S::template State<Px, T> inner;
-        Tex<T> line[RV > 0 ? RV : 1];
-    };
+    template <class Px, int T> using State = typename S::template State<Px, T>;
     template <class Px, int T> using Feed = OwnFeed<Px, T>;
     template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params& p, State<Px, T>& s, const Lane<T>& L, f4* lds, const Tex<2 * T>& v, bool real, bool first, bool emit, Tex<2 * T>& out)
     {
         Tex<T> o = tex_zero<T>();
-        S::template advance<Px, REV, T, KEEP>(p, s.inner, L, lds, take_slot<T>(v, K), real, first, emit, o);
+        S::template advance<Px, REV, T, KEEP>(p, s, L, lds, take_slot<T>(v, K), real, first, emit, o);
         put_slot<T>(out, K, o);
-        const Tex<T> other = take_slot<T>(v, 1 - K);
-        if constexpr (RV == 0) {
-            put_slot<T>(out, 1 - K, other);
-        } else {
-            if (first) {
-#pragma unroll
-                for (int i = 0; i < RV; ++i) s.line[i] = other;
-            }
-            put_slot<T>(out, 1 - K, s.line[0]);
-#pragma unroll
-            for (int i = 0; i + 1 < RV; ++i) s.line[i] = s.line[i + 1];
-            s.line[RV - 1] = other;
-        }
     }
 };
 template <int K, class S> struct SlotsOf<StOn<K, S>> { static constexpr int value = 2; };
+
+// D rows of delay on slot K: the end of the branch with the smaller vertical radius.  It needs no row above the one it emits
+// and D rows below (the rows that push it out): RT = 0, RB = D in the schedule (every other stage: RT = RB = RV).
+template <int K, int D> struct StDelay {
+    static_assert(D >= 1, "a delay of nothing is no stage");
+    static constexpr int RV = 0, RH = 0, LDS_ROWS = 0;
+    struct Params {};
+    template <class Px, int T> struct State { Tex<T> line[D]; };
+    template <class Px, int T> using Feed = OwnFeed<Px, T>;
+    template <class Px, bool REV, int T, bool KEEP> RF_DEV static void advance(const Params&, State<Px, T>& s, const Lane<T>&, f4*, const Tex<2 * T>& v, bool, bool, bool, Tex<2 * T>& out)
+    {
+        put_slot<T>(out, K, s.line[0]);      // the row that arrived D ticks ago (before that: never emitted, see the schedule)
+#pragma unroll
+        for (int i = 0; i + 1 < D; ++i) s.line[i] = s.line[i + 1];
+        s.line[D - 1] = take_slot<T>(v, K);
+    }
+};
+template <int K, int D> struct SlotsOf<StDelay<K, D>> { static constexpr int value = 2; };
 
 // the join: combination, out = fma(mix, b - a, a) per channel (oracle/rf_oracle.c rfo_mix), a = slot 0, b = slot 1
 struct StMix {
@@ -638,28 +642,54 @@ template <class S, class... Rest> struct alignas(8) ParamPack<S, Rest...> {
     alignas(8) ParamPack<Rest...> rest;
 };
 
-template <class... S> struct SumRH { static constexpr int value = 0; };
-template <class S, class... Rest> struct SumRH<S, Rest...> { static constexpr int value = S::RH + SumRH<Rest...>::value; };
+// which slot of a pair pipeline a stage works on: 0 / 1 for the stages of a branch, -1 for everything else (a plain chain, the
+// stages before the fork and after the join -- slot 0 --, the fork and the join themselves)
+template <class S> struct BranchOf { static constexpr int value = -1; };
+template <int K, class S> struct BranchOf<StOn<K, S>> { static constexpr int value = K; };
+template <int K, int D> struct BranchOf<StDelay<K, D>> { static constexpr int value = K; };
+// rows a stage needs above / below the row it emits
+template <class S> struct RowsAbove { static constexpr int value = S::RV; };
+template <class S> struct RowsBelow { static constexpr int value = S::RV; };
+template <int K, int D> struct RowsBelow<StDelay<K, D>> { static constexpr int value = D; };
+// reach of a stage list: the stages outside the branches add up, of the two branches the larger counts
+template <int B, class... S> struct BranchRH { static constexpr int value = 0; };
+template <int B, class S, class... Rest> struct BranchRH<B, S, Rest...> { static constexpr int value = (BranchOf<S>::value == B ? S::RH : 0) + BranchRH<B, Rest...>::value; };
+template <int B, class... S> struct BranchRV { static constexpr int value = 0; };
+template <int B, class S, class... Rest> struct BranchRV<B, S, Rest...> { static constexpr int value = (BranchOf<S>::value == B ? S::RV : 0) + BranchRV<B, Rest...>::value; };
+template <class... S> struct SumRH {
+    static constexpr int value = BranchRH<-1, S...>::value + (BranchRH<0, S...>::value > BranchRH<1, S...>::value ? BranchRH<0, S...>::value : BranchRH<1, S...>::value);
+};
 template <class... S> struct SumLDS { static constexpr int value = 0; };
 template <class S, class... Rest> struct SumLDS<S, Rest...> { static constexpr int value = S::LDS_ROWS + SumLDS<Rest...>::value; };
-template <class... S> struct SumRV { static constexpr int value = 0; };
-template <class S, class... Rest> struct SumRV<S, Rest...> { static constexpr int value = S::RV + SumRV<Rest...>::value; };
+template <class... S> struct SumRV {
+    static constexpr int value = BranchRV<-1, S...>::value + (BranchRV<0, S...>::value > BranchRV<1, S...>::value ? BranchRV<0, S...>::value : BranchRV<1, S...>::value);
+};
 template <class... S> struct MaxRV { static constexpr int value = 0; };
 template <class S, class... Rest> struct MaxRV<S, Rest...> { static constexpr int value = S::RV > MaxRV<Rest...>::value ? S::RV : MaxRV<Rest...>::value; };
 template <class S, class...> struct FirstOf { typedef S type; };
 
 // REV: the wave walks its chunk bottom-up (rows are addressed with a negated pitch, so the
 // schedule below is unchanged); stages whose tap order depends on the row direction read it.
+//
+// The schedule is PER SLOT (NS = 2 in a fork/join pipeline, where the two branches run side by side on the two halves of the
+// value): which rows a slot's stream carries (Rows), at which iteration its upstream emitted last (Ticks), and whether it
+// carries a row this iteration (bit k of `hb`).  A plain chain has one slot and everything below folds to scalars.
+template <int NS> struct Rows { int a[NS], b[NS]; };      // first / last row of each slot's stream
+template <int NS> struct Ticks { int t[NS]; };
 template <class Px, bool REV, int T, int NS, int LdsIdx, class... S> struct Chain;     // NS: slots of the value between stages (2 in a fork/join pipeline)
 
 // end of the chain: the store
 template <class Px, bool REV, int T, int NS, int LdsIdx> struct Chain<Px, REV, T, NS, LdsIdx> {
-    RF_DEV void plan_backward(int oa, int ob, int, int, int& in_a, int& in_b) { in_a = oa; in_b = ob; }
-    RF_DEV int plan_forward(int tprev) { return tprev; }
-    template <int MODE> RF_DEV void step(bool has, const Tex<T * NS>& v, int it, const Lane<T>&, Sink<T>& k, const ParamPack<>&)
+    RF_DEV void plan_backward(int oa, int ob, int, int, Rows<NS>& in)
+    {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { in.a[k] = oa; in.b[k] = ob; }
+    }
+    RF_DEV int plan_forward(const Ticks<NS>& tp) { return tp.t[0]; }
+    template <int MODE> RF_DEV void step(unsigned hb, const Tex<T * NS>& v, int it, const Lane<T>&, Sink<T>& k, const ParamPack<>&)
     {
         constexpr bool STEADY = MODE != 0;
-        if (STEADY || has) {
+        if (STEADY || (hb & 1u)) {
             // the row's values are computed HERE, under the full exec mask: left to itself hipcc sinks the
             // last stage's arithmetic into the exec-masked store block and schedules it there as one
             // serial chain per half texel with an s_nop between dependent packed fmas
@@ -678,34 +708,67 @@ template <class Px, bool REV, int T, int NS, int LdsIdx> struct Chain<Px, REV, T
 };
 
 template <class Px, bool REV, int T, int NS, int LdsIdx, class S, class... Rest> struct Chain<Px, REV, T, NS, LdsIdx, S, Rest...> {
-    static_assert(NS == 1 || SlotsOf<S>::value == 2, "every stage of a fork/join pipeline works on the pair (StSolo / StDup / StOn / StMix)");
+    static_assert(NS == 1 || SlotsOf<S>::value == 2, "every stage of a fork/join pipeline works on the pair (StSolo / StDup / StOn / StDelay / StMix)");
     typedef Tex<T * NS> V;
+    static constexpr int K = BranchOf<S>::value > 0 ? BranchOf<S>::value : 0;      // the slot whose schedule this stage follows
+    static constexpr bool kBranch = NS == 2 && BranchOf<S>::value >= 0;             // a stage of a branch: the other slot passes through
+    static constexpr bool kFork = std::is_same<S, StDup>::value, kJoin = std::is_same<S, StMix>::value;
+    static constexpr int RT = RowsAbove<S>::value, RB = RowsBelow<S>::value;
     typename S::template State<Px, T> st;
     // wave-uniform schedule
     int a;        // first input row
     int oa;       // first output row
     int flush;    // replications of the last input row (frame bottom edge)
-    int tprev;    // iteration of the upstream stage's last emission
+    int tprev;    // iteration of the upstream stage's last emission (into this stage's slot)
     int cnt;      // input rows consumed
+    int sa[NS], sb[NS], bb;      // the fork only: the rows each slot's stream starts and ends with, the fork's own last row
     Chain<Px, REV, T, NS, LdsIdx + S::LDS_ROWS, Rest...> next;
 
     // given the rows the LAST stage must emit, derive what each stage must emit/consume
-    RF_DEV void plan_backward(int oa_last, int ob_last, int lo, int hi, int& in_a, int& in_b)
+    RF_DEV void plan_backward(int oa_last, int ob_last, int lo, int hi, Rows<NS>& in)
     {
-        int need_a, need_b;
-        next.plan_backward(oa_last, ob_last, lo, hi, need_a, need_b);
-        oa = need_a;
-        a = max(lo, need_a - S::RV);
-        int b = min(hi, need_b + S::RV);
-        flush = need_b + S::RV - b;
+        Rows<NS> need;
+        next.plan_backward(oa_last, ob_last, lo, hi, need);
+        in = need;
+        if constexpr (kFork) {
+            // one stream in, two out: it must carry every row either slot wants; each slot is handed its own rows only
+#pragma unroll
+            for (int k = 0; k < NS; ++k) { sa[k] = need.a[k]; sb[k] = need.b[k]; }
+            a = oa = min(need.a[0], need.a[NS - 1]);
+            bb = max(need.b[0], need.b[NS - 1]);
+            flush = 0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) { in.a[k] = a; in.b[k] = bb; }
+        } else if constexpr (kJoin) {
+            a = oa = need.a[0];
+            flush = 0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) { in.a[k] = need.a[0]; in.b[k] = need.b[0]; }
+        } else {
+            oa = need.a[K];
+            a = max(lo, need.a[K] - RT);
+            const int b = min(hi, need.b[K] + RB);
+            flush = need.b[K] + RB - b;
+            in.a[K] = a;
+            in.b[K] = b;
+        }
         cnt = 0;
-        in_a = a;
-        in_b = b;
     }
-    RF_DEV int plan_forward(int tp)
+    RF_DEV int plan_forward(Ticks<NS> tp)
     {
-        tprev = tp;
-        return next.plan_forward(tp + flush);
+        tprev = tp.t[K];
+        if constexpr (kFork) {
+            // row r of the fork's stream arrives (bb - r) iterations before its last one
+            const int last = tp.t[0];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) tp.t[k] = last - (bb - sb[k]);
+        } else if constexpr (kJoin) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) tp.t[k] = tp.t[0];
+        } else {
+            tp.t[K] += flush;
+        }
+        return next.plan_forward(tp);
     }
     RF_DEV f4* lds_of(const Lane<T>& L) const { return L.lds + LdsIdx * 64 * T; }
     // the source feeds slot 0 (the first stage of a pair pipeline is an StSolo or the StDup itself)
@@ -716,33 +779,59 @@ template <class Px, bool REV, int T, int NS, int LdsIdx, class S, class... Rest>
         for (int j = 0; j < T; ++j) o.v[j] = a.v[j];
         return o;
     }
+    // which slots carry a row after this stage: the fork hands row r (the one it has just consumed) to the slots that want it,
+    // the join emits when it ran, every other stage answers for its own slot and leaves the other bit alone
+    RF_DEV unsigned bits_after(unsigned hb, bool ran, bool has) const
+    {
+        if constexpr (kFork) {
+            if (!ran) return 0u;
+            const int r = a + cnt - 1;
+            unsigned ob = 0u;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) ob |= (r >= sa[k] && r <= sb[k]) ? (1u << k) : 0u;
+            return ob;
+        } else if constexpr (kJoin) {
+            return has ? 1u : 0u;
+        } else {
+            return (hb & ~(1u << K)) | (has ? (1u << K) : 0u);
+        }
+    }
+    // the slot a branch stage does not work on passes through, whether or not the stage had a row of its own this iteration
+    RF_DEV static void pass_other(const V& v, V& out)
+    {
+        if constexpr (kBranch) put_slot<T>(out, 1 - K, take_slot<T>(v, 1 - K));
+    }
     // A row (or a flush tick) enters this stage.  STEADY = every stage receives a real row,
     // is past its first row and emits: the schedule tests fold away at compile time.
-    template <int MODE> RF_DEV void step(bool has_prev, const V& v, int it, const Lane<T>& L, Sink<T>& k, const ParamPack<S, Rest...>& P)
+    template <int MODE> RF_DEV void step(unsigned hb, const V& v, int it, const Lane<T>& L, Sink<T>& k, const ParamPack<S, Rest...>& P)
     {
         constexpr bool STEADY = MODE != 0;
         constexpr bool KEEP = MODE == 0 || MODE == 3;   // phases that may hold a stage's last real row
-        bool has = false;
+        // this stage's own input: its slot's bit (the join: both slots, which arrive together by construction)
+        const bool has_prev = kJoin ? ((hb & ((1u << NS) - 1u)) == ((1u << NS) - 1u)) : (((hb >> K) & 1u) != 0u);
+        bool has = false, ran = false;
         V out = tex_zero<T * NS>();
         if constexpr (STEADY) {
             S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), v, true, false, true, out);
             cnt += 1;
-            has = true;
-        } else if constexpr (S::RV == 0) {
+            has = ran = true;
+        } else if constexpr (RT == 0 && RB == 0) {
             if (has_prev) {              // row-local stage: one row in, one row out, never flushed
                 S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), v, true, cnt == 0, true, out);
                 cnt += 1;
-                has = true;
+                has = ran = true;
             }
         } else {
             const bool flushing = !has_prev && it > tprev && it <= tprev + flush;
             if (has_prev || flushing) {
-                has = (a + cnt - S::RV) >= oa;
+                has = (a + cnt - RB) >= oa;
                 S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), v, has_prev, cnt == 0, has, out);
                 cnt += 1;
+                ran = true;
             }
         }
-        next.template step<MODE>(has, out, it, L, k, P.rest);
+        pass_other(v, out);
+        next.template step<MODE>(STEADY ? hb : bits_after(hb, ran, has), out, it, L, k, P.rest);
     }
     // first stage: the row comes from the source feed; once it is consumed its ring slot is
     // refilled and the NEXT row's values are fetched into registers
@@ -755,7 +844,8 @@ template <class Px, bool REV, int T, int NS, int LdsIdx, class S, class... Rest>
     {
         constexpr bool STEADY = MODE != 0;
         constexpr bool KEEP = MODE == 0 || MODE == 3;
-        bool has = false;
+        static_assert(!kBranch && !kJoin, "a pipeline starts with a stage of slot 0 or with the fork");
+        bool has = false, ran = false;
         V out = tex_zero<T * NS>();
         if constexpr (STEADY) {
             if constexpr (std::is_same<Feed, OwnFeed<Px, T>>::value)
@@ -763,7 +853,7 @@ template <class Px, bool REV, int T, int NS, int LdsIdx, class S, class... Rest>
             else
                 out = S::template from_taps<T>(P.p, feed);
             cnt += 1;
-            has = true;
+            has = ran = true;
             if constexpr (MODE == 3) {
                 if (it + 1 < src.n0) {
                     wait_vmcnt<0>();
@@ -776,21 +866,22 @@ template <class Px, bool REV, int T, int NS, int LdsIdx, class S, class... Rest>
                 feed.fetch(src, it + 1, L);
             }
         } else {
-            if constexpr (S::RV == 0) {
+            if constexpr (RT == 0 && RB == 0) {
                 if (has0) {
                     if constexpr (std::is_same<Feed, OwnFeed<Px, T>>::value)
                         S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), widen(feed.own()), true, cnt == 0, true, out);
                     else
                         out = S::template from_taps<T>(P.p, feed);
                     cnt += 1;
-                    has = true;
+                    has = ran = true;
                 }
             } else {
                 const bool flushing = !has0 && it > tprev && it <= tprev + flush;
                 if (has0 || flushing) {
-                    has = (a + cnt - S::RV) >= oa;
+                    has = (a + cnt - RB) >= oa;
                     S::template advance<Px, REV, T, KEEP>(P.p, st, L, lds_of(L), widen(feed.own()), has0, cnt == 0, has, out);
                     cnt += 1;
+                    ran = true;
                 }
             }
             if (has0) {
@@ -801,7 +892,7 @@ template <class Px, bool REV, int T, int NS, int LdsIdx, class S, class... Rest>
                 }
             }
         }
-        next.template step<MODE>(has, out, it, L, k, P.rest);
+        next.template step<MODE>(STEADY ? ~0u : bits_after(has0 ? 1u : 0u, ran, has), out, it, L, k, P.rest);
     }
 };
 
@@ -856,10 +947,15 @@ RF_DEV void stream_wave(const StreamArgs<S...>& A, const Lane<T>& L, int wave, c
 
     Chain<Px, REV, T, MaxSlots<S...>::value, 0, S...> chain;
     Src src;
-    int b0;
-    chain.plan_backward(v0, v1 - 1, lo, hi, src.a0, b0);
-    src.n0 = b0 - src.a0 + 1;                        // source rows
-    const int total = chain.plan_forward(src.n0 - 1) + 1;
+    constexpr int kSlots = MaxSlots<S...>::value;
+    Rows<kSlots> in;
+    chain.plan_backward(v0, v1 - 1, lo, hi, in);
+    src.a0 = in.a[0];
+    src.n0 = in.b[0] - in.a[0] + 1;                  // source rows
+    Ticks<kSlots> last;
+#pragma unroll
+    for (int q = 0; q < kSlots; ++q) last.t[q] = src.n0 - 1;
+    const int total = chain.plan_forward(last) + 1;
 
     // source: rows a0..b0, column clamp(x)
     src.src = A.src;

@@ -227,7 +227,7 @@ def test_fusion_groups():
     # a fork/join whose branches descend from one image is ONE launch: both branches ride the stage chain as a pair of rows
     d = rf.Plan(rf.Config(util.DIAMOND), 0)
     assert d.launches() == ["blur+sharp+mixer"] and d.needs_jit() == [False]        # (this very diamond is in the catalogue)
-    assert d.launch_info()[0]["inputs"] == ["rf:file-input"] and d.launch_info()[0]["radius"] == 3
+    assert d.launch_info()[0]["inputs"] == ["rf:file-input"] and d.launch_info()[0]["radius"] == 2        # pre + max(2, 1) + post: the branches run side by side
     assert d.images() == ["rf:file-input", "rf:final-output"]                       # neither branch result is materialised
     assert rf.Plan(rf.Config(util.DIAMOND), NF).launches() == ["blur", "sharp", "mixer"]
     # a branch image that somebody else reads keeps the fork/join unfused
