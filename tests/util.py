@@ -141,7 +141,7 @@ def random_graph(rng):
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHADERS = os.path.join(ROOT, "shaders")
-USER_TYPES = ("invert", "edge_detect", "unsharp_mask", "tone_curve", "apply_curve", "local_contrast")
+USER_TYPES = ("invert", "edge_detect", "unsharp_mask", "tone_curve", "apply_curve", "local_contrast", "streak")
 
 
 def register_user_types():
@@ -186,13 +186,13 @@ def random_dag(rng, split=False, user=False):
                 outputs.append(sname + ":chroma_image")
             continue
         if user and rng.rand() < 0.3:
-            kind = ["invert", "edge_detect", "unsharp_mask", "curve", "local_contrast"][rng.randint(5)]
+            kind = ["invert", "edge_detect", "unsharp_mask", "curve", "local_contrast", "streak"][rng.randint(6)]
             if kind == "invert":
                 decl.append("%s: invert { enabled: %s, strength: %.2f }" % (name, "true" if rng.rand() < 0.8 else "false", rng.uniform(0.0, 1.0)))
             elif kind == "edge_detect":
                 decl.append("%s: edge_detect { scale: %.2f }" % (name, rng.uniform(0.2, 3.0)))
-            elif kind == "local_contrast":          # RADIUS 2: a node of its own that reads its input through a window
-                decl.append("%s: local_contrast { amount: %.2f }" % (name, rng.uniform(0.0, 1.5)))
+            elif kind in ("local_contrast", "streak"):          # RADIUS 2 / 7: a node of its own that reads its input through a window (LDS tiles)
+                decl.append("%s: %s { amount: %.2f }" % (name, kind, rng.uniform(0.0, 1.5)))
             elif kind == "unsharp_mask" and len(outputs) >= 2:
                 a, b = [outputs[k] for k in rng.choice(len(outputs), 2, replace=False)]
                 decl.append("%s: unsharp_mask { amount: %.2f, threshold: %.3f }" % (name, rng.uniform(0.0, 2.0), rng.uniform(0.0, 0.1)))
