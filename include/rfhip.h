@@ -214,9 +214,31 @@ uint64_t    rf_plan_signature(const rf_plan* plan);
  * [host] process-wide, like Render's shader path (render.rs:537-588). */
 rf_status   rf_set_shader_path(const char* dir);
 const char* rf_shader_path(void);
-/* [host] modification time (ns) of {shader_path}/{type}.stage.hip as last loaded, -1 if there is no such file: what a
+/* [host] modification time (ns) of {shader_path}/{type}.stage.hip (or {type}.comp) as last loaded, -1 if there is no such file: what a
  * live-reload loop polls (reload_changed_pipelines, render.rs:225-249) */
 long long   rf_user_stage_mtime(const char* type_name);
+/* Filter types in the reference's OWN file form: {shader_path}/T.comp, a GLSL 450 compute shader -- what a reforge user already
+ * has (src/config/config.rs:59-75; shaders/passthrough.comp is the one the reference ships).  A type that is neither built in nor
+ * a T.stage.hip is looked for as T.comp.  No GLSL compiler is needed: rf_glsl.cpp TRANSLATES the subset a compute filter uses to
+ * HIP device source (vectors with swizzles, matrices, the built-in functions, image2D storage images by variable name, uniform
+ * blocks -- their scalar members are the node's parameters, std140 --, storage blocks by block TYPE name -- std430 --, structs,
+ * #define, shared variables and barrier()), hiprtc compiles it at rf_graph_create, and rfglsl::glsl_node_kernel runs one invocation
+ * per thread over the reference's dispatch, ceil(W/16) x ceil(H/16) workgroups of the file's local_size (src/vulkan/command.rs:167-168).
+ * What shaderc + spirv-reflect give the reference (src/vulkan/shader.rs:73-160) falls out of the same parse.  Any number of images
+ * (<= 32) and storage blocks (<= 32) per node; an image or block without readonly / writeonly is read and written in place
+ * (pipeline_graph.rs:228,:240-247).  `#pragma rf radius N` (a GLSL compiler ignores it) states how many rows above / below its own
+ * an invocation reads: required of a node that is to be split into row strips.  A file outside the subset is refused with
+ * "T.comp:LINE: why", like a file that does not compile (Option::None + warning, shader.rs:92; the caller keeps its graph).
+ * [host] the translation of `text` (HIP device source; its first line is a comment naming the namespace it lives in) */
+rf_status   rf_glsl_translate(const char* type_name, const char* text, char* buf, size_t cap, size_t* len);
+/* [host] the reflection of `text` as JSON: {"local_size": [x, y, z], "grouped", "radius" (-1: not stated), "uniform_bytes",
+ * "images": [{"name", "binding", "readonly", "writeonly"}], "uniform_blocks" / "storage_blocks": [{"type_name", "instance",
+ * "binding", "bytes", "base", "members": [{"name", "base": "f|i|u|b", "comps", "cols", "dims", "offset", "stride", "bytes"}]}]} */
+rf_status   rf_glsl_reflect(const char* type_name, const char* text, char* buf, size_t cap, size_t* len);
+/* [host] which wins when a type name is both built in and a file in {shader_path}: 0 (default) the built-in, hand-written
+ * kernel; 1 the FILE -- the reference's rule, where the file is the type: a reforge user's shader directory then runs as it is */
+rf_status   rf_set_type_lookup(int files_first);
+int         rf_type_lookup(void);
 /* Kernels compiled at graph creation.  A fused launch whose stage list the ahead-of-time kernel catalogue lacks is
  * compiled by rf_graph_create with hiprtc from the library's own device source -- the counterpart of
  * Shader::from_path + Pipeline::new_compute (src/vulkan/shader.rs:29-93, pipeline.rs:73-88), which run at the same

@@ -15,7 +15,8 @@ from ._lib import (RF_FORMAT_RGBA8, RF_FORMAT_RGBA32F, RF_GRAPH_TIMERS, RF_GRAPH
                    RF_EXEC_FORCE_SPLIT, RF_EXEC_NO_ALTERNATE, RF_EXEC_ALTERNATE, RF_CONV_AUTO, RF_CONV_TILE,
                    RF_CONV_MFMA, RF_CONV_VALU, SO_PATH, lib)
 from .host import (RfError, Config, Plan, Context, Graph, Render, RenderInfo, get_dim, comm_selftest,
-                   registry_types, registry_binding, strip_rows, set_shader_path, shader_path, config_syntax, FILE_INPUT, FINAL_OUTPUT)
+                   registry_types, registry_binding, strip_rows, set_shader_path, shader_path, config_syntax, FILE_INPUT, FINAL_OUTPUT,
+                   glsl_translate, glsl_reflect, set_type_lookup)
 
 __all__ = [
     "RF_FORMAT_RGBA8", "RF_FORMAT_RGBA32F", "RF_GRAPH_TIMERS", "RF_GRAPH_NO_FUSION",
@@ -24,4 +25,5 @@ __all__ = [
     "RF_CONV_VALU", "SO_PATH", "lib",
     "RfError", "Config", "Plan", "Context", "Graph", "Render", "RenderInfo", "get_dim",
     "registry_types", "registry_binding", "strip_rows", "set_shader_path", "shader_path", "config_syntax", "FILE_INPUT", "FINAL_OUTPUT",
+    "glsl_translate", "glsl_reflect", "set_type_lookup",
 ]

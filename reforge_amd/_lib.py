@@ -101,6 +101,10 @@ SIGNATURES = {
     "rf_set_shader_path": (_i, [_cp]),
     "rf_shader_path": (_cp, []),
     "rf_user_stage_mtime": (C.c_longlong, [_cp]),
+    "rf_glsl_translate": (_i, [_cp, _cp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rf_glsl_reflect": (_i, [_cp, _cp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "rf_set_type_lookup": (_i, [C.c_int]),
+    "rf_type_lookup": (C.c_int, []),
     "rf_jit_available": (_i, []),
     "rf_jit_compile_count": (_i, []),
     "rf_jit_library": (_cp, []),

@@ -5,6 +5,7 @@
 
 #include "rf_jit.h"
 #include "rf_user.h"
+#include "rf_glsl.h"
 #include "rf_runtime.h"
 
 namespace rf {
@@ -358,6 +359,34 @@ extern "C" long long rf_user_stage_mtime(const char* type_name)
     std::string err;
     const UserStage* u = user_stage_for_type(type_name, err);
     return u ? u->mtime_ns : -1;
+}
+
+extern "C" rf_status rf_set_type_lookup(int files_first_) { set_files_first(files_first_ != 0); return RF_OK; }
+extern "C" int rf_type_lookup(void) { return files_first() ? 1 : 0; }
+
+// ---- {type}.comp: GLSL compute shaders, translated (rf_glsl.cpp) ------------------------------------
+static rf_status glsl_text_out(const char* what, const std::string& text, char* buf, size_t cap, size_t* len)
+{
+    *len = text.size();
+    if (text.size() + 1 > cap) return fail(RF_ERR_INVALID, std::string(what) + ": the buffer is too small");
+    std::memcpy(buf, text.c_str(), text.size() + 1);
+    return RF_OK;
+}
+extern "C" rf_status rf_glsl_translate(const char* type_name, const char* text, char* buf, size_t cap, size_t* len)
+{
+    if (!type_name || !text || !len || (!buf && cap)) return fail(RF_ERR_INVALID, "rf_glsl_translate: null argument");
+    UserStage st;
+    std::string err;
+    if (!parse_glsl_stage(type_name, text, st, err)) return fail(RF_ERR_GRAPH, err);
+    return glsl_text_out("rf_glsl_translate", "// " + st.ident + "\n" + st.glsl_source, buf, cap, len);
+}
+extern "C" rf_status rf_glsl_reflect(const char* type_name, const char* text, char* buf, size_t cap, size_t* len)
+{
+    if (!type_name || !text || !len || (!buf && cap)) return fail(RF_ERR_INVALID, "rf_glsl_reflect: null argument");
+    GlslShader sh;
+    std::string err;
+    if (!glsl_translate(type_name, text, "reflect", sh, err)) return fail(RF_ERR_GRAPH, err);
+    return glsl_text_out("rf_glsl_reflect", glsl_reflection_json(sh), buf, cap, len);
 }
 
 // ---- kernels compiled at graph creation (rf_jit.cpp) --------------------------------------------

@@ -1,0 +1,822 @@
+// rf_glsl.cpp -- see rf_glsl.h.  Host only, no dependency beyond the standard library.
+#include "rf_glsl.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <set>
+
+namespace rf {
+
+namespace {
+
+enum TokKind { T_ID, T_NUM, T_PUNCT, T_PP, T_END };
+struct Tok {
+    TokKind k = T_END;
+    std::string s;       // the text that is emitted (rewritten in place)
+    std::string ws;      // what stood in front of it: white space; comments are reduced to their line breaks
+    int line = 1;
+    bool drop = false;   // emit the white space only
+};
+
+struct Fail {
+    int line;
+    std::string msg;
+};
+
+bool id_start(char c) { return std::isalpha((unsigned char)c) || c == '_'; }
+bool id_char(char c) { return std::isalnum((unsigned char)c) || c == '_'; }
+
+// ---- lexer ------------------------------------------------------------------------------------------------------------------
+std::vector<Tok> lex(const std::string& t)
+{
+    std::vector<Tok> out;
+    size_t i = 0;
+    int line = 1;
+    bool line_start = true;
+    std::string ws;
+    while (i < t.size()) {
+        const char c = t[i];
+        if (c == '\n') { ws += c; ++line; ++i; line_start = true; continue; }
+        if (c == ' ' || c == '\t' || c == '\r' || c == '\f' || c == '\v') { ws += c; ++i; continue; }
+        if (c == '\\' && i + 1 < t.size() && t[i + 1] == '\n') { ws += '\n'; ++line; i += 2; continue; }      // a spliced line outside a directive
+        if (t.compare(i, 2, "//") == 0) { while (i < t.size() && t[i] != '\n') ++i; continue; }
+        if (t.compare(i, 2, "/*") == 0) {
+            size_t e = t.find("*/", i + 2);
+            if (e == std::string::npos) e = t.size() - 2;
+            for (size_t k = i; k < e + 2 && k < t.size(); ++k)
+                if (t[k] == '\n') { ws += '\n'; ++line; }
+            ws += ' ';
+            i = e + 2;
+            continue;
+        }
+        Tok k;
+        k.ws = ws;
+        k.line = line;
+        ws.clear();
+        if (c == '#' && line_start) {
+            // a directive: to the end of the line, spliced lines included; comments inside removed
+            std::string d;
+            while (i < t.size() && t[i] != '\n') {
+                if (t[i] == '\\' && i + 1 < t.size() && t[i + 1] == '\n') { d += ' '; ws += '\n'; ++line; i += 2; continue; }
+                if (t.compare(i, 2, "//") == 0) { while (i < t.size() && t[i] != '\n') ++i; break; }
+                if (t.compare(i, 2, "/*") == 0) {
+                    size_t e = t.find("*/", i + 2);
+                    if (e == std::string::npos) e = t.size() - 2;
+                    for (size_t q = i; q < e + 2 && q < t.size(); ++q)
+                        if (t[q] == '\n') { ws += '\n'; ++line; }
+                    d += ' ';
+                    i = e + 2;
+                    continue;
+                }
+                d += t[i++];
+            }
+            k.k = T_PP;
+            k.s = d;
+            out.push_back(k);
+            continue;      // ws now holds the line breaks the directive swallowed
+        }
+        line_start = false;
+        if (id_start(c)) {
+            size_t e = i;
+            while (e < t.size() && id_char(t[e])) ++e;
+            k.k = T_ID;
+            k.s = t.substr(i, e - i);
+            i = e;
+        } else if (std::isdigit((unsigned char)c) || (c == '.' && i + 1 < t.size() && std::isdigit((unsigned char)t[i + 1]))) {
+            size_t e = i;
+            bool is_float = false, hex = false;
+            if (c == '0' && e + 1 < t.size() && (t[e + 1] == 'x' || t[e + 1] == 'X')) {
+                hex = true;
+                e += 2;
+                while (e < t.size() && std::isxdigit((unsigned char)t[e])) ++e;
+            } else {
+                while (e < t.size() && std::isdigit((unsigned char)t[e])) ++e;
+                if (e < t.size() && t[e] == '.') { is_float = true; ++e; while (e < t.size() && std::isdigit((unsigned char)t[e])) ++e; }
+                if (e < t.size() && (t[e] == 'e' || t[e] == 'E')) {
+                    size_t q = e + 1;
+                    if (q < t.size() && (t[q] == '+' || t[q] == '-')) ++q;
+                    if (q < t.size() && std::isdigit((unsigned char)t[q])) { is_float = true; e = q; while (e < t.size() && std::isdigit((unsigned char)t[e])) ++e; }
+                }
+            }
+            std::string num = t.substr(i, e - i), suffix;
+            while (e < t.size() && id_char(t[e])) suffix += t[e++];
+            i = e;
+            k.k = T_NUM;
+            if (!hex && (is_float || suffix == "f" || suffix == "F" || suffix == "lf" || suffix == "LF")) {
+                // GLSL: a literal with a point or an exponent is a float (C++: a double, and the arithmetic around it with it)
+                if (suffix == "lf" || suffix == "LF") k.s = num + (is_float ? "" : ".0");
+                else k.s = num + (is_float ? "f" : ".0f");
+            } else {
+                k.s = num + suffix;      // integers: 1, 1u, 0x1Fu mean the same in C++
+            }
+        } else {
+            k.k = T_PUNCT;
+            k.s = std::string(1, c);
+            ++i;
+        }
+        out.push_back(k);
+    }
+    Tok e;
+    e.k = T_END;
+    e.ws = ws;
+    e.line = line;
+    out.push_back(e);
+    return out;
+}
+
+bool is(const Tok& t, const char* s) { return (t.k == T_ID || t.k == T_PUNCT) && t.s == s; }
+
+const std::set<std::string>& vector_types()
+{
+    static const std::set<std::string> s = {"vec2", "vec3", "vec4", "ivec2", "ivec3", "ivec4", "uvec2", "uvec3", "uvec4", "bvec2", "bvec3", "bvec4", "mat2", "mat3", "mat4"};
+    return s;
+}
+const std::set<std::string>& scalar_types()
+{
+    static const std::set<std::string> s = {"float", "int", "uint", "bool"};
+    return s;
+}
+const std::set<std::string>& dropped_qualifiers()
+{
+    static const std::set<std::string> s = {"precise", "highp", "mediump", "lowp", "invariant"};
+    return s;
+}
+const std::set<std::string>& unsupported_words()
+{
+    static const std::set<std::string> s = {"double",      "dvec2",       "dvec3",       "dvec4",      "dmat2",       "dmat3",          "dmat4",        "sampler1D",
+                                            "sampler2D",   "sampler3D",   "samplerCube", "texture",    "texelFetch",  "image1D",        "image3D",      "imageCube",
+                                            "image2DArray", "iimage2D",   "uimage2D",    "atomicAdd",  "atomicMin",   "atomicMax",      "atomicExchange", "atomicCompSwap",
+                                            "imageAtomicAdd", "subroutine", "mat2x2",    "mat2x3",     "mat2x4",      "mat3x2",         "mat3x3",       "mat3x4",
+                                            "mat4x2",      "mat4x3",      "mat4x4",      "push_constant"};
+    return s;
+}
+
+struct Ctx {
+    std::string type;
+    std::set<std::string> structs, struct_members, ssbo_scalars, ssbo_instances, macros;
+};
+
+size_t match(const std::vector<Tok>& v, size_t open, size_t end)
+{
+    const std::string o = v[open].s, c = o == "(" ? ")" : (o == "[" ? "]" : "}");
+    int depth = 0;
+    for (size_t i = open; i < end; ++i) {
+        if (v[i].k != T_PUNCT) continue;
+        if (v[i].s == o) ++depth;
+        else if (v[i].s == c && --depth == 0) return i;
+    }
+    throw Fail{v[open].line, "unbalanced `" + o + "`"};
+}
+
+size_t next_live(const std::vector<Tok>& v, size_t i, size_t end)
+{
+    while (i < end && v[i].drop) ++i;
+    return i;
+}
+
+// the rewrites that need no knowledge of where a token stands: [b, e)
+void rewrite(std::vector<Tok>& v, size_t b, size_t e, const Ctx& cx)
+{
+    for (size_t i = b; i < e; ++i) {
+        Tok& t = v[i];
+        if (t.drop || t.k != T_ID) continue;
+        const size_t n = next_live(v, i + 1, e);
+        const bool call = n < e && is(v[n], "(");
+        const bool after_dot = i > b && is(v[i - 1], ".");
+        if (after_dot) {
+            // a swizzle spelled with texture coordinates: clang's vectors know xyzw and rgba
+            bool stpq = !t.s.empty() && t.s.size() <= 4 && !cx.struct_members.count(t.s);
+            for (char c : t.s) stpq = stpq && (c == 's' || c == 't' || c == 'p' || c == 'q');
+            if (stpq)
+                for (char& c : t.s) c = c == 's' ? 'x' : (c == 't' ? 'y' : (c == 'p' ? 'z' : 'w'));
+            continue;
+        }
+        if (unsupported_words().count(t.s)) throw Fail{t.line, "`" + t.s + "` is outside the GLSL subset this library translates (rf_glsl.h)"};
+        if (dropped_qualifiers().count(t.s)) { t.drop = true; continue; }
+        const bool basic = vector_types().count(t.s) || scalar_types().count(t.s);
+        if ((basic || cx.structs.count(t.s)) && n < e && is(v[n], "[")) {
+            // T[](a, b, c) / T[3](a, b, c): an array constructor -> {a, b, c}
+            const size_t rb = match(v, n, e), p = next_live(v, rb + 1, e);
+            if (p < e && is(v[p], "(")) {
+                const size_t q = match(v, p, e);
+                for (size_t k = i; k <= rb; ++k) v[k].drop = true;
+                v[p].s = "{";
+                v[q].s = "}";
+                continue;
+            }
+        }
+        if (call && vector_types().count(t.s)) { t.s = "mk_" + t.s; continue; }
+        if (call && cx.structs.count(t.s)) {      // Light(a, b) -> Light{a, b}
+            const size_t q = match(v, n, e);
+            v[n].s = "{";
+            v[q].s = "}";
+            continue;
+        }
+        if (call && t.s == "not") { t.s = "rfg_not"; continue; }
+        if (cx.ssbo_scalars.count(t.s)) { t.s = "(*rfg_p_" + t.s + ")"; continue; }
+        if (cx.ssbo_instances.count(t.s) && n < e && is(v[n], ".")) { v[n].s = "->"; continue; }
+    }
+}
+
+std::string emit(const std::vector<Tok>& v, size_t b, size_t e)
+{
+    std::string o;
+    for (size_t i = b; i < e; ++i) {
+        o += v[i].ws;
+        if (!v[i].drop) o += v[i].s;
+    }
+    return o;
+}
+
+void blank(std::vector<Tok>& v, size_t b, size_t e)
+{
+    for (size_t i = b; i < e; ++i) v[i].drop = true;
+}
+
+// a directive: what is kept of it, translated ("" = dropped)
+std::string directive(const Tok& t, Ctx& cx, GlslShader& sh)
+{
+    size_t i = 1;
+    const std::string& d = t.s;
+    while (i < d.size() && (d[i] == ' ' || d[i] == '\t')) ++i;
+    size_t e = i;
+    while (e < d.size() && id_char(d[e])) ++e;
+    const std::string name = d.substr(i, e - i), rest = d.substr(e);
+    if (name == "version" || name == "extension" || name == "line") return "";
+    if (name == "pragma") {
+        std::vector<Tok> r = lex(rest);
+        if (r.size() >= 3 && is(r[0], "rf") && is(r[1], "radius")) {
+            if (r[2].k != T_NUM || r.size() != 4) throw Fail{t.line, "#pragma rf radius N: N is an integer 0.." + std::to_string(1 << 12)};
+            sh.radius = std::atoi(r[2].s.c_str());
+            if (sh.radius < 0 || sh.radius > (1 << 12)) throw Fail{t.line, "#pragma rf radius " + r[2].s + " is out of range"};
+        }
+        return "";
+    }
+    if (name == "include") throw Fail{t.line, "#include is not available (the reference compiles the file alone, shader.rs:73-93)"};
+    if (name == "define") {
+        std::vector<Tok> r = lex(rest);
+        if (r.empty() || r[0].k != T_ID) throw Fail{t.line, "#define without a name"};
+        cx.macros.insert(r[0].s);
+        size_t body = 1;
+        if (r.size() > 2 && is(r[1], "(") && r[1].ws.empty()) body = match(r, 1, r.size()) + 1;      // a function-like macro: its parameter list stays
+        rewrite(r, body, r.size() - 1, cx);
+        return "#define" + emit(r, 0, r.size());
+    }
+    return d;      // #undef, #if, #ifdef, #ifndef, #else, #elif, #endif, #error: the C++ preprocessor reads them the same way
+}
+
+struct TypeInfo {
+    char base;
+    int comps, cols;
+};
+bool block_member_type(const std::string& s, TypeInfo& ti)
+{
+    static const std::map<std::string, TypeInfo> m = {
+        {"float", {'f', 1, 1}}, {"int", {'i', 1, 1}},   {"uint", {'u', 1, 1}},  {"bool", {'b', 1, 1}},  {"vec2", {'f', 2, 1}},  {"vec3", {'f', 3, 1}},
+        {"vec4", {'f', 4, 1}},  {"ivec2", {'i', 2, 1}}, {"ivec3", {'i', 3, 1}}, {"ivec4", {'i', 4, 1}}, {"uvec2", {'u', 2, 1}}, {"uvec3", {'u', 3, 1}},
+        {"uvec4", {'u', 4, 1}}, {"mat2", {'f', 2, 2}},  {"mat3", {'f', 3, 3}},  {"mat4", {'f', 4, 4}}};
+    auto it = m.find(s);
+    if (it == m.end()) return false;
+    ti = it->second;
+    return true;
+}
+std::string cpp_type(const GlslMember& m)
+{
+    if (m.cols > 1) return "mat" + std::to_string(m.cols);
+    const std::string p = m.base == 'f' ? "vec" : (m.base == 'i' ? "ivec" : "uvec");
+    if (m.comps > 1) return p + std::to_string(m.comps);
+    return m.base == 'f' ? "float" : (m.base == 'i' ? "int" : (m.base == 'u' ? "uint" : "bool"));
+}
+int cpp_elem_bytes(const GlslMember& m)      // sizeof of one array element as the C++ side lays it out
+{
+    const int v = m.comps == 1 ? (m.base == 'b' ? 1 : 4) : (m.comps == 2 ? 8 : 16);
+    return v * m.cols;
+}
+int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// an integer constant expression of a declaration: literals, the macros and constants seen so far, + - * / ( )
+struct ConstEval {
+    const std::map<std::string, long>& names;
+    const std::vector<Tok>& v;
+    size_t i, e;
+    long primary()
+    {
+        if (i >= e) throw Fail{v[e].line, "an array size is missing"};
+        const Tok& t = v[i];
+        if (is(t, "(")) { ++i; const long r = sum(); if (i >= e || !is(v[i], ")")) throw Fail{t.line, "unbalanced ( in an array size"}; ++i; return r; }
+        if (is(t, "-")) { ++i; return -primary(); }
+        if (is(t, "+")) { ++i; return primary(); }
+        if (t.k == T_NUM) { ++i; return std::strtol(t.s.c_str(), nullptr, 0); }
+        if (t.k == T_ID) {
+            auto it = names.find(t.s);
+            if (it == names.end()) throw Fail{t.line, "the array size `" + t.s + "` of a block member is not a constant this translator can evaluate (a literal, an object-like #define or a const int of literals)"};
+            ++i;
+            return it->second;
+        }
+        throw Fail{t.line, "cannot evaluate the array size"};
+    }
+    long product()
+    {
+        long r = primary();
+        while (i < e && (is(v[i], "*") || is(v[i], "/") || is(v[i], "%"))) {
+            const char op = v[i].s[0];
+            ++i;
+            const long b = primary();
+            if (op != '*' && b == 0) throw Fail{v[i - 1].line, "division by zero in an array size"};
+            r = op == '*' ? r * b : (op == '/' ? r / b : r % b);
+        }
+        return r;
+    }
+    long sum()
+    {
+        long r = product();
+        while (i < e && (is(v[i], "+") || is(v[i], "-"))) {
+            const char op = v[i].s[0];
+            ++i;
+            const long b = product();
+            r = op == '+' ? r + b : r - b;
+        }
+        return r;
+    }
+};
+
+struct Translator {
+    const std::string& type;
+    GlslShader& sh;
+    Ctx cx;
+    std::vector<Tok> v;
+    std::string hoisted;                       // in front of the struct: directives, constants, shared variables
+    std::string members, bind;                 // generated members of Shader and the body of rfg_bind
+    std::map<std::string, long> int_consts;    // object-like macros and const ints whose value is a literal expression
+    std::set<int> bindings;
+    bool has_main = false;
+
+    Translator(const std::string& ty, GlslShader& s) : type(ty), sh(s) { cx.type = ty; }
+
+    [[noreturn]] void fail(int line, const std::string& m) { throw Fail{line, m}; }
+
+    void claim_binding(int b, int line, const std::string& what)
+    {
+        if (b < 0) fail(line, what + " has no layout(binding = N)");
+        if (!bindings.insert(b).second) fail(line, what + ": binding " + std::to_string(b) + " is used twice (one descriptor set, one resource per binding: shader.rs:122-128)");
+    }
+
+    // layout ( id [= value], ... ) starting at v[i] == "layout": returns the index behind ")"
+    size_t parse_layout(size_t i, std::map<std::string, std::string>& q)
+    {
+        if (!is(v[i + 1], "(")) fail(v[i].line, "layout without (");
+        const size_t e = match(v, i + 1, v.size());
+        for (size_t k = i + 2; k < e;) {
+            if (v[k].k != T_ID) fail(v[k].line, "cannot read the layout qualifier `" + v[k].s + "`");
+            const std::string id = v[k].s;
+            ++k;
+            std::string val;
+            if (k < e && is(v[k], "=")) {
+                ++k;
+                const size_t vb = k;
+                while (k < e && !is(v[k], ",")) ++k;
+                ConstEval ce{int_consts, v, vb, k};
+                val = std::to_string(ce.sum());
+            }
+            q[id] = val;
+            if (k < e && is(v[k], ",")) ++k;
+        }
+        return e + 1;
+    }
+
+    // [dims] at v[i]: returns the index behind them
+    size_t parse_dims(size_t i, std::vector<int>& dims)
+    {
+        while (is(v[i], "[")) {
+            const size_t e = match(v, i, v.size());
+            if (e == i + 1) fail(v[i].line, "unsized arrays are not supported (the reference sizes a buffer from its block's members, pipeline_graph.rs:158-175: an unsized array has none)");
+            ConstEval ce{int_consts, v, i + 1, e};
+            const long n = ce.sum();
+            if (ce.i != e) fail(v[i].line, "cannot evaluate the array size");
+            if (n < 1 || n > (1 << 24)) fail(v[i].line, "array size " + std::to_string(n) + " is out of range");
+            dims.push_back((int)n);
+            i = e + 1;
+        }
+        return i;
+    }
+
+    // Block { members } [instance] ;  with v[i] == the block's type name, v[i + 1] == "{"
+    size_t parse_block(size_t i, bool is_ubo, bool std140, GlslBlock& blk)
+    {
+        blk.type_name = v[i].s;
+        const size_t close = match(v, i + 1, v.size());
+        int cur = 0, max_align = 4;
+        for (size_t k = i + 2; k < close;) {
+            while (k < close && v[k].k == T_ID && (dropped_qualifiers().count(v[k].s) || v[k].s == "readonly" || v[k].s == "writeonly" || v[k].s == "coherent" || v[k].s == "restrict" || v[k].s == "volatile")) ++k;
+            if (k >= close) break;
+            if (is(v[k], "layout")) fail(v[k].line, "layout() on a block member (explicit offsets) is not supported");
+            TypeInfo ti;
+            if (v[k].k != T_ID || !block_member_type(v[k].s, ti)) fail(v[k].line, "block member of type `" + v[k].s + "`: members are float, int, uint, bool, vectors and matrices of them, and arrays (nested structs are not supported)");
+            ++k;
+            for (;;) {
+                if (v[k].k != T_ID) fail(v[k].line, "cannot read the member name `" + v[k].s + "`");
+                GlslMember m;
+                m.name = v[k].s;
+                m.base = ti.base;
+                m.comps = ti.comps;
+                m.cols = ti.cols;
+                cx.struct_members.insert(m.name);
+                k = parse_dims(k + 1, m.dims);
+                // std140 / std430 (OpenGL 4.6 7.6.2.2): a vec3 is aligned like a vec4; an array element (and a matrix column) is
+                // aligned to 16 bytes in std140, to its own alignment in std430
+                const int vec_bytes = m.comps * 4, vec_align = m.comps == 3 ? 16 : vec_bytes;
+                const bool arrayish = !m.dims.empty() || m.cols > 1;
+                const int elem_align = arrayish && std140 ? 16 : vec_align;
+                const int col_stride = arrayish ? round_up(vec_bytes, elem_align) : vec_bytes;
+                long count = m.cols;
+                for (int d : m.dims) count *= d;
+                m.stride = m.cols > 1 ? col_stride * m.cols : col_stride;
+                m.offset = round_up(cur, elem_align);
+                m.bytes = arrayish ? (int)std::min<long>(count * col_stride, 1L << 30) : vec_bytes;
+                if (arrayish && count * col_stride > (1L << 28)) fail(v[k].line, "block member `" + m.name + "` is larger than 256 MiB");
+                cur = m.offset + m.bytes;
+                max_align = std::max(max_align, elem_align);
+                blk.members.push_back(m);
+                if (is(v[k], ",")) { ++k; continue; }
+                if (!is(v[k], ";")) fail(v[k].line, "expected `;` after the member `" + m.name + "`");
+                ++k;
+                break;
+            }
+        }
+        blk.bytes = round_up(cur, std140 ? 16 : max_align);
+        size_t k = close + 1;
+        if (v[k].k == T_ID) { blk.instance = v[k].s; ++k; }
+        if (is(v[k], "[")) fail(v[k].line, "arrays of blocks are not supported");
+        if (!is(v[k], ";")) fail(v[k].line, "expected `;` after the block " + blk.type_name);
+        if (blk.members.empty()) fail(v[i].line, "the block " + blk.type_name + " has no members");
+        (void)is_ubo;
+        return k + 1;
+    }
+
+    std::string dims_text(const std::vector<int>& d, size_t from = 0)
+    {
+        std::string s;
+        for (size_t i = from; i < d.size(); ++i) s += "[" + std::to_string(d[i]) + "]";
+        return s;
+    }
+
+    void add_ubo(GlslBlock blk, int line)
+    {
+        blk.ubo_base = round_up(sh.ubo_bytes, 16);
+        sh.ubo_bytes = blk.ubo_base + blk.bytes;
+        if (sh.ubo_bytes > kGlslMaxUniformBytes) fail(line, "the uniform blocks of this shader take " + std::to_string(sh.ubo_bytes) + " bytes; the limit is " + std::to_string(kGlslMaxUniformBytes));
+        const std::string pre = blk.instance.empty() ? "" : blk.instance + ".";
+        if (!blk.instance.empty()) members += "    struct " + blk.type_name + "_t {\n";
+        for (auto& m : blk.members) {
+            const std::string ty = cpp_type(m);
+            members += std::string(blk.instance.empty() ? "    " : "        ") + ty + " " + m.name + dims_text(m.dims) + ";\n";
+            const int at = blk.ubo_base + m.offset;
+            long count = 1;
+            for (int d : m.dims) count *= d;
+            const std::string lv = pre + m.name;
+            if (m.base == 'b') {
+                if (m.comps != 1) fail(line, "boolean vectors in a uniform block are not supported");
+                bind += "        for (int i = 0; i < " + std::to_string(count) + "; ++i) { unsigned t; __builtin_memcpy(&t, ubo + " + std::to_string(at) + " + i * " + std::to_string(m.stride) +
+                        ", 4); reinterpret_cast<bool*>(&" + lv + ")[i] = t != 0u; }\n";
+            } else if (m.cols > 1) {
+                // a matrix: `cols` columns per element, a column every (stride / cols) bytes
+                bind += "        for (int i = 0; i < " + std::to_string(count * m.cols) + "; ++i) __builtin_memcpy(reinterpret_cast<char*>(&" + lv + ") + i * " + std::to_string(m.comps == 2 ? 8 : 16) + ", ubo + " +
+                        std::to_string(at) + " + i * " + std::to_string(m.stride / m.cols) + ", " + std::to_string(m.comps * 4) + ");\n";
+            } else {
+                bind += "        for (int i = 0; i < " + std::to_string(count) + "; ++i) __builtin_memcpy(reinterpret_cast<char*>(&" + lv + ") + i * " + std::to_string(cpp_elem_bytes(m)) + ", ubo + " + std::to_string(at) +
+                        " + i * " + std::to_string(m.dims.empty() ? 0 : m.stride) + ", " + std::to_string(m.comps * 4) + ");\n";
+            }
+            m.name = pre + m.name;      // the key the reference's UBO map carries (pipeline_graph.rs:276-292)
+        }
+        if (!blk.instance.empty()) members += "    } " + blk.instance + ";\n";
+        sh.ubos.push_back(blk);
+    }
+
+    void add_ssbo(GlslBlock blk, bool std140, int line)
+    {
+        if ((int)sh.ssbos.size() >= kGlslMaxBuffers) fail(line, "more than " + std::to_string(kGlslMaxBuffers) + " storage buffers");
+        const std::string slot = std::to_string(sh.ssbos.size());
+        if (!blk.instance.empty()) {
+            members += "    struct " + blk.type_name + "_t {\n";
+            for (const auto& m : blk.members) members += "        " + cpp_type(m) + " " + m.name + dims_text(m.dims) + ";\n";
+            members += "    };\n    " + blk.type_name + "_t* " + blk.instance + ";\n";
+            for (const auto& m : blk.members)
+                members += "    static_assert(__builtin_offsetof(" + blk.type_name + "_t, " + m.name + ") == " + std::to_string(m.offset) + ", \"" + type + ".comp: the member " + m.name + " of the storage block " +
+                           blk.type_name + " does not lie where " + (std140 ? "std140" : "std430") + " puts it (a scalar behind a vec3?): not supported\");\n";
+            bind += "        " + blk.instance + " = static_cast<" + blk.type_name + "_t*>(buf[" + slot + "]);\n";
+            cx.ssbo_instances.insert(blk.instance);
+        }
+        for (const auto& m : blk.members) {
+            const bool arrayish = !m.dims.empty();
+            if (m.base == 'b') fail(line, "bool members of a storage block are not supported");
+            if ((arrayish || m.cols > 1) && m.stride != cpp_elem_bytes(m))
+                fail(line, "the member " + m.name + " of the storage block " + blk.type_name + " has a " + std::to_string(m.stride) + "-byte array stride (std140); declare the block std430");
+            if (!blk.instance.empty()) continue;
+            const std::string ty = cpp_type(m), at = "static_cast<char*>(buf[" + slot + "]) + " + std::to_string(m.offset);
+            if (!arrayish) {
+                members += "    " + ty + "* rfg_p_" + m.name + ";\n";
+                bind += "        rfg_p_" + m.name + " = reinterpret_cast<" + ty + "*>(" + at + ");\n";
+                cx.ssbo_scalars.insert(m.name);
+            } else if (m.dims.size() == 1) {
+                members += "    " + ty + "* " + m.name + ";\n";
+                bind += "        " + m.name + " = reinterpret_cast<" + ty + "*>(" + at + ");\n";
+            } else {
+                members += "    " + ty + " (*" + m.name + ")" + dims_text(m.dims, 1) + ";\n";
+                bind += "        " + m.name + " = reinterpret_cast<" + ty + " (*)" + dims_text(m.dims, 1) + ">(" + at + ");\n";
+            }
+        }
+        sh.ssbos.push_back(blk);
+    }
+
+    // a function definition whose name is v[name]; v[name + 1] == "(".  `first` = first token of the statement.
+    size_t function(size_t first, size_t name)
+    {
+        const size_t close = match(v, name + 1, v.size());
+        // parameters
+        size_t pb = name + 2;
+        while (pb < close) {
+            size_t pe = pb;
+            int depth = 0;
+            while (pe < close && !(depth == 0 && is(v[pe], ","))) {
+                if (is(v[pe], "(") || is(v[pe], "[")) ++depth;
+                if (is(v[pe], ")") || is(v[pe], "]")) --depth;
+                ++pe;
+            }
+            bool by_ref = false;
+            size_t pname = pe;
+            int d2 = 0;
+            for (size_t k = pb; k < pe; ++k) {
+                if (is(v[k], "[")) ++d2;
+                if (is(v[k], "]")) --d2;
+                if (d2 == 0 && v[k].k == T_ID) {
+                    if (v[k].s == "out" || v[k].s == "inout") { by_ref = true; v[k].drop = true; }
+                    else if (v[k].s == "in") v[k].drop = true;
+                    else if (v[k].s != "const" && !dropped_qualifiers().count(v[k].s)) pname = k;      // the last identifier outside brackets: the name
+                }
+            }
+            if (by_ref) {
+                if (pname >= pe) fail(v[pb].line, "an out parameter without a name");
+                const bool arr = pname + 1 < pe && is(v[pname + 1], "[");
+                v[pname].s = arr ? "(&" + v[pname].s + ")" : "&" + v[pname].s;
+            }
+            pb = pe + 1;
+        }
+        rewrite(v, first, close + 1, cx);
+        size_t after = close + 1;
+        if (is(v[after], ";")) {      // a prototype: member functions need none (and must not be declared twice)
+            blank(v, first, after + 1);
+            return after + 1;
+        }
+        if (!is(v[after], "{")) fail(v[after].line, "expected the body of " + v[name].s);
+        const size_t end = match(v, after, v.size());
+        rewrite(v, after, end + 1, cx);
+        size_t f = first;
+        while (v[f].drop) ++f;
+        v[f].s = "RFG " + v[f].s;
+        if (v[name].s == "main") has_main = true;
+        return end + 1;
+    }
+
+    void run()
+    {
+        v = lex(sh.source);
+        sh.source.clear();
+        for (const auto& t : v)
+            if (t.k == T_ID && (t.s == "gl_LocalInvocationID" || t.s == "gl_LocalInvocationIndex" || t.s == "gl_WorkGroupID" || t.s == "gl_NumWorkGroups" || t.s == "shared" || t.s == "barrier" ||
+                                t.s == "memoryBarrierShared" || t.s == "groupMemoryBarrier"))
+                sh.grouped = true;
+        bool local_size = false;
+        size_t i = 0;
+        while (v[i].k != T_END) {
+            Tok& t = v[i];
+            if (t.k == T_PP) {
+                const std::string d = directive(t, cx, sh);
+                // an object-like macro whose body is an integer expression can size arrays of blocks
+                if (d.compare(0, 7, "#define") == 0) {
+                    std::vector<Tok> r = lex(d.substr(7));
+                    if (r.size() >= 3 && r[0].k == T_ID && !(is(r[1], "(") && r[1].ws.empty())) {
+                        try {
+                            ConstEval ce{int_consts, r, 1, r.size() - 1};
+                            const long val = ce.sum();
+                            if (ce.i == r.size() - 1) int_consts[r[0].s] = val;
+                        } catch (const Fail&) {
+                        }
+                    }
+                }
+                t.s = d;
+                if (d.empty()) t.drop = true;
+                else hoisted += d + "\n";
+                ++i;
+                continue;
+            }
+            if (is(t, ";")) { ++i; continue; }
+            const size_t first = i;
+            std::map<std::string, std::string> lq;
+            bool has_layout = false;
+            if (is(v[i], "layout")) { i = parse_layout(i, lq); has_layout = true; }
+            bool q_uniform = false, q_buffer = false, q_ro = false, q_wo = false, q_shared = false, q_const = false, q_in = false;
+            for (;; ++i) {
+                if (v[i].k != T_ID) break;
+                const std::string& s = v[i].s;
+                if (s == "uniform") q_uniform = true;
+                else if (s == "buffer") q_buffer = true;
+                else if (s == "readonly") q_ro = true;
+                else if (s == "writeonly") q_wo = true;
+                else if (s == "shared") q_shared = true;
+                else if (s == "const") q_const = true;
+                else if (s == "in") q_in = true;
+                else if (s == "coherent" || s == "volatile" || s == "restrict" || dropped_qualifiers().count(s)) {}
+                else break;
+            }
+            if (q_in && has_layout) {      // layout(local_size_x = ...) in;
+                if (!is(v[i], ";")) fail(v[i].line, "expected `;` after `in`");
+                for (const auto& kv : lq) {
+                    int* dst = kv.first == "local_size_x" ? &sh.lx : (kv.first == "local_size_y" ? &sh.ly : (kv.first == "local_size_z" ? &sh.lz : nullptr));
+                    if (!dst) fail(v[first].line, "layout(" + kv.first + ") in: only local_size_x / _y / _z are read");
+                    *dst = std::atoi(kv.second.c_str());
+                }
+                local_size = true;
+                blank(v, first, i + 1);
+                ++i;
+                continue;
+            }
+            if (v[i].k == T_ID && v[i].s == "precision") {
+                while (!is(v[i], ";")) { if (v[i].k == T_END) fail(v[first].line, "precision statement without `;`"); ++i; }
+                blank(v, first, i + 1);
+                ++i;
+                continue;
+            }
+            if (q_uniform || q_buffer) {
+                if (lq.count("set") && lq["set"] != "0") fail(v[first].line, "descriptor set " + lq["set"] + ": only set 0 is supported (shader.rs:125-127)");
+                const int binding = lq.count("binding") ? std::atoi(lq["binding"].c_str()) : -1;
+                if (v[i].k != T_ID) fail(v[i].line, "cannot read this declaration");
+                if (q_uniform && v[i].s == "image2D") {
+                    size_t k = i + 1;
+                    if (v[k].k != T_ID) fail(v[k].line, "an image variable needs a name");
+                    GlslImageVar im;
+                    im.name = v[k].s;
+                    im.binding = binding;
+                    im.readonly = q_ro;
+                    im.writeonly = q_wo;
+                    if (!is(v[k + 1], ";")) fail(v[k + 1].line, is(v[k + 1], "[") ? "arrays of images are not supported" : "expected `;` after the image variable " + im.name);
+                    claim_binding(binding, v[first].line, "image2D " + im.name);
+                    if ((int)sh.images.size() >= kGlslMaxImages) fail(v[first].line, "more than " + std::to_string(kGlslMaxImages) + " image variables");
+                    for (const auto& o : sh.images)
+                        if (o.name == im.name) fail(v[k].line, "the image variable " + im.name + " is declared twice");
+                    members += "    image2D<Px> " + im.name + ";\n";
+                    bind += "        " + im.name + " = image2D<Px>{img[" + std::to_string(sh.images.size()) + "].base, img[" + std::to_string(sh.images.size()) + "].pitch, f.W, f.H, f.row_lo, f.row_hi, f.y0, f.y1 - 1};\n";
+                    sh.images.push_back(im);
+                    blank(v, first, k + 2);
+                    i = k + 2;
+                    continue;
+                }
+                if (!is(v[i + 1], "{")) fail(v[i].line, "`" + v[i].s + "`: a uniform is a storage image (image2D) or a block; a buffer is a block");
+                GlslBlock blk;
+                blk.binding = binding;
+                blk.readonly = q_ro;
+                blk.writeonly = q_wo;
+                const bool std140 = q_uniform ? true : lq.count("std140") > 0;
+                if (q_uniform && lq.count("std430")) fail(v[first].line, "a uniform block cannot be std430");
+                const size_t end = parse_block(i, q_uniform, std140, blk);
+                claim_binding(binding, v[first].line, "block " + blk.type_name);
+                if (q_uniform) add_ubo(blk, v[first].line);
+                else {
+                    for (const auto& o : sh.ssbos)
+                        if (o.type_name == blk.type_name) fail(v[first].line, "the storage block " + blk.type_name + " is declared twice (buffers are found by their block's type name, shader.rs:144-147)");
+                    add_ssbo(blk, std140, v[first].line);
+                }
+                blank(v, first, end);
+                i = end;
+                continue;
+            }
+            if (has_layout && !lq.count("constant_id")) fail(v[first].line, "this layout() declaration is not supported");
+            if (has_layout) blank(v, first, i), rewrite(v, first, first, cx);      // layout(constant_id = N) const T x = default; -> the default
+            if (v[i].k == T_ID && v[i].s == "struct") {
+                if (v[i + 1].k != T_ID || !is(v[i + 2], "{")) fail(v[i].line, "cannot read this struct");
+                cx.structs.insert(v[i + 1].s);
+                const size_t close = match(v, i + 2, v.size());
+                for (size_t k = i + 3; k < close; ++k)
+                    if (v[k].k == T_ID && (is(v[k + 1], ";") || is(v[k + 1], ",") || is(v[k + 1], "["))) cx.struct_members.insert(v[k].s);
+                size_t e = close + 1;
+                while (!is(v[e], ";")) { if (v[e].k == T_END) fail(v[i].line, "struct without `;`"); ++e; }
+                rewrite(v, i, e + 1, cx);
+                i = e + 1;
+                continue;
+            }
+            // [const] type name ...
+            if (v[i].k != T_ID) fail(v[i].line, "cannot read this declaration (at `" + v[i].s + "`)");
+            const size_t ty = i;
+            size_t k = i + 1;
+            if (is(v[k], "[")) k = match(v, k, v.size()) + 1;      // float[3] name
+            if (v[k].k != T_ID) fail(v[k].line, "cannot read this declaration (at `" + v[k].s + "`)");
+            if (is(v[k + 1], "(")) { i = function(first, k); continue; }
+            // a global variable: to its `;`
+            size_t e = k;
+            int depth = 0;
+            while (!(depth == 0 && is(v[e], ";"))) {
+                if (v[e].k == T_END) fail(v[first].line, "declaration without `;`");
+                if (is(v[e], "(") || is(v[e], "[") || is(v[e], "{")) ++depth;
+                if (is(v[e], ")") || is(v[e], "]") || is(v[e], "}")) --depth;
+                ++e;
+            }
+            rewrite(v, first, e + 1, cx);
+            if (q_shared) {
+                // LDS of the workgroup: a variable in front of the struct (a class cannot hold one)
+                std::string text;
+                for (size_t q = first; q <= e; ++q)
+                    if (!v[q].drop && !(v[q].k == T_ID && v[q].s == "shared")) text += (text.empty() ? "" : " ") + v[q].s;
+                hoisted += "__shared__ " + text + "\n";
+                blank(v, first, e + 1);
+            } else if (q_const && scalar_types().count(v[ty].s) && is(v[k + 1], "=")) {
+                bool calls = false;
+                for (size_t q = k + 2; q < e; ++q) calls = calls || (v[q].k == T_ID && is(v[q + 1], "("));
+                if (!calls) {
+                    // a constant of literals: in front of the struct, where array sizes (also of shared variables) can use it
+                    std::string text;
+                    for (size_t q = first; q <= e; ++q)
+                        if (!v[q].drop && !(v[q].k == T_ID && v[q].s == "const")) text += (text.empty() ? "" : " ") + v[q].s;
+                    hoisted += "static constexpr " + text + "\n";
+                    if (v[ty].s == "int" || v[ty].s == "uint") {
+                        try {
+                            ConstEval ce{int_consts, v, k + 2, e};
+                            const long val = ce.sum();
+                            if (ce.i == e) int_consts[v[k].s] = val;
+                        } catch (const Fail&) {
+                        }
+                    }
+                    blank(v, first, e + 1);
+                }
+            }
+            i = e + 1;
+        }
+        if (!has_main) fail(v.back().line, "no `void main()`");
+        if (!local_size) { sh.lx = sh.ly = sh.lz = 1; }
+        if (sh.lx < 1 || sh.ly < 1 || sh.lz < 1 || (long)sh.lx * sh.ly * sh.lz > 1024) fail(1, "local_size " + std::to_string(sh.lx) + " x " + std::to_string(sh.ly) + " x " + std::to_string(sh.lz) + " is out of range (1..1024 invocations)");
+    }
+};
+
+}  // namespace
+
+bool glsl_translate(const std::string& type, const std::string& text, const std::string& ident, GlslShader& out, std::string& err)
+{
+    out = GlslShader();
+    out.source = text;
+    Translator tr(type, out);
+    try {
+        tr.run();
+    } catch (const Fail& f) {
+        err = type + ".comp:" + std::to_string(f.line) + ": " + f.msg;
+        out = GlslShader();
+        return false;
+    }
+    std::string s = "\nnamespace rfglsl { namespace " + ident + " {\n";
+    s += tr.hoisted;
+    s += "template <class Px> struct Shader {\n"
+         "    uvec3 gl_NumWorkGroups, gl_WorkGroupID, gl_LocalInvocationID, gl_GlobalInvocationID;\n"
+         "    uint gl_LocalInvocationIndex;\n"
+         "    const uvec3 gl_WorkGroupSize = uvec3{" + std::to_string(out.lx) + "u, " + std::to_string(out.ly) + "u, " + std::to_string(out.lz) + "u};\n";
+    s += tr.members;
+    s += "    RFG void rfg_bind(const GlslFrame& f, const GlslImage* img, void* const* buf, const unsigned char* ubo)\n    {\n        (void)f; (void)img; (void)buf; (void)ubo;\n" + tr.bind + "    }\n";
+    s += "#line 1 \"" + type + ".comp\"\n";
+    s += emit(tr.v, 0, tr.v.size());
+    s += "\n};\n";
+    for (const auto& m : tr.cx.macros) s += "#undef " + m + "\n";
+    s += "struct Info {\n    static constexpr int LX = " + std::to_string(out.lx) + ", LY = " + std::to_string(out.ly) + ", LZ = " + std::to_string(out.lz) + ", NIMG = " + std::to_string(out.images.size()) +
+         ", NBUF = " + std::to_string(out.ssbos.size()) + ", UBO = " + std::to_string(out.ubo_bytes) + ";\n    static constexpr bool GROUPED = " + (out.grouped ? "true" : "false") + ";\n};\n} }\n";
+    out.source = s;
+    return true;
+}
+
+std::string glsl_reflection_json(const GlslShader& s)
+{
+    auto q = [](const std::string& x) { return "\"" + x + "\""; };
+    std::string j = "{\"local_size\": [" + std::to_string(s.lx) + ", " + std::to_string(s.ly) + ", " + std::to_string(s.lz) + "], \"grouped\": " + (s.grouped ? "true" : "false") +
+                    ", \"radius\": " + std::to_string(s.radius) + ", \"uniform_bytes\": " + std::to_string(s.ubo_bytes) + ", \"images\": [";
+    for (size_t i = 0; i < s.images.size(); ++i)
+        j += std::string(i ? ", " : "") + "{\"name\": " + q(s.images[i].name) + ", \"binding\": " + std::to_string(s.images[i].binding) + ", \"readonly\": " + (s.images[i].readonly ? "true" : "false") +
+             ", \"writeonly\": " + (s.images[i].writeonly ? "true" : "false") + "}";
+    auto blocks = [&](const std::vector<GlslBlock>& bl) {
+        std::string o;
+        for (size_t i = 0; i < bl.size(); ++i) {
+            const GlslBlock& b = bl[i];
+            o += std::string(i ? ", " : "") + "{\"type_name\": " + q(b.type_name) + ", \"instance\": " + q(b.instance) + ", \"binding\": " + std::to_string(b.binding) + ", \"bytes\": " + std::to_string(b.bytes) +
+                 ", \"base\": " + std::to_string(b.ubo_base) + ", \"readonly\": " + (b.readonly ? "true" : "false") + ", \"writeonly\": " + (b.writeonly ? "true" : "false") + ", \"members\": [";
+            for (size_t k = 0; k < b.members.size(); ++k) {
+                const GlslMember& m = b.members[k];
+                std::string dims;
+                for (size_t d = 0; d < m.dims.size(); ++d) dims += std::string(d ? ", " : "") + std::to_string(m.dims[d]);
+                o += std::string(k ? ", " : "") + "{\"name\": " + q(m.name) + ", \"base\": " + q(std::string(1, m.base)) + ", \"comps\": " + std::to_string(m.comps) + ", \"cols\": " + std::to_string(m.cols) +
+                     ", \"dims\": [" + dims + "], \"offset\": " + std::to_string(m.offset) + ", \"stride\": " + std::to_string(m.stride) + ", \"bytes\": " + std::to_string(m.bytes) + "}";
+            }
+            o += "]}";
+        }
+        return o;
+    };
+    j += "], \"uniform_blocks\": [" + blocks(s.ubos) + "], \"storage_blocks\": [" + blocks(s.ssbos) + "]}";
+    return j;
+}
+
+}  // namespace rf

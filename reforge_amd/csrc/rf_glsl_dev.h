@@ -1,0 +1,409 @@
+// rf_glsl_dev.h -- what a translated GLSL compute shader ({shader_path}/{type}.comp, rf_glsl.h) is compiled against: the GLSL
+// types and built-in functions a filter uses, storage images, and the kernel that runs one invocation per thread.
+//
+// In the reference a filter type IS such a file: shaderc compiles it to SPIR-V (src/vulkan/shader.rs:73-93), spirv-reflect
+// finds its bindings (shader.rs:106-160) and vkCmdDispatch runs ceil(W/16) x ceil(H/16) workgroups of it
+// (src/vulkan/command.rs:166-194).  Here the translator (rf_glsl.cpp) rewrites the shader into a C++ struct template --
+// `template <class Px> struct Shader { <globals as members> <functions as member functions> void main(); }` inside
+// namespace rfglsl, so that every GLSL name below is found before anything of the HIP headers -- and hiprtc compiles
+// glsl_node_kernel<Px, Shader> at rf_graph_create (rf_jit.cpp), Px = the graph's texel format (rf_device.h: imageLoad /
+// imageStore convert as DESIGN.md 3 says, whatever format qualifier the file carries -- shaders/passthrough.comp:4-5 says
+// rgba8 and is run on rgba32f images by default, src/main.rs:60).
+//
+// Vectors are clang extended vectors: swizzles (.xyzw / .rgba, also as l-values), component-wise arithmetic and
+// vector-scalar arithmetic come with the type.  Constructors are calls of mk_<type>(...), which the translator writes for
+// every `vecN(...)` (a C++ cast between vectors would reinterpret bits).  -ffp-contract=off: a * b + c stays two
+// roundings, fma() is one -- what `precise` asks for.
+//
+// The first half of this file (up to RFGLSL_KERNEL) has no HIP in it: the oracle compiles it for the host with clang++
+// (oracle/glsl_host.py) to run the same translation on the CPU.
+#pragma once
+
+#if defined(__HIPCC_RTC__) || defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+#define RFG __device__ __forceinline__
+#else
+#include <math.h>
+#include <string.h>
+#define RFG inline
+#endif
+
+namespace rfglsl {
+
+typedef unsigned int uint;
+#define RFG_VEC(T, name)                                    \
+    typedef T name##2 __attribute__((ext_vector_type(2))); \
+    typedef T name##3 __attribute__((ext_vector_type(3))); \
+    typedef T name##4 __attribute__((ext_vector_type(4)));
+RFG_VEC(float, vec)
+RFG_VEC(int, ivec)
+RFG_VEC(unsigned, uvec)
+typedef ivec2 bvec2;      // a boolean vector is an int vector holding 0 / 1
+typedef ivec3 bvec3;
+typedef ivec4 bvec4;
+#undef RFG_VEC
+
+// ---- constructors: the arguments' components in order, converted; one scalar fills every component ------------------------
+template <class T> struct Comps {
+    T v[16];
+    int n = 0;
+    RFG void put(float s) { v[n++] = (T)s; }
+    RFG void put(double s) { v[n++] = (T)s; }
+    RFG void put(int s) { v[n++] = (T)s; }
+    RFG void put(unsigned s) { v[n++] = (T)s; }
+    RFG void put(bool s) { v[n++] = (T)(s ? 1 : 0); }
+#define RFG_PUT(V, N) \
+    RFG void put(V s) { for (int i = 0; i < N; ++i) v[n++] = (T)s[i]; }
+    RFG_PUT(vec2, 2) RFG_PUT(vec3, 3) RFG_PUT(vec4, 4) RFG_PUT(ivec2, 2) RFG_PUT(ivec3, 3) RFG_PUT(ivec4, 4) RFG_PUT(uvec2, 2) RFG_PUT(uvec3, 3) RFG_PUT(uvec4, 4)
+#undef RFG_PUT
+};
+template <class V, class T, int N, class... A> RFG V mk_vector(A... a)
+{
+    static_assert(sizeof...(A) >= 1, "a constructor needs an argument");
+    Comps<T> c;
+    (c.put(a), ...);
+    V r;
+    for (int i = 0; i < N; ++i) r[i] = c.n == 1 ? c.v[0] : c.v[i];
+    return r;
+}
+#define RFG_MK(V, T, N) \
+    template <class... A> RFG V mk_##V(A... a) { return mk_vector<V, T, N>(a...); }
+RFG_MK(vec2, float, 2) RFG_MK(vec3, float, 3) RFG_MK(vec4, float, 4)
+RFG_MK(ivec2, int, 2) RFG_MK(ivec3, int, 3) RFG_MK(ivec4, int, 4)
+RFG_MK(uvec2, unsigned, 2) RFG_MK(uvec3, unsigned, 3) RFG_MK(uvec4, unsigned, 4)
+#undef RFG_MK
+template <class V, int N, class... A> RFG V mk_bvector(A... a)
+{
+    Comps<float> c;
+    (c.put(a), ...);
+    V r;
+    for (int i = 0; i < N; ++i) r[i] = (c.n == 1 ? c.v[0] : c.v[i]) != 0.0f ? 1 : 0;
+    return r;
+}
+template <class... A> RFG bvec2 mk_bvec2(A... a) { return mk_bvector<bvec2, 2>(a...); }
+template <class... A> RFG bvec3 mk_bvec3(A... a) { return mk_bvector<bvec3, 3>(a...); }
+template <class... A> RFG bvec4 mk_bvec4(A... a) { return mk_bvector<bvec4, 4>(a...); }
+
+// ---- component-wise built-ins ----------------------------------------------------------------------------------------------
+#define RFG_MAP1(V, N, name) \
+    RFG V name(V a) { V r; for (int i = 0; i < N; ++i) r[i] = name(a[i]); return r; }
+#define RFG_MAP2(V, N, name) \
+    RFG V name(V a, V b) { V r; for (int i = 0; i < N; ++i) r[i] = name(a[i], b[i]); return r; }
+#define RFG_MAP2S(V, N, S, name) \
+    RFG V name(V a, S b) { V r; for (int i = 0; i < N; ++i) r[i] = name(a[i], b); return r; }
+#define RFG_MAP3(V, N, name) \
+    RFG V name(V a, V b, V c) { V r; for (int i = 0; i < N; ++i) r[i] = name(a[i], b[i], c[i]); return r; }
+#define RFG_MAP3S(V, N, S, name) \
+    RFG V name(V a, S b, S c) { V r; for (int i = 0; i < N; ++i) r[i] = name(a[i], b, c); return r; }
+#define RFG_V1(P, name) RFG_MAP1(P##2, 2, name) RFG_MAP1(P##3, 3, name) RFG_MAP1(P##4, 4, name)
+#define RFG_V2(P, name) RFG_MAP2(P##2, 2, name) RFG_MAP2(P##3, 3, name) RFG_MAP2(P##4, 4, name)
+#define RFG_V2S(P, S, name) RFG_MAP2S(P##2, 2, S, name) RFG_MAP2S(P##3, 3, S, name) RFG_MAP2S(P##4, 4, S, name)
+#define RFG_V3(P, name) RFG_MAP3(P##2, 2, name) RFG_MAP3(P##3, 3, name) RFG_MAP3(P##4, 4, name)
+#define RFG_V3S(P, S, name) RFG_MAP3S(P##2, 2, S, name) RFG_MAP3S(P##3, 3, S, name) RFG_MAP3S(P##4, 4, S, name)
+#define RFG_FV1(name) RFG_V1(vec, name)
+#define RFG_FV2(name) RFG_V2(vec, name)
+#define RFG_FV2S(name) RFG_V2S(vec, float, name)
+#define RFG_FV3(name) RFG_V3(vec, name)
+#define RFG_FV3S(name) RFG_V3S(vec, float, name)
+
+RFG float abs(float x) { return ::fabsf(x); }
+RFG int abs(int x) { return x < 0 ? -x : x; }
+RFG float sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+RFG int sign(int x) { return x > 0 ? 1 : (x < 0 ? -1 : 0); }
+RFG float floor(float x) { return ::floorf(x); }
+RFG float ceil(float x) { return ::ceilf(x); }
+RFG float trunc(float x) { return ::truncf(x); }
+RFG float roundEven(float x) { return ::rintf(x); }
+RFG float round(float x) { return ::rintf(x); }          // "the fraction 0.5 rounds in a direction chosen by the implementation"
+RFG float fract(float x) { return x - ::floorf(x); }
+RFG float sqrt(float x) { return ::sqrtf(x); }
+RFG float inversesqrt(float x) { return 1.0f / ::sqrtf(x); }
+RFG float exp(float x) { return ::expf(x); }
+RFG float exp2(float x) { return ::exp2f(x); }
+RFG float log(float x) { return ::logf(x); }
+RFG float log2(float x) { return ::log2f(x); }
+RFG float sin(float x) { return ::sinf(x); }
+RFG float cos(float x) { return ::cosf(x); }
+RFG float tan(float x) { return ::tanf(x); }
+RFG float asin(float x) { return ::asinf(x); }
+RFG float acos(float x) { return ::acosf(x); }
+RFG float atan(float x) { return ::atanf(x); }
+RFG float sinh(float x) { return ::sinhf(x); }
+RFG float cosh(float x) { return ::coshf(x); }
+RFG float tanh(float x) { return ::tanhf(x); }
+RFG float radians(float x) { return x * 0.017453292519943295f; }
+RFG float degrees(float x) { return x * 57.29577951308232f; }
+RFG_FV1(abs) RFG_FV1(sign) RFG_FV1(floor) RFG_FV1(ceil) RFG_FV1(trunc) RFG_FV1(roundEven) RFG_FV1(round) RFG_FV1(fract) RFG_FV1(sqrt)
+RFG_FV1(inversesqrt) RFG_FV1(exp) RFG_FV1(exp2) RFG_FV1(log) RFG_FV1(log2) RFG_FV1(sin) RFG_FV1(cos) RFG_FV1(tan) RFG_FV1(asin) RFG_FV1(acos)
+RFG_FV1(atan) RFG_FV1(sinh) RFG_FV1(cosh) RFG_FV1(tanh) RFG_FV1(radians) RFG_FV1(degrees)
+RFG_V1(ivec, abs) RFG_V1(ivec, sign)
+
+// min / max: "y if y < x, otherwise x" / "y if x < y, otherwise x" (the GLSL wording; it decides what a NaN operand gives)
+RFG float min(float x, float y) { return y < x ? y : x; }
+RFG float max(float x, float y) { return x < y ? y : x; }
+RFG int min(int x, int y) { return y < x ? y : x; }
+RFG int max(int x, int y) { return x < y ? y : x; }
+RFG uint min(uint x, uint y) { return y < x ? y : x; }
+RFG uint max(uint x, uint y) { return x < y ? y : x; }
+RFG float mod(float x, float y) { return x - y * ::floorf(x / y); }
+RFG float pow(float x, float y) { return ::powf(x, y); }
+RFG float atan(float y, float x) { return ::atan2f(y, x); }
+RFG float step(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
+RFG_FV2(min) RFG_FV2(max) RFG_FV2(mod) RFG_FV2(pow) RFG_FV2(atan) RFG_FV2(step) RFG_FV2S(min) RFG_FV2S(max) RFG_FV2S(mod)
+RFG_V2(ivec, min) RFG_V2(ivec, max) RFG_V2S(ivec, int, min) RFG_V2S(ivec, int, max) RFG_V2(uvec, min) RFG_V2(uvec, max) RFG_V2S(uvec, uint, min) RFG_V2S(uvec, uint, max)
+RFG vec2 step(float e, vec2 x) { return step(mk_vec2(e), x); }
+RFG vec3 step(float e, vec3 x) { return step(mk_vec3(e), x); }
+RFG vec4 step(float e, vec4 x) { return step(mk_vec4(e), x); }
+
+RFG float clamp(float x, float lo, float hi) { return min(max(x, lo), hi); }
+RFG int clamp(int x, int lo, int hi) { return min(max(x, lo), hi); }
+RFG uint clamp(uint x, uint lo, uint hi) { return min(max(x, lo), hi); }
+RFG float mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+RFG float mix(float x, float y, bool a) { return a ? y : x; }
+RFG float smoothstep(float e0, float e1, float x)
+{
+    const float t = clamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+RFG float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
+RFG vec2 fma(vec2 a, vec2 b, vec2 c) { return __builtin_elementwise_fma(a, b, c); }
+RFG vec3 fma(vec3 a, vec3 b, vec3 c) { return __builtin_elementwise_fma(a, b, c); }
+RFG vec4 fma(vec4 a, vec4 b, vec4 c) { return __builtin_elementwise_fma(a, b, c); }
+RFG_FV3(clamp) RFG_FV3S(clamp) RFG_FV3(mix) RFG_FV3(smoothstep)
+RFG_V3(ivec, clamp) RFG_V3S(ivec, int, clamp) RFG_V3(uvec, clamp) RFG_V3S(uvec, uint, clamp)
+RFG vec2 mix(vec2 x, vec2 y, float a) { return mix(x, y, mk_vec2(a)); }
+RFG vec3 mix(vec3 x, vec3 y, float a) { return mix(x, y, mk_vec3(a)); }
+RFG vec4 mix(vec4 x, vec4 y, float a) { return mix(x, y, mk_vec4(a)); }
+RFG vec2 mix(vec2 x, vec2 y, bvec2 a) { vec2 r; for (int i = 0; i < 2; ++i) r[i] = a[i] ? y[i] : x[i]; return r; }
+RFG vec3 mix(vec3 x, vec3 y, bvec3 a) { vec3 r; for (int i = 0; i < 3; ++i) r[i] = a[i] ? y[i] : x[i]; return r; }
+RFG vec4 mix(vec4 x, vec4 y, bvec4 a) { vec4 r; for (int i = 0; i < 4; ++i) r[i] = a[i] ? y[i] : x[i]; return r; }
+RFG vec2 smoothstep(float a, float b, vec2 x) { return smoothstep(mk_vec2(a), mk_vec2(b), x); }
+RFG vec3 smoothstep(float a, float b, vec3 x) { return smoothstep(mk_vec3(a), mk_vec3(b), x); }
+RFG vec4 smoothstep(float a, float b, vec4 x) { return smoothstep(mk_vec4(a), mk_vec4(b), x); }
+
+RFG bool isnan(float x) { return x != x; }
+RFG bool isinf(float x) { return ::fabsf(x) == __builtin_huge_valf(); }
+RFG int floatBitsToInt(float x) { int r; __builtin_memcpy(&r, &x, 4); return r; }
+RFG uint floatBitsToUint(float x) { uint r; __builtin_memcpy(&r, &x, 4); return r; }
+RFG float intBitsToFloat(int x) { float r; __builtin_memcpy(&r, &x, 4); return r; }
+RFG float uintBitsToFloat(uint x) { float r; __builtin_memcpy(&r, &x, 4); return r; }
+#define RFG_BITS(name, VI, VO) \
+    RFG VO##2 name(VI##2 a) { VO##2 r; __builtin_memcpy(&r, &a, sizeof(r)); return r; } \
+    RFG VO##3 name(VI##3 a) { VO##3 r; for (int i = 0; i < 3; ++i) r[i] = name(a[i]); return r; } \
+    RFG VO##4 name(VI##4 a) { VO##4 r; __builtin_memcpy(&r, &a, sizeof(r)); return r; }
+RFG_BITS(floatBitsToInt, vec, ivec) RFG_BITS(floatBitsToUint, vec, uvec) RFG_BITS(intBitsToFloat, ivec, vec) RFG_BITS(uintBitsToFloat, uvec, vec)
+#undef RFG_BITS
+
+// ---- geometric --------------------------------------------------------------------------------------------------------------
+RFG float dot(float a, float b) { return a * b; }
+RFG float dot(vec2 a, vec2 b) { return a.x * b.x + a.y * b.y; }
+RFG float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RFG float dot(vec4 a, vec4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+RFG float length(float a) { return ::fabsf(a); }
+RFG float length(vec2 a) { return ::sqrtf(dot(a, a)); }
+RFG float length(vec3 a) { return ::sqrtf(dot(a, a)); }
+RFG float length(vec4 a) { return ::sqrtf(dot(a, a)); }
+RFG float distance(float a, float b) { return length(a - b); }
+RFG float distance(vec2 a, vec2 b) { return length(a - b); }
+RFG float distance(vec3 a, vec3 b) { return length(a - b); }
+RFG float distance(vec4 a, vec4 b) { return length(a - b); }
+RFG vec2 normalize(vec2 a) { return a / length(a); }
+RFG vec3 normalize(vec3 a) { return a / length(a); }
+RFG vec4 normalize(vec4 a) { return a / length(a); }
+RFG vec3 cross(vec3 a, vec3 b) { return vec3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+RFG vec2 reflect(vec2 i, vec2 n) { return i - 2.0f * dot(n, i) * n; }
+RFG vec3 reflect(vec3 i, vec3 n) { return i - 2.0f * dot(n, i) * n; }
+RFG vec4 reflect(vec4 i, vec4 n) { return i - 2.0f * dot(n, i) * n; }
+
+// ---- relational -------------------------------------------------------------------------------------------------------------
+#define RFG_REL(name, op, V, B, N) \
+    RFG B name(V a, V b) { B r; for (int i = 0; i < N; ++i) r[i] = a[i] op b[i] ? 1 : 0; return r; }
+#define RFG_RELS(name, op)                                                                                                     \
+    RFG_REL(name, op, vec2, bvec2, 2) RFG_REL(name, op, vec3, bvec3, 3) RFG_REL(name, op, vec4, bvec4, 4)                      \
+    RFG_REL(name, op, ivec2, bvec2, 2) RFG_REL(name, op, ivec3, bvec3, 3) RFG_REL(name, op, ivec4, bvec4, 4)                   \
+    RFG_REL(name, op, uvec2, bvec2, 2) RFG_REL(name, op, uvec3, bvec3, 3) RFG_REL(name, op, uvec4, bvec4, 4)
+RFG_RELS(lessThan, <) RFG_RELS(lessThanEqual, <=) RFG_RELS(greaterThan, >) RFG_RELS(greaterThanEqual, >=) RFG_RELS(equal, ==) RFG_RELS(notEqual, !=)
+#undef RFG_RELS
+#undef RFG_REL
+RFG bool any(bvec2 a) { return (a.x | a.y) != 0; }
+RFG bool any(bvec3 a) { return (a.x | a.y | a.z) != 0; }
+RFG bool any(bvec4 a) { return (a.x | a.y | a.z | a.w) != 0; }
+RFG bool all(bvec2 a) { return a.x != 0 && a.y != 0; }
+RFG bool all(bvec3 a) { return a.x != 0 && a.y != 0 && a.z != 0; }
+RFG bool all(bvec4 a) { return a.x != 0 && a.y != 0 && a.z != 0 && a.w != 0; }
+RFG bvec2 rfg_not(bvec2 a) { return bvec2{a.x == 0, a.y == 0}; }       // GLSL's not(): `not` is an operator spelling in C++, the translator renames the call
+RFG bvec3 rfg_not(bvec3 a) { return bvec3{a.x == 0, a.y == 0, a.z == 0}; }
+RFG bvec4 rfg_not(bvec4 a) { return bvec4{a.x == 0, a.y == 0, a.z == 0, a.w == 0}; }
+RFG bvec2 isnan(vec2 a) { return bvec2{a.x != a.x, a.y != a.y}; }
+RFG bvec3 isnan(vec3 a) { return bvec3{a.x != a.x, a.y != a.y, a.z != a.z}; }
+RFG bvec4 isnan(vec4 a) { return bvec4{a.x != a.x, a.y != a.y, a.z != a.z, a.w != a.w}; }
+
+// ---- matrices: column vectors, m[c][r] as in GLSL ------------------------------------------------------------------------------
+template <class V, int N> struct matN {
+    V c[N];
+    RFG V& operator[](int i) { return c[i]; }
+    RFG const V& operator[](int i) const { return c[i]; }
+};
+typedef matN<vec2, 2> mat2;
+typedef matN<vec3, 3> mat3;
+typedef matN<vec4, 4> mat4;
+template <class M, class V, int N, class... A> RFG M mk_matrix(A... a)
+{
+    Comps<float> c;
+    (c.put(a), ...);
+    M m;
+    for (int col = 0; col < N; ++col)
+        for (int row = 0; row < N; ++row) m.c[col][row] = c.n == 1 ? (col == row ? c.v[0] : 0.0f) : c.v[col * N + row];
+    return m;
+}
+template <class... A> RFG mat2 mk_mat2(A... a) { return mk_matrix<mat2, vec2, 2>(a...); }
+template <class... A> RFG mat3 mk_mat3(A... a) { return mk_matrix<mat3, vec3, 3>(a...); }
+template <class... A> RFG mat4 mk_mat4(A... a) { return mk_matrix<mat4, vec4, 4>(a...); }
+RFG mat3 mk_mat3(mat4 m) { mat3 r; for (int i = 0; i < 3; ++i) r.c[i] = m.c[i].xyz; return r; }
+RFG mat2 mk_mat2(mat3 m) { mat2 r; for (int i = 0; i < 2; ++i) r.c[i] = m.c[i].xy; return r; }
+template <class V, int N> RFG V operator*(const matN<V, N>& m, V v)      // columns scaled and summed left to right
+{
+    V r = m.c[0] * v[0];
+    for (int i = 1; i < N; ++i) r = r + m.c[i] * v[i];
+    return r;
+}
+template <class V, int N> RFG V operator*(V v, const matN<V, N>& m)
+{
+    V r;
+    for (int i = 0; i < N; ++i) r[i] = dot(v, m.c[i]);
+    return r;
+}
+template <class V, int N> RFG matN<V, N> operator*(const matN<V, N>& a, const matN<V, N>& b)
+{
+    matN<V, N> r;
+    for (int i = 0; i < N; ++i) r.c[i] = a * b.c[i];
+    return r;
+}
+template <class V, int N> RFG matN<V, N> operator*(const matN<V, N>& a, float s) { matN<V, N> r; for (int i = 0; i < N; ++i) r.c[i] = a.c[i] * s; return r; }
+template <class V, int N> RFG matN<V, N> operator*(float s, const matN<V, N>& a) { return a * s; }
+template <class V, int N> RFG matN<V, N> operator+(const matN<V, N>& a, const matN<V, N>& b) { matN<V, N> r; for (int i = 0; i < N; ++i) r.c[i] = a.c[i] + b.c[i]; return r; }
+template <class V, int N> RFG matN<V, N> operator-(const matN<V, N>& a, const matN<V, N>& b) { matN<V, N> r; for (int i = 0; i < N; ++i) r.c[i] = a.c[i] - b.c[i]; return r; }
+template <class V, int N> RFG matN<V, N> transpose(const matN<V, N>& a)
+{
+    matN<V, N> r;
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) r.c[i][j] = a.c[j][i];
+    return r;
+}
+
+// ---- storage images -------------------------------------------------------------------------------------------------------------
+// `uniform image2D name`: the allocated image the graph wires to the variable's binding.  Coordinates are FRAME coordinates
+// (imageSize = the whole frame); a rank of a row-strip partition holds rows [y_first - ghost, y_last + ghost] of it
+// (row_lo .. row_hi), which `#pragma rf radius N` promises to be enough.  A load outside the image returns zero, a store
+// outside it is dropped (what Vulkan's robust image access gives; the reference leaves it to the driver).
+template <class Px> struct image2D {
+    char* base;                   // address of frame row 0 (rows outside [row_lo, row_hi] are not this rank's to touch)
+    unsigned long long pitch;
+    int W, H, row_lo, row_hi;     // frame size; frame rows this rank may read
+    int wr_lo, wr_hi;             // frame rows this LAUNCH writes, inclusive (the whole frame on one GPU; a strip's rows, or one part of a split launch)
+};
+template <class Px> RFG ivec2 imageSize(const image2D<Px>& im) { return ivec2{im.W, im.H}; }
+template <class Px> RFG vec4 imageLoad(const image2D<Px>& im, ivec2 p)
+{
+    if ((unsigned)p.x >= (unsigned)im.W || p.y < im.row_lo || p.y > im.row_hi || !im.base) return vec4{0.0f, 0.0f, 0.0f, 0.0f};
+    const auto t = Px::decode(Px::load(im.base + (long long)p.y * (long long)im.pitch, (unsigned)p.x * (unsigned)Px::BPP));
+    return vec4{t.x, t.y, t.z, t.w};
+}
+template <class Px> RFG void imageStore(const image2D<Px>& im, ivec2 p, vec4 v)
+{
+    if ((unsigned)p.x >= (unsigned)im.W || p.y < im.wr_lo || p.y > im.wr_hi || !im.base) return;
+    Px::store(im.base + (long long)p.y * (long long)im.pitch, (unsigned)p.x * (unsigned)Px::BPP, Px::texel(v.x, v.y, v.z, v.w));
+}
+
+// what the kernel hands a shader object (GlslArgs below, the oracle's driver on the host)
+struct GlslImage {
+    char* base;
+    unsigned long long pitch;
+};
+struct GlslFrame {
+    int W, H;                 // the frame (imageSize)
+    int row_lo, row_hi;       // frame rows this rank may read
+    int y0, y1;               // frame rows this launch writes: invocations of other rows do not run
+    int groups_x, groups_y;   // the dispatch: ceil(W/16) x ceil(H/16) workgroups (command.rs:167-168) whatever local_size says
+    int row_origin;           // frame row of the images' local row 0
+    int pad;
+};
+
+}  // namespace rfglsl
+
+// =====================================================================================================================================
+#ifdef __HIPCC_RTC__
+#define RFGLSL_KERNEL 1
+namespace rfglsl {
+
+// Texel formats with the constructor imageStore needs (rf_device.h)
+struct GPxF32 : rf::PxF32 {
+    RFG static rf::f4 texel(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
+};
+struct GPxU8 : rf::PxU8 {
+    RFG static rf::f4 texel(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
+};
+
+RFG void barrier() { __syncthreads(); }
+RFG void memoryBarrier() { __threadfence(); }
+RFG void memoryBarrierShared() { __threadfence_block(); }
+RFG void memoryBarrierImage() { __threadfence(); }
+RFG void memoryBarrierBuffer() { __threadfence(); }
+RFG void groupMemoryBarrier() { __threadfence_block(); }
+
+// One invocation per thread.  S = the translated shader (`Shader<Px>` of its namespace), I = its Info:
+//   I::LX, LY, LZ   local_size of the file
+//   I::GROUPED      the file uses workgroup built-ins, shared variables or barrier(): workgroups are exactly the file's, dispatched
+//                   as the reference does; otherwise only gl_GlobalInvocationID is observable and the launch takes 64 x 4 threads
+//                   per workgroup over the same set of invocations (a wave then reads 64 adjacent texels of a row = 1 KiB
+//                   rgba32f), in XCD-contiguous order
+//   I::NIMG, NBUF, UBO   images (in the order of the shader's `bind`), storage buffers, bytes of uniform data
+// Args: GlslFrame, then NIMG x GlslImage, NBUF x pointer, UBO bytes (all 8-byte aligned; the host packs the same way).
+template <class I> struct GlslArgs {
+    GlslFrame f;
+    GlslImage img[I::NIMG > 0 ? I::NIMG : 1];
+    void* buf[I::NBUF > 0 ? I::NBUF : 1];
+    unsigned char ubo[I::UBO > 0 ? (I::UBO + 7) / 8 * 8 : 8];
+};
+
+template <class S, class I>
+__global__ __launch_bounds__(I::GROUPED ? I::LX * I::LY * I::LZ : 256) void glsl_node_kernel(GlslArgs<I> A)
+{
+    S s;
+    uvec3 wg, lid;
+    if constexpr (I::GROUPED) {
+        const unsigned q = blockIdx.x;
+        if (q >= (unsigned)(A.f.groups_x * A.f.groups_y)) return;
+        wg = uvec3{q % (unsigned)A.f.groups_x, q / (unsigned)A.f.groups_x, 0u};
+        const unsigned t = threadIdx.x;
+        lid = uvec3{t % (unsigned)I::LX, (t / (unsigned)I::LX) % (unsigned)I::LY, t / (unsigned)(I::LX * I::LY)};
+        // a strip: workgroups none of whose rows this launch writes do not run (a workgroup-uniform decision)
+        const int gy0 = (int)wg.y * I::LY;
+        if (gy0 + I::LY <= A.f.y0 || gy0 >= A.f.y1) return;
+    } else {
+        // the same invocations -- x < groups_x * LX, y < groups_y * LY -- in tiles of 64 x 4, every XCD a contiguous range of tiles in
+        // raster order (workgroups are dealt round-robin over the 8 XCDs)
+        const unsigned tiles_x = ((unsigned)(A.f.groups_x * I::LX) + 63u) / 64u;
+        const unsigned y_first = (unsigned)A.f.y0 & ~3u;
+        const unsigned tiles_y = ((unsigned)A.f.y1 - y_first + 3u) / 4u;
+        const unsigned per_xcd = gridDim.x >> 3;
+        const unsigned q = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+        if (q >= tiles_x * tiles_y) return;
+        const unsigned gx = (q % tiles_x) * 64u + (threadIdx.x & 63u), gy = y_first + (q / tiles_x) * 4u + (threadIdx.x >> 6);
+        if (gx >= (unsigned)(A.f.groups_x * I::LX) || gy >= (unsigned)(A.f.groups_y * I::LY)) return;
+        wg = uvec3{gx / (unsigned)I::LX, gy / (unsigned)I::LY, 0u};
+        lid = uvec3{gx % (unsigned)I::LX, gy % (unsigned)I::LY, 0u};
+    }
+    s.gl_WorkGroupID = wg;
+    s.gl_LocalInvocationID = lid;
+    s.gl_NumWorkGroups = uvec3{(unsigned)A.f.groups_x, (unsigned)A.f.groups_y, 1u};
+    s.gl_GlobalInvocationID = wg * uvec3{(unsigned)I::LX, (unsigned)I::LY, (unsigned)I::LZ} + lid;
+    s.gl_LocalInvocationIndex = lid.z * (unsigned)(I::LX * I::LY) + lid.y * (unsigned)I::LX + lid.x;
+    s.rfg_bind(A.f, A.img, A.buf, A.ubo);
+    if constexpr (!I::GROUPED) {
+        if ((int)s.gl_GlobalInvocationID.y < A.f.y0 || (int)s.gl_GlobalInvocationID.y >= A.f.y1) return;
+    }
+    s.main();
+}
+
+}  // namespace rfglsl
+#endif

@@ -187,6 +187,86 @@ rf_status exchange_rows(rf_graph* g, const DeviceImage& img, int r, hipStream_t 
 
 bool exchange_mode(const rf_graph* g) { return g->ctx->world > 1 && !(g->opt.flags & RF_GRAPH_NO_HALO_XCHG); }
 
+// name of the scratch block behind a storage buffer a .comp node declares and the graph leaves unwired (the shader writes it
+// whether anybody reads it or not): allocated with the graph's other buffers
+static std::string unwired_buffer_name(const std::string& label, const std::string& block) { return "\x01unwired:" + label + ":" + block; }
+
+// a node whose type is {shader_path}/{type}.comp (rf_glsl.h): rfglsl::glsl_node_kernel, one invocation of the translated
+// main() per thread.  The dispatch is the reference's: ceil(W/16) x ceil(H/16) workgroups of the file's local_size
+// (command.rs:167-168), in FRAME coordinates; a row strip runs the invocations of its own rows.
+static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, const Geom& geo, hipStream_t stream, const UserStage* u, const JitKernel* k)
+{
+    const Op& op = L.ops[0];
+    const int y_org = g->strip_y0;
+    struct Frame { int W, H, row_lo, row_hi, y0, y1, groups_x, groups_y, row_origin, pad; } fr;
+    static_assert(sizeof(Frame) == 40, "GlslFrame of rf_glsl_dev.h");
+    fr.W = geo.W;
+    fr.H = g->opt.height;
+    fr.row_lo = geo.row_lo + y_org;
+    fr.row_hi = geo.row_hi + y_org;
+    fr.y0 = geo.y0 + y_org;
+    fr.y1 = geo.y1 + y_org;
+    fr.groups_x = (fr.W + 15) / 16;
+    fr.groups_y = (fr.H + 15) / 16;
+    fr.row_origin = y_org;
+    fr.pad = 0;
+    std::vector<unsigned char> args(sizeof(Frame));
+    std::memcpy(args.data(), &fr, sizeof(Frame));
+    auto push = [&](const void* p, size_t n) { args.insert(args.end(), static_cast<const unsigned char*>(p), static_cast<const unsigned char*>(p) + n); };
+    const size_t n_img = std::max<size_t>(u->glsl_images.size(), 1);
+    for (size_t i = 0; i < n_img; ++i) {
+        struct { char* base; unsigned long long pitch; } im{nullptr, 0ull};
+        if (i < u->glsl_images.size()) {
+            const DeviceImage* di = nullptr;
+            for (size_t d = 0; d < L.dsts.size(); ++d)
+                if (u->glsl_image_written[i] && L.dst_bindings[d] == u->glsl_image_binding[i]) di = &f.images.at(L.dsts[d]);
+            if (!di) {
+                auto at = std::find(u->inputs.begin(), u->inputs.end(), u->glsl_images[i]);
+                if (at != u->inputs.end() && (size_t)(at - u->inputs.begin()) < L.src.size()) di = &f.images.at(L.src[(size_t)(at - u->inputs.begin())]);
+            }
+            if (di) {      // address of FRAME row 0 (an address this rank may not own: the shader's loads and stores are bounded by row_lo .. row_hi)
+                im.base = di->base - (ptrdiff_t)y_org * (ptrdiff_t)di->pitch;
+                im.pitch = di->pitch;
+            }
+        }
+        push(&im, sizeof(im));
+    }
+    const size_t n_buf = std::max<size_t>((size_t)u->glsl_buffers, 1);
+    for (size_t b = 0; b < n_buf; ++b) {
+        void* ptr = nullptr;
+        if ((int)b < u->glsl_buffers) {
+            const UserStage::Buffer* decl = nullptr;
+            for (const auto* list : {&u->buf_in, &u->buf_out})
+                for (const auto& x : *list)
+                    if (x.slot == (int)b) decl = &x;
+            if (!decl) return hipErrorInvalidValue;
+            std::string name;
+            for (size_t q = 0; q < L.out_buffers.size(); ++q)
+                if (L.out_buffer_bindings[q] == decl->binding) name = L.out_buffers[q];
+            for (size_t q = 0; q < L.in_buffers.size() && name.empty(); ++q)
+                if (L.in_buffer_bindings[q] == decl->binding) name = L.in_buffers[q];
+            if (name.empty()) name = unwired_buffer_name(L.label, decl->name);
+            auto it = g->dev_buffers.find(name);
+            if (it == g->dev_buffers.end()) return hipErrorInvalidValue;
+            ptr = it->second;
+        }
+        push(&ptr, sizeof(ptr));
+    }
+    const size_t ubo = std::max<size_t>(((size_t)u->params_size + 7) / 8 * 8, 8);
+    if (ubo > sizeof(op.user_params)) return hipErrorInvalidValue;
+    push(op.user_params, ubo);
+    if (u->glsl_grouped) {
+        const unsigned threads = (unsigned)(u->glsl_groups[0] * u->glsl_groups[1] * u->glsl_groups[2]);
+        return jit_launch(*k, (unsigned)fr.groups_x * (unsigned)fr.groups_y, threads, args.data(), args.size(), stream);
+    }
+    // 64 x 4 invocations per workgroup over x < groups_x * LX, the rows of this launch (the kernel aligns the first to 4)
+    const unsigned tiles_x = ((unsigned)(fr.groups_x * u->glsl_groups[0]) + 63u) / 64u;
+    const unsigned y_first = (unsigned)fr.y0 & ~3u;
+    const unsigned tiles_y = ((unsigned)fr.y1 - y_first + 3u) / 4u;
+    const unsigned long tiles = (unsigned long)tiles_x * tiles_y;
+    return jit_launch(*k, (unsigned)((tiles + 7) / 8 * 8), 256, args.data(), args.size(), stream);
+}
+
 // a user NODE (rf_user.h, a stage file that declares its images): user_node_kernel of rf_user_dev.h, compiled at graph creation
 static hipError_t launch_user_node(rf_graph* g, const Launch& L, FrameSlot& f, const Geom& geo, hipStream_t stream)
 {
@@ -196,6 +276,7 @@ static hipError_t launch_user_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     const UserStage* u = user_stage_by_id(op.user_id);
     const JitKernel* k = jit_lookup_user_node(fmt, op.user_id);
     if (!u || !k || L.src.size() != u->inputs.size()) return hipErrorInvalidDeviceFunction;      // graph_build compiled it: cannot happen
+    if (u->glsl) return launch_glsl_node(g, L, f, geo, stream, u, k);
     UserNodeArgs A;
     std::memset(&A, 0, sizeof(A));
     for (size_t i = 0; i < L.src.size(); ++i) {
@@ -218,7 +299,7 @@ static hipError_t launch_user_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     A.grid_x = (geo.W + 255) / 256;
     A.row_lo = geo.row_lo;
     A.row_hi = geo.row_hi;
-    static_assert(sizeof(A.params) == sizeof(op.user_params), "Params block");
+    static_assert(sizeof(A.params) <= sizeof(op.user_params), "Params block");
     std::memcpy(A.params, op.user_params, sizeof(A.params));
     // storage buffers by block type name (shader.rs:144-147): the one it reads must be wired (build_launches), the one it fills
     // is filled only when the graph wires it to something
@@ -691,9 +772,27 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
     }
     rebuild_ops(g);
     for (const auto& L : g->launches) {
-        if (L.ops.size() != 1 || L.ops[0].kind != OP_USERN || L.out_buffers.empty()) continue;
+        if (L.ops.size() != 1 || L.ops[0].kind != OP_USERN) continue;
         const UserStage* u = user_stage_by_id(L.ops[0].user_id);
-        if (u && !u->buf_out.empty()) g->fills_buffers = true;
+        if (u && u->glsl) {
+            // a .comp node addresses the FRAME: split over ranks it needs to say how far it reads (#pragma rf radius N, rf_glsl.h)
+            if (ctx->world > 1 && !u->radius_stated)
+                return fail(RF_ERR_UNSUPPORTED, "node '" + L.label + "': " + u->file_name() + " does not say `#pragma rf radius N` (rows an invocation reads above / below its own); "
+                                                "without it the node cannot be split into row strips");
+            // the blocks it declares and the graph leaves unwired: the shader writes them all the same
+            for (const auto* list : {&u->buf_in, &u->buf_out})
+                for (const auto& b : *list) {
+                    if (std::find(L.in_buffer_bindings.begin(), L.in_buffer_bindings.end(), b.binding) != L.in_buffer_bindings.end() ||
+                        std::find(L.out_buffer_bindings.begin(), L.out_buffer_bindings.end(), b.binding) != L.out_buffer_bindings.end()) continue;
+                    const std::string name = unwired_buffer_name(L.label, b.name);
+                    if (g->dev_buffers.count(name)) continue;
+                    float* d = nullptr;
+                    HIP_TRY(hipMalloc((void**)&d, std::max<size_t>(b.bytes, 4)));
+                    g->dev_buffers[name] = d;
+                    HIP_TRY(hipMemset(d, 0, std::max<size_t>(b.bytes, 4)));
+                }
+        }
+        if (u && !u->buf_out.empty() && (!L.out_buffers.empty() || u->glsl)) g->fills_buffers = true;
     }
     if (g->fills_buffers && opt.num_frames > 1) HIP_TRY(hipEventCreateWithFlags(&g->buffers_idle, hipEventDisableTiming));
     g->input_image = std::find(plan.images.begin(), plan.images.end(), kFileInput) != plan.images.end() ? kFileInput : "";

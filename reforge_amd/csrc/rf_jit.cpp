@@ -18,7 +18,7 @@ namespace rf {
 
 namespace {
 
-// the device source: rf_device.h + rf_stream_dev.h + rf_user_dev.h, generated into build/ by the Makefile
+// the device source: rf_device.h + rf_stream_dev.h + rf_user_dev.h + rf_glsl_dev.h, generated into build/ by the Makefile
 const char kSource[] =
 #include "build/rf_jit_source.inc"
     ;
@@ -185,6 +185,10 @@ void cache_store(const std::string& stem, const Compiled& c)
 
 std::string node_expression(int fmt, const UserStage& u)
 {
+    if (u.glsl) {      // {type}.comp: rfglsl::glsl_node_kernel<Shader<texel format>, Info> (rf_glsl_dev.h)
+        const std::string ns = "rfglsl::" + u.ident + "::";
+        return "rfglsl::glsl_node_kernel<" + ns + "Shader<" + (fmt == kFmtRGBA8 ? "rfglsl::GPxU8" : "rfglsl::GPxF32") + ">, " + ns + "Info>";
+    }
     return std::string("rf::user_node_kernel<") + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", rfuser::" + u.ident + "::Stage>";
 }
 
@@ -222,7 +226,7 @@ const Compiled* compile_expr(const std::string& expr, const std::vector<int>& us
     // A user NODE reads its neighbourhood through Window::at inside loops of the file's own (rf_user_dev.h): with small radii the
     // window is a register copy, which only pays when those loops are unrolled -- a 5 x 5 tap loop over an inlined body is beyond
     // the compiler's default threshold, so it is raised for these kernels (their bodies are a few hundred instructions).
-    const bool node = expr.find("user_node_kernel") != std::string::npos;
+    const bool node = expr.find("user_node_kernel") != std::string::npos || expr.find("glsl_node_kernel") != std::string::npos;
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", wpb.c_str(), "-mllvm", "-unroll-threshold=6000"};
     rc = r->AddNameExpression(prog, expr.c_str());
     if (rc == 0) rc = r->CompileProgram(prog, node ? 7 : 5, opts);
@@ -357,7 +361,7 @@ bool jit_compile_user_node(int fmt, int user_id, std::string& err)
     std::lock_guard<std::mutex> lock(g_mu);
     const UserStage* u = user_stage_by_id(user_id);
     if (!u || !u->multi) { err = "not a user node"; return false; }
-    if (!u->buf_out.empty() && !load_expr(fill_expression(*u), {user_id}, 1, 4, err)) return false;      // RF_BUFFER_OUT: its fill kernel
+    if (!u->glsl && !u->buf_out.empty() && !load_expr(fill_expression(*u), {user_id}, 1, 4, err)) return false;      // RF_BUFFER_OUT: its fill kernel
     return load_expr(node_expression(fmt, *u), {user_id}, 1, 4, err);
 }
 
@@ -365,7 +369,7 @@ const JitKernel* jit_lookup_user_fill(int user_id)
 {
     std::lock_guard<std::mutex> lock(g_mu);
     const UserStage* u = user_stage_by_id(user_id);
-    if (!u || u->buf_out.empty()) return nullptr;
+    if (!u || u->glsl || u->buf_out.empty()) return nullptr;
     auto it = g_loaded.find(loaded_key(fill_expression(*u)));
     return it == g_loaded.end() ? nullptr : &it->second;
 }
@@ -385,7 +389,7 @@ size_t jit_compile_only_user_node(int fmt, int user_id, std::string& err)
     const UserStage* u = user_stage_by_id(user_id);
     if (!u || !u->multi) { err = "not a user node"; return 0; }
     size_t total = 0;
-    if (!u->buf_out.empty()) {
+    if (!u->glsl && !u->buf_out.empty()) {
         const Compiled* f = compile_expr(fill_expression(*u), {user_id}, 4, err);
         if (!f) return 0;
         total += f->code.size();

@@ -53,7 +53,8 @@ struct Op {
     float wc = 1, ws = 0;            // sharpen centre / side weight
     const float* dev_weights = nullptr;   // conv2d: device pointer, [K][K]
     int   user_id = -1;              // OP_USER / OP_USERN: the stage (rf_user.h) ...
-    unsigned char user_params[56] = {};   // ... and its Params block, laid out as the device compiler does
+    unsigned char user_params[256] = {};  // ... and its Params block, laid out as the device compiler does (stage files: up to 56 bytes;
+                                     // a .comp file: its uniform blocks, std140, up to 256)
     int   slot = 0;                  // inside a fused fork/join launch: 1 = node of the branch feeding input_image0, 2 = of the branch
                                      // feeding input_image1; 0 = before the fork, the join itself, after the join, or a plain chain
 };

@@ -80,10 +80,15 @@ const std::vector<NodeType>& registry()
 
 const NodeType* find_type(const std::string& name, std::string* why)
 {
+    std::string err;
+    if (files_first()) {      // the reference's rule: the file IS the type (config.rs:59-75) -- a file that does not translate is an error, not a fallback
+        const UserStage* u = user_stage_for_type(name, err);
+        if (u) return &u->node_type;
+        if (!err.empty()) { if (why) *why = err; return nullptr; }
+    }
     for (const auto& t : registry())
         if (name == t.name) return &t;
-    // not built in: a type that is a file, {shader_path}/{name}.stage.hip (config.rs:59-75; rf_user.h)
-    std::string err;
+    // not built in: a type that is a file, {shader_path}/{name}.stage.hip or {name}.comp (config.rs:59-75; rf_user.h, rf_glsl.h)
     const UserStage* u = user_stage_for_type(name, err);
     if (why) *why = err;
     return u ? &u->node_type : nullptr;
@@ -853,18 +858,34 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
                     return false;
                 }
                 L.in_buffers.push_back(nm);
+                L.in_buffer_bindings.push_back(b.second);
             }
-            for (const auto& b : info.output_ssbos) L.out_buffers.push_back(plan.resolve_buffer(b.first));
-            if (unode && !unode->buf_in.empty() && L.in_buffers.empty()) {
-                err = "node '" + unit + "' needs a storage buffer wired to " + unode->buf_in[0].name;
-                return false;
-            }
+            for (const auto& b : info.output_ssbos) { L.out_buffers.push_back(plan.resolve_buffer(b.first)); L.out_buffer_bindings.push_back(b.second); }
             if (unode) {
+                auto has = [](const std::vector<UserStage::Buffer>& v, int binding) {
+                    for (const auto& b : v)
+                        if (b.binding == binding) return true;
+                    return false;
+                };
+                auto block_of = [&](int binding) {
+                    for (const auto* list : {&unode->buf_in, &unode->buf_out})
+                        for (const auto& b : *list)
+                            if (b.binding == binding) return b.name;
+                    return std::string("?");
+                };
+                // every block the node only READS must be wired (a block it fills may stay unwired: a stage file's is then not filled, a .comp file's is private to the node)
+                for (const auto& b : unode->buf_in) {
+                    if (has(unode->buf_out, b.binding)) continue;      // updated in place: wired on either side, or private to the node (rf_graph.cpp allocates it)
+                    if (std::find(L.in_buffer_bindings.begin(), L.in_buffer_bindings.end(), b.binding) == L.in_buffer_bindings.end()) {
+                        err = "node '" + unit + "' needs a storage buffer wired to " + b.name;
+                        return false;
+                    }
+                }
                 // a block type name wired on the wrong side (the planner looked it up without regard to direction)
-                for (const auto& b : info.input_ssbos)
-                    if (unode->buf_in.empty() || b.second != unode->buf_in[0].binding) { err = "node '" + unit + "': " + unode->buf_out[0].name + " is the buffer " + unode->type_name + " writes, the graph wires it as an input"; return false; }
-                for (const auto& b : info.output_ssbos)
-                    if (unode->buf_out.empty() || b.second != unode->buf_out[0].binding) { err = "node '" + unit + "': " + unode->buf_in[0].name + " is the buffer " + unode->type_name + " reads, the graph wires it as an output"; return false; }
+                for (int bb : L.in_buffer_bindings)
+                    if (!has(unode->buf_in, bb)) { err = "node '" + unit + "': " + block_of(bb) + " is the buffer " + unode->type_name + " writes, the graph wires it as an input"; return false; }
+                for (int bb : L.out_buffer_bindings)
+                    if (!has(unode->buf_out, bb)) { err = "node '" + unit + "': " + block_of(bb) + " is the buffer " + unode->type_name + " reads, the graph wires it as an output"; return false; }
             }
             for (const auto& s : L.src) {
                 if (std::find(plan.images.begin(), plan.images.end(), s) == plan.images.end()) {

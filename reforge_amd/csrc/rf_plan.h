@@ -103,6 +103,7 @@ struct LaunchDesc {
     std::vector<std::string> dsts;  // every allocated image the launch writes: 1, or up to 2 for a multi-output node (split_luma)
     std::vector<int> dst_bindings;  // the output binding each entry of `dsts` is wired to
     std::vector<std::string> in_buffers, out_buffers;   // allocated storage-buffer names the launch reads / writes
+    std::vector<int> in_buffer_bindings, out_buffer_bindings;   // the binding each of them is wired to
     int radius = 0;                 // vertical halo read beyond the rows written
     int need_src = 0;               // ghost rows of src the launch reads (multi-rank)
     int need_dst = 0;               // ghost rows of dst the launch must also produce (over-fetch mode)

@@ -1,5 +1,6 @@
 // rf_user.cpp -- see rf_user.h.  Host only.
 #include "rf_user.h"
+#include "rf_glsl.h"
 
 #include <sys/stat.h>
 
@@ -18,6 +19,7 @@ namespace {
 
 std::mutex g_mu;
 std::string g_dir;
+bool g_files_first = false;
 std::deque<UserStage> g_stages;                        // stable addresses: NodeType pointers are handed out
 std::map<std::string, int> g_latest;                   // type name -> newest entry
 std::map<const NodeType*, int> g_by_type;
@@ -146,6 +148,7 @@ bool parse_user_stage(const std::string& type, const std::string& text, UserStag
             return false;
         }
         b.count = (int)count;
+        b.bytes = (size_t)count * sizeof(float);
         (side == 0 ? out.buf_in : out.buf_out).push_back(b);
         out.multi = true;
     }
@@ -172,6 +175,7 @@ bool parse_user_stage(const std::string& type, const std::string& text, UserStag
 
 std::string UserStage::wrapper() const
 {
+    if (glsl) return glsl_source;
     std::string w = "\nnamespace rfuser { namespace " + ident + " {\nusing rf::f4;\nusing rf::Window;\n#define RF_STAGE static __device__ __forceinline__\n"
                     "#define RF_INPUTS(...) static_assert(true, \"\")\n#define RF_OUTPUTS(...) static_assert(true, \"\")\n"
                     "#define RF_BUFFER_IN(...) static_assert(true, \"\")\n#define RF_BUFFER_OUT(...) static_assert(true, \"\")\n#line 1 \"" +
@@ -195,6 +199,78 @@ std::string UserStage::wrapper() const
     return w;
 }
 
+bool parse_glsl_stage(const std::string& type, const std::string& text, UserStage& out, std::string& err)
+{
+    out = UserStage();
+    out.type_name = type;
+    out.text = text;
+    out.glsl = true;
+    out.multi = true;
+    char hx[40];
+    std::snprintf(hx, sizeof(hx), "g%d_%016llx", kGlslTranslatorVersion, (unsigned long long)fnv1a(type + "\n" + text));
+    out.ident = hx;
+    GlslShader sh;
+    if (!glsl_translate(type, text, out.ident, sh, err)) return false;
+    out.glsl_source = sh.source;
+    out.radius = sh.radius < 0 ? 0 : sh.radius;
+    out.radius_stated = sh.radius >= 0;
+    out.glsl_grouped = sh.grouped;
+    out.glsl_groups[0] = sh.lx; out.glsl_groups[1] = sh.ly; out.glsl_groups[2] = sh.lz;
+    out.inputs.clear();
+    out.outputs.clear();
+    for (const auto& im : sh.images) {
+        out.glsl_images.push_back(im.name);
+        out.glsl_image_binding.push_back(im.binding);
+        out.glsl_image_written.push_back(!im.readonly);
+        if (!im.writeonly) { out.inputs.push_back(im.name); out.in_binding.push_back(im.binding); }
+        if (!im.readonly) { out.outputs.push_back(im.name); out.out_binding.push_back(im.binding); }
+    }
+    if (out.outputs.empty() && sh.ssbos.empty()) { err = type + ".comp: the shader writes no image and has no storage block: nothing it does can be observed"; return false; }
+    if (out.radius > 0)
+        for (const auto& im : sh.images)
+            if (!im.readonly && !im.writeonly) { err = type + ".comp: `" + im.name + "` is read and written (no readonly / writeonly) by a shader that reads its neighbourhood (#pragma rf radius " + std::to_string(out.radius) + "): a stencil cannot run in place"; return false; }
+    for (size_t k = 0; k < sh.ssbos.size(); ++k) {
+        const GlslBlock& b = sh.ssbos[k];
+        UserStage::Buffer ub;
+        ub.name = b.type_name;
+        ub.count = b.bytes / 4;
+        ub.bytes = (size_t)b.bytes;
+        ub.binding = b.binding;
+        ub.slot = (int)k;
+        if (!b.writeonly) out.buf_in.push_back(ub);
+        if (!b.readonly) out.buf_out.push_back(ub);
+    }
+    out.glsl_buffers = (int)sh.ssbos.size();
+    // uniform members the host can set: scalars (render.rs:169-185: FLOAT, INT -- spirv-reflect's flag for both signednesses --, BOOL);
+    // every other member stays zero, as there (render.rs:200-203)
+    for (const auto& blk : sh.ubos)
+        for (const auto& m : blk.members) {
+            if (m.comps != 1 || m.cols != 1 || !m.dims.empty()) continue;
+            UserParam p;
+            p.name = m.name;
+            p.type = m.base == 'f' ? PARAM_F32 : (m.base == 'b' ? PARAM_BOOL : PARAM_I32);
+            p.offset = blk.ubo_base + m.offset;
+            p.size = 4;
+            for (const auto& q : out.params)
+                if (q.name == p.name) { err = type + ".comp: two uniform members are called `" + p.name + "` (parameters are matched by member name, pipeline_graph.rs:276-292)"; return false; }
+            out.params.push_back(p);
+        }
+    out.params_size = std::max(1, sh.ubo_bytes);
+    return true;
+}
+
+void set_files_first(bool on)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_files_first = on;
+}
+
+bool files_first()
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    return g_files_first;
+}
+
 void set_shader_path(const std::string& dir)
 {
     std::lock_guard<std::mutex> lock(g_mu);
@@ -214,8 +290,14 @@ const UserStage* user_stage_for_type(const std::string& type, std::string& err)
     std::lock_guard<std::mutex> lock(g_mu);
     err.clear();
     if (g_dir.empty() || !ident_ok(type)) return nullptr;
-    const std::string path = g_dir + "/" + type + ".stage.hip";
-    const long long mt = file_mtime_ns(path);
+    std::string path = g_dir + "/" + type + ".stage.hip";
+    long long mt = file_mtime_ns(path);
+    bool glsl = false;
+    if (mt < 0) {      // the reference's own form: {type}.comp (config.rs:59-75)
+        path = g_dir + "/" + type + ".comp";
+        mt = file_mtime_ns(path);
+        glsl = true;
+    }
     if (mt < 0) return nullptr;                       // no such filter (Shader::from_path -> None, utils.rs:23)
     auto it = g_latest.find(type);
     if (it != g_latest.end() && g_stages[(size_t)it->second].mtime_ns == mt && g_stages[(size_t)it->second].path == path) return &g_stages[(size_t)it->second];
@@ -227,7 +309,7 @@ const UserStage* user_stage_for_type(const std::string& type, std::string& err)
         return &g_stages[(size_t)it->second];
     }
     UserStage st;
-    if (!parse_user_stage(type, text, st, err)) return nullptr;
+    if (!(glsl ? parse_glsl_stage(type, text, st, err) : parse_user_stage(type, text, st, err))) return nullptr;
     st.path = path;
     st.mtime_ns = mt;
     st.id = (int)g_stages.size();
@@ -240,8 +322,12 @@ const UserStage* user_stage_for_type(const std::string& type, std::string& err)
     for (size_t i = 0; i < s.inputs.size(); ++i) s.node_type.images.push_back({s.inputs[i].c_str(), s.in_binding[i]});
     for (size_t o = 0; o < s.outputs.size(); ++o)
         if (std::find(s.inputs.begin(), s.inputs.end(), s.outputs[o]) == s.inputs.end()) s.node_type.images.push_back({s.outputs[o].c_str(), s.out_binding[o]});
-    for (const auto* list : {&s.buf_in, &s.buf_out})
-        for (const auto& b : *list) s.node_type.buffers.push_back(NodeType::BufferDef{b.name.c_str(), b.binding, (size_t)b.count * sizeof(float)});
+    for (const auto& b : s.buf_in) s.node_type.buffers.push_back(NodeType::BufferDef{b.name.c_str(), b.binding, b.bytes});
+    for (const auto& b : s.buf_out) {
+        bool listed = false;
+        for (const auto& a : s.buf_in) listed = listed || a.binding == b.binding;      // a block updated in place: one binding, listed once
+        if (!listed) s.node_type.buffers.push_back(NodeType::BufferDef{b.name.c_str(), b.binding, b.bytes});
+    }
     for (const auto& p : s.params) s.node_type.params.push_back(ParamDef{p.name.c_str(), p.type});
     g_latest[type] = s.id;
     g_by_type[&s.node_type] = s.id;

@@ -44,8 +44,20 @@ struct UserStage {
     std::vector<int> in_binding, out_binding;      // their bindings: inputs 0.., outputs after them; a name on both sides shares one
     // storage buffers of a node (RF_BUFFER_IN / RF_BUFFER_OUT: block TYPE name + number of floats; shader.rs:144-147): at most one
     // read (handed to apply() as `const float*`) and one written (element i = fill(params, i), by a small kernel in front of the node's)
-    struct Buffer { std::string name; int count = 0, binding = -1; };
+    struct Buffer { std::string name; int count = 0, binding = -1; size_t bytes = 0; int slot = -1; };     // slot: GLSL, the index in GlslArgs::buf
     std::vector<Buffer> buf_in, buf_out;
+    // {type}.comp, the reference's own plugin form (rf_glsl.h): translated GLSL, always a node with a kernel of its own
+    // (rfglsl::glsl_node_kernel), any number of images and storage blocks; a block that is neither readonly nor writeonly is on
+    // both lists (one binding: updated in place, pipeline_graph.rs:240-247)
+    bool glsl = false;
+    bool radius_stated = true;    // GLSL: the file says `#pragma rf radius N` (what a row-strip partition needs to know)
+    std::vector<std::string> glsl_images;          // image variables in declaration order (= GlslArgs::img)
+    std::vector<int> glsl_image_binding;
+    std::vector<bool> glsl_image_written;          // the variable is not readonly
+    int glsl_buffers = 0, glsl_groups[3] = {1, 1, 1};
+    bool glsl_grouped = false;
+    std::string glsl_source;      // the translation
+    std::string file_name() const { return type_name + (glsl ? ".comp" : ".stage.hip"); }
     std::vector<UserParam> params;
     int params_size = 1;          // sizeof(Params) as the device compiler lays it out (checked there by static_assert)
     long long mtime_ns = 0;
@@ -56,12 +68,18 @@ struct UserStage {
 // [host] directory searched for {type}.stage.hip ("" = none); process-wide like Render's shader_path (render.rs:537-588)
 void set_shader_path(const std::string& dir);
 const std::string& shader_path();
-// the stage of a type the built-in registry lacks: loads / reloads {shader_path}/{type}.stage.hip.  nullptr: no such file
-// (err empty) or a file that does not parse (err set)
+// the stage of a type the built-in registry lacks: loads / reloads {shader_path}/{type}.stage.hip, or, when there is no such
+// file, {shader_path}/{type}.comp.  nullptr: no such file (err empty) or a file that does not parse (err set)
 const UserStage* user_stage_for_type(const std::string& type, std::string& err);
 const UserStage* user_stage_by_id(int id);
 const UserStage* user_stage_of(const NodeType* t);
 // parse one stage file's text (exposed for the tests of the parser)
 bool parse_user_stage(const std::string& type, const std::string& text, UserStage& out, std::string& err);
+// the same for {type}.comp: translate (rf_glsl.h) and fill the entry from the shader's reflection
+bool parse_glsl_stage(const std::string& type, const std::string& text, UserStage& out, std::string& err);
+// 0 (default): a built-in type wins over a file of the same name; 1: a file in {shader_path} wins -- the reference's rule, where
+// the file IS the type (config.rs:59-75): a reforge user's shader directory then runs as it is, built-in names included
+void set_files_first(bool on);
+bool files_first();
 
 }  // namespace rf

@@ -87,6 +87,37 @@ def shader_path():
     return lib().rf_shader_path().decode()
 
 
+def _glsl_text(fn, what, type_name, text):
+    raw = text.encode("utf-8")
+    cap = 16 * len(raw) + (1 << 16)
+    while True:
+        buf = C.create_string_buffer(cap)
+        n = C.c_size_t()
+        st = fn(type_name.encode(), raw, buf, cap, C.byref(n))
+        if st == 1 and n.value + 1 > cap:
+            cap = n.value + 1
+            continue
+        _check(st, what)
+        return buf.raw[:n.value].decode("utf-8")
+
+
+def glsl_translate(type_name, text):
+    """HIP device source of the GLSL compute shader `text` ({shader_path}/{type_name}.comp, rf_glsl_translate); raises RfError
+    with "type.comp:LINE: why" for a file outside the translated subset."""
+    return _glsl_text(lib().rf_glsl_translate, "rf_glsl_translate", type_name, text)
+
+
+def glsl_reflect(type_name, text):
+    """What spirv-reflect gives the reference for the shader (src/vulkan/shader.rs:106-160), as a dict (rf_glsl_reflect)."""
+    import json
+    return json.loads(_glsl_text(lib().rf_glsl_reflect, "rf_glsl_reflect", type_name, text))
+
+
+def set_type_lookup(files_first):
+    """True: a file in the shader path wins over a built-in type of the same name (the reference's rule); False (default): the built-in."""
+    _check(lib().rf_set_type_lookup(1 if files_first else 0), "rf_set_type_lookup")
+
+
 def strip_rows(height, world, rank):
     y0, y1 = C.c_int(), C.c_int()
     _check(lib().rf_strip_rows(height, world, rank, C.byref(y0), C.byref(y1)), "rf_strip_rows")

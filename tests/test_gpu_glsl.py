@@ -1,0 +1,330 @@
+"""GPU: filter types in the reference's own file form -- {shader_path}/{type}.comp, GLSL 450 compute (src/config/config.rs:59-75,
+src/vulkan/shader.rs:29-160) -- translated by rf_glsl.cpp, compiled by hiprtc at rf_graph_create, run by rfglsl::glsl_node_kernel.
+
+Oracle: shaders/*.comp restate the authored node types in the oracle's tap order, so a graph run THROUGH THE GLSL FILES
+must give the bits oracle/rf_oracle.c gives for the same config -- a check of the translator, the GLSL prelude and the kernel against
+code that shares nothing with them.  Shaders that have no counterpart in the oracle (workgroup-shared memory, storage blocks updated
+in place, matrices, structs, out parameters) are checked against numpy restatements written here."""
+import os
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+import reforge_amd as rf
+from oracle import graph as ograph
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHADERS = os.path.join(ROOT, "shaders")
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import glsl_weights  # noqa: E402
+
+
+@pytest.fixture
+def glsl_dir(tmp_path):
+    """an empty shader directory with the FILE-first lookup of the reference; a test copies in the .comp files it wants run as GLSL"""
+    old = rf.shader_path()
+    rf.set_shader_path(str(tmp_path))
+    rf.set_type_lookup(True)
+    yield tmp_path
+    rf.set_type_lookup(False)
+    rf.set_shader_path(old)
+
+
+def use(glsl_dir, *types):
+    for t in types:
+        shutil.copy(os.path.join(SHADERS, t + ".comp"), glsl_dir / (t + ".comp"))
+
+
+def glsl_launches(text):
+    return rf.Plan(rf.Config(text)).launches()
+
+
+G5 = glsl_weights.as_params(1.0, 2)
+G9 = glsl_weights.as_params(2.0, 4)
+G7 = glsl_weights.as_params(2.5, 7)
+
+# (types run as GLSL, config): every authored node type through its .comp file
+TWINS = {
+    "gaussian5": (["gaussian5"], "input -> gg -> output\ngg: gaussian5 { sigma: 1.0, %s }" % G5),
+    "gaussian9": (["gaussian9"], "input -> gg -> output\ngg: gaussian9 { sigma: 2.0, %s }" % G9),
+    "gaussian_r7": (["gaussian"], "input -> gg -> output\ngg: gaussian { sigma: 2.5, radius: 7, %s }" % G7),
+    "colour_grade": (["colour_grade"], "input -> cg -> output\ncg: colour_grade { slope: 1.1, offset: -0.02, saturation: 1.2 }"),
+    "colour_grade_inplace": (["colour_grade_inplace"], "input -> aa -> cg:image -> bb -> output\naa: passthrough {}\nbb: passthrough {}\ncg: colour_grade_inplace { slope: 0.9, offset: 0.03, saturation: 0.4 }"),
+    "sharpen": (["sharpen"], "input -> sh -> output\nsh: sharpen { amount: 0.75 }"),
+    "combination": (["combination"], "input -> aa -> mx:input_image0\ninput -> mx:input_image1\nmx -> output\naa: sharpen { amount: 1.0 }\nmx: combination { mix: 0.3 }"),
+    "split_luma": (["split_luma"], util.SPLIT2),
+    "conv2d_7": (["conv2d"], "input -> kw -> cv -> output\nkw:ConvWeights -> cv:ConvWeights\nkw: conv2d_weights { ksize: 7, sigma: 1.5 }\ncv: conv2d { ksize: 7 }"),
+    "chain3": (["gaussian5", "colour_grade", "sharpen"], util.CHAIN3.replace("sigma: 1.0 }", "sigma: 1.0, %s }" % G5)),
+}
+
+
+@pytest.mark.parametrize("fmt", [util.F32, util.U8], ids=["rgba32f", "rgba8"])
+@pytest.mark.parametrize("name", sorted(TWINS))
+def test_a_graph_run_through_the_glsl_files_matches_the_oracle(ctx, glsl_dir, name, fmt):
+    types, text = TWINS[name]
+    use(glsl_dir, *types)
+    for W, H in ((250, 131), (64, 4), (17, 13), (1, 1)):
+        img = util.synthetic(W, H, fmt, seed=0x61 + W)
+        want = util.run_oracle(text, img)
+        got = util.run_hip(ctx, text, img)
+        util.assert_same(got, want, "%s %dx%d" % (name, W, H))
+
+
+def test_the_files_are_what_ran(ctx, glsl_dir):
+    """with the file-first lookup a type that is a file is a node with a kernel of its own: the 3-stage chain is three launches, not one fused"""
+    use(glsl_dir, "gaussian5", "colour_grade", "sharpen")
+    assert glsl_launches(util.CHAIN3) == ["blur", "grade", "sharp"]
+    rf.set_type_lookup(False)
+    assert glsl_launches(util.CHAIN3) == ["blur+grade+sharp"]
+    rf.set_type_lookup(True)
+    assert rf.Plan(rf.Config(util.CHAIN3)).needs_jit() == [True, True, True]
+
+
+def test_the_reference_passthrough_shader_text(ctx, glsl_dir):
+    """the one shader the reference ships (shaders/passthrough.comp there: rgba8 qualifiers, no bounds guard, local_size 16 x 16):
+    restated here character for character in its 13 lines' terms -- loads and stores outside the image are dropped"""
+    (glsl_dir / "passthrough.comp").write_text(
+        "#version 450\n\nlayout (local_size_x = 16, local_size_y = 16) in;\nlayout (binding = 0, rgba8) uniform readonly image2D input_image;\n"
+        "layout (binding = 1, rgba8) uniform writeonly image2D output_image;\n\nvoid main()\n{\t\n    vec4 res = imageLoad(input_image, ivec2(gl_GlobalInvocationID.xy));\n\n\n"
+        "    imageStore(output_image, ivec2(gl_GlobalInvocationID.xy), res);\n}\n")
+    for fmt in (util.F32, util.U8):
+        for W, H in ((512, 512), (250, 131), (3, 5)):
+            img = util.synthetic(W, H, fmt)
+            got = util.run_hip(ctx, "input -> pp -> output\npp: passthrough {}", img)
+            util.assert_same(got, img, "passthrough %dx%d" % (W, H))
+
+
+# ---- the reference's dispatch: ceil(W/16) x ceil(H/16) workgroups of WHATEVER local_size the file declares (command.rs:167-168) ------
+def test_a_local_size_below_16_covers_part_of_the_frame_as_in_the_reference(ctx, glsl_dir):
+    (glsl_dir / "half.comp").write_text("""#version 450
+layout (local_size_x = 8, local_size_y = 4) in;
+layout (binding = 0, rgba32f) uniform readonly image2D input_image;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); imageStore(output_image, p, imageLoad(input_image, p) + vec4(1.0)); }
+""")
+    W, H = 100, 70
+    img = util.synthetic(W, H, util.F32)
+    got = util.run_hip(ctx, "input -> hh -> output\nhh: half {}", img)
+    cx, cy = ((W + 15) // 16) * 8, ((H + 15) // 16) * 4        # invocations that exist
+    assert cx < W and cy < H
+    util.assert_same(got[:cy, :cx], img[:cy, :cx] + np.float32(1.0), "covered")
+    want = img + np.float32(1.0)
+    assert not (got[cy:] == want[cy:]).any() and not (got[:, cx:] == want[:, cx:]).any()      # never written
+
+
+# ---- workgroup-shared memory and barrier(): the file's own workgroups -----------------------------------------------------------------
+TILE_BLUR = """#version 450
+// a 3x3 box mean through a workgroup tile: 16 x 16 invocations stage an 18 x 18 tile (clamp-to-edge) in shared memory
+#pragma rf radius 1
+#define T 16
+layout (local_size_x = T, local_size_y = T) in;
+layout (binding = 0, rgba32f) uniform readonly image2D input_image;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+const int HALO = 1;
+shared vec4 tile[T + 2 * HALO][T + 2 * HALO];
+
+vec4 fetch(ivec2 q, ivec2 size) { return imageLoad(input_image, clamp(q, ivec2(0), size - 1)); }
+
+void main()
+{
+    ivec2 size = imageSize(input_image);
+    ivec2 p = ivec2(gl_GlobalInvocationID.xy);
+    ivec2 l = ivec2(gl_LocalInvocationID.xy);
+    ivec2 org = ivec2(gl_WorkGroupID.xy) * T - HALO;
+    for (uint i = gl_LocalInvocationIndex; i < uint((T + 2) * (T + 2)); i += gl_WorkGroupSize.x * gl_WorkGroupSize.y) {
+        ivec2 t = ivec2(int(i) % (T + 2), int(i) / (T + 2));
+        tile[t.y][t.x] = fetch(org + t, size);
+    }
+    barrier();
+    if (p.x >= size.x || p.y >= size.y) return;
+    precise vec4 acc = vec4(0.0);
+    for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx) acc += tile[l.y + dy][l.x + dx];
+    imageStore(output_image, p, acc * (1.0 / 9.0));
+}
+"""
+
+
+def box3(img):
+    H, W, _ = img.shape
+    ys = np.clip(np.arange(-1, H + 1), 0, H - 1)
+    xs = np.clip(np.arange(-1, W + 1), 0, W - 1)
+    pad = img[ys][:, xs]
+    acc = np.zeros_like(img)
+    for dy in range(3):
+        for dx in range(3):
+            acc = acc + pad[dy:dy + H, dx:dx + W]
+    return acc * np.float32(1.0 / 9.0)
+
+
+def test_shared_memory_and_barrier_run_in_the_files_own_workgroups(ctx, glsl_dir):
+    (glsl_dir / "tile_blur.comp").write_text(TILE_BLUR)
+    r = rf.glsl_reflect("tile_blur", TILE_BLUR)
+    assert r["grouped"] and r["radius"] == 1 and r["local_size"] == [16, 16, 1]
+    for W, H in ((250, 131), (16, 16), (33, 7)):
+        img = util.synthetic(W, H, util.F32)
+        got = util.run_hip(ctx, "input -> tb -> output\ntb: tile_blur {}", img)
+        util.assert_same(got, box3(img), "tile_blur %dx%d" % (W, H))
+
+
+# ---- language coverage: structs, out parameters, matrices, swizzles, integer / bool / vector uniforms, several storage blocks ------------
+KITCHEN = """#version 450
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform readonly image2D input_image;
+layout (binding = 4, rgba32f) uniform readonly image2D other_image;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+layout (binding = 2) uniform Params {
+    float gain;
+    int   shift;
+    bool  flip;
+    uint  mask;
+    vec3  tint;          // not a parameter the host sets (render.rs:169-185 knows scalars): stays zero
+    float bias;
+};
+layout (std430, binding = 3) readonly buffer Lut { float lut[8]; vec4 corner; };
+layout (std430, binding = 5) buffer Stats { uint hits[4]; } stats;
+
+struct Pair { vec3 a; float k; };
+const mat3 TO_YUV = mat3(0.299, -0.147, 0.615, 0.587, -0.289, -0.515, 0.114, 0.436, -0.100);
+
+void split(vec4 t, out vec3 rgb, out float a) { rgb = t.rgb; a = t.a; }
+float pick(float v[3], int i) { return v[i]; }
+Pair make(vec3 a, float k) { return Pair(a, k); }
+
+void main()
+{
+    ivec2 size = imageSize(output_image);
+    ivec2 p = ivec2(gl_GlobalInvocationID.xy);
+    if (any(greaterThanEqual(p, size))) return;
+    ivec2 q = flip ? ivec2(size.x - 1 - p.x, p.y) : p;
+    vec3 rgb; float a;
+    split(imageLoad(input_image, q), rgb, a);
+    vec3 yuv = TO_YUV * rgb;
+    Pair pr = make(yuv.zyx, gain);
+    float w[3] = float[](pr.a.x, pr.a.y, pr.a.z);
+    vec4 o = vec4(pick(w, 2), pick(w, 1), pick(w, 0), a);
+    o.rg = o.gr * pr.k;
+    o.b += lut[(p.x + shift) & 7] + bias + tint.x;
+    uvec2 u = uvec2(p) & mask;
+    o.a = float(u.x + u.y) + corner.w + imageLoad(other_image, p).s;
+    if (p.x < 4 && p.y == 0) stats.hits[p.x] = stats.hits[p.x] + uint(p.x) + 1u;
+    imageStore(output_image, p, mix(o, o.wzyx, bvec4(false, true, false, true)));
+}
+"""
+
+KITCHEN_FILL = """#version 450
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform readonly image2D input_image;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+layout (std430, binding = 3) writeonly buffer Lut { float lut[8]; vec4 corner; };
+void main()
+{
+    ivec2 p = ivec2(gl_GlobalInvocationID.xy);
+    if (p.y == 0 && p.x < 8) lut[p.x] = 0.125 * float(p.x);
+    if (p.x == 0 && p.y == 0) corner = vec4(1.0, 2.0, 3.0, 0.5);
+    imageStore(output_image, p, imageLoad(input_image, p));
+}
+"""
+
+
+def kitchen(img, other, gain, shift, flip, mask, bias):
+    H, W, _ = img.shape
+    f = np.float32
+    src = img[:, ::-1] if flip else img
+    m = np.array([[0.299, -0.147, 0.615], [0.587, -0.289, -0.515], [0.114, 0.436, -0.100]], f)      # columns of TO_YUV
+    rgb = src[..., :3]
+    yuv = (m[0] * rgb[..., 0:1] + m[1] * rgb[..., 1:2]) + m[2] * rgb[..., 2:3]      # columns scaled, summed left to right
+    zyx = yuv[..., ::-1]
+    o = np.empty_like(img)
+    o[..., 0], o[..., 1], o[..., 2], o[..., 3] = zyx[..., 2], zyx[..., 1], zyx[..., 0], src[..., 3]
+    r, g = o[..., 1] * f(gain), o[..., 0] * f(gain)
+    o[..., 0], o[..., 1] = r, g
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H))
+    lut = (f(0.125) * np.arange(8, dtype=f))
+    o[..., 2] = (o[..., 2] + ((lut[(xs + shift) & 7] + f(bias)) + f(0.0))).astype(f)
+    o[..., 3] = ((xs & mask) + (ys & mask)).astype(f) + f(0.5) + other[..., 0]
+    out = o.copy()
+    out[..., 1], out[..., 3] = o[..., 2], o[..., 0]      # mix(o, o.wzyx, (F, T, F, T)): y <- z, w <- x
+    return out
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_structs_matrices_out_parameters_and_several_storage_blocks(ctx, glsl_dir, flip):
+    (glsl_dir / "kitchen.comp").write_text(KITCHEN)
+    (glsl_dir / "kitchen_fill.comp").write_text(KITCHEN_FILL)
+    text = """
+input -> kf -> kk:input_image
+input -> gg -> kk:other_image
+kf:Lut -> kk:Lut
+kk -> output
+gg: colour_grade { slope: 0.5, offset: 0.25, saturation: 1.0 }
+kf: kitchen_fill {}
+kk: kitchen { gain: 1.5, shift: 3, flip: %s, mask: 5, bias: 0.25 }
+""" % ("true" if flip else "false")
+    r = rf.glsl_reflect("kitchen", KITCHEN)
+    off = {m["name"]: m["offset"] for m in r["uniform_blocks"][0]["members"]}
+    assert off == {"gain": 0, "shift": 4, "flip": 8, "mask": 12, "tint": 16, "bias": 28} and r["uniform_bytes"] == 32      # std140: the float packs behind the vec3
+    lut = r["storage_blocks"][0]
+    assert [m["offset"] for m in lut["members"]] == [0, 32] and lut["bytes"] == 48
+    W, H = 70, 37
+    img = util.synthetic(W, H, util.F32)
+    other = util.run_oracle("input -> gg -> output\ngg: colour_grade { slope: 0.5, offset: 0.25, saturation: 1.0 }", img)
+    got = util.run_hip(ctx, text, img)
+    util.assert_same(got, kitchen(img, other, 1.5, 3, flip, 5, 0.25), "kitchen flip=%s" % flip)
+
+
+# ---- row strips: the launch split into interior and boundary rows (the geometry of the halo exchange, one GPU) ----------------------------
+def test_a_stencil_shader_split_into_row_ranges_gives_the_same_frame(ctx, glsl_dir, monkeypatch):
+    use(glsl_dir, "local_contrast", "gaussian5")
+    lc = (glsl_dir / "local_contrast.comp").read_text()
+    (glsl_dir / "local_contrast.comp").write_text(lc.replace("layout (local_size_x", "#pragma rf radius 2\nlayout (local_size_x", 1))
+    g5 = (glsl_dir / "gaussian5.comp").read_text()
+    (glsl_dir / "gaussian5.comp").write_text(g5.replace("#define RADIUS 2", "#define RADIUS 2\n#pragma rf radius 2", 1))
+    text = "input -> gg -> lc -> output\ngg: gaussian5 { sigma: 1.0, %s }\nlc: local_contrast { amount: 0.8 }" % G5
+    assert [l["radius"] for l in rf.Plan(rf.Config(text)).launch_info()] == [2, 2]
+    img = util.synthetic(200, 90, util.F32)
+    whole = util.run_hip(ctx, text, img)
+    monkeypatch.setenv("RF_FORCE_SPLIT", "1")
+    split = util.run_hip(ctx, text, img)
+    util.assert_same(split, whole, "split launches")
+    rf.set_type_lookup(False)
+    from tests.util import register_user_types
+    old = register_user_types()
+    try:
+        want = util.run_oracle(text, img)
+    finally:
+        rf.set_shader_path(old)
+    util.assert_same(whole, want, "against the oracle (stage-file twin of local_contrast)")
+
+
+def test_an_edited_shader_is_translated_again(ctx, glsl_dir):
+    src = open(os.path.join(SHADERS, "invert.comp")).read()
+    (glsl_dir / "invert.comp").write_text(src)
+    text = "input -> iv -> output\niv: invert { enabled: true, strength: 1.0 }"
+    img = util.synthetic(64, 20, util.F32)
+    a = util.run_hip(ctx, text, img)
+    t0 = rf.lib().rf_user_stage_mtime(b"invert")
+    assert t0 > 0
+    (glsl_dir / "invert.comp").write_text(src.replace("void main()", "void main_body()").replace("#version 450", "#version 450\nvoid main_body();", 1) +
+                                         "\nvoid main() { main_body(); ivec2 p = ivec2(gl_GlobalInvocationID.xy); imageStore(output_image, p, imageLoad(input_image, p) * 0.5); }\n")
+    os.utime(glsl_dir / "invert.comp", ns=(10 ** 18, 10 ** 18))
+    b = util.run_hip(ctx, text, img)
+    util.assert_same(b, img * np.float32(0.5), "edited")
+    assert not np.array_equal(a, b) and rf.lib().rf_user_stage_mtime(b"invert") == 10 ** 18
+
+
+def test_a_file_outside_the_subset_is_refused_with_its_line(ctx, glsl_dir):
+    (glsl_dir / "bad.comp").write_text("#version 450\nlayout (local_size_x = 16, local_size_y = 16) in;\nlayout (binding = 0) uniform sampler2D tex;\nvoid main() {}\n")
+    with pytest.raises(rf.RfError) as e:
+        rf.Plan(rf.Config("input -> bb -> output\nbb: bad {}"))
+    assert "bad.comp:3" in str(e.value)
+    (glsl_dir / "worse.comp").write_text("#version 450\nlayout (local_size_x = 16) in;\nlayout (binding = 0, rgba32f) uniform readonly image2D input_image;\n"
+                                        "layout (binding = 1, rgba32f) uniform writeonly image2D output_image;\nvoid main() { imageStore(output_image, ivec2(0), undefined_thing); }\n")
+    img = util.synthetic(16, 16, util.F32)
+    with pytest.raises(rf.RfError) as e:
+        util.run_hip(ctx, "input -> ww -> output\nww: worse {}", img)
+    assert "worse.comp" in str(e.value) and "undefined_thing" in str(e.value)
