@@ -779,13 +779,25 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
          "    uint gl_LocalInvocationIndex;\n"
          "    const uvec3 gl_WorkGroupSize = uvec3{" + std::to_string(out.lx) + "u, " + std::to_string(out.ly) + "u, " + std::to_string(out.lz) + "u};\n";
     s += tr.members;
+    // readable images get a tile of the workgroup's neighbourhood in LDS when the file states its radius (rf_glsl_dev.h)
+    std::string tiles, read_list;
+    int n_read = 0;
+    for (size_t i = 0; i < out.images.size(); ++i)
+        if (!out.images[i].writeonly) {
+            tiles += "        " + out.images[i].name + ".set_tile(lds0 + " + std::to_string(n_read) + "u * bytes_each, tx0, ty0, tw, th);\n";
+            read_list += (n_read ? ", " : "") + std::to_string(i);
+            ++n_read;
+        }
+    s += "    typedef Px PxT;\n    RFG void rfg_tiles(unsigned lds0, unsigned bytes_each, int tx0, int ty0, int tw, int th)\n    {\n        (void)lds0; (void)bytes_each; (void)tx0; (void)ty0; (void)tw; (void)th;\n" + tiles + "    }\n";
     s += "    RFG void rfg_bind(const GlslFrame& f, const GlslImage* img, void* const* buf, const unsigned char* ubo)\n    {\n        (void)f; (void)img; (void)buf; (void)ubo;\n" + tr.bind + "    }\n";
     s += "#line 1 \"" + type + ".comp\"\n";
     s += emit(tr.v, 0, tr.v.size());
     s += "\n};\n";
     for (const auto& m : tr.cx.macros) s += "#undef " + m + "\n";
     s += "struct Info {\n    static constexpr int LX = " + std::to_string(out.lx) + ", LY = " + std::to_string(out.ly) + ", LZ = " + std::to_string(out.lz) + ", NIMG = " + std::to_string(out.images.size()) +
-         ", NBUF = " + std::to_string(out.ssbos.size()) + ", UBO = " + std::to_string(out.ubo_bytes) + ";\n    static constexpr bool GROUPED = " + (out.grouped ? "true" : "false") + ";\n};\n} }\n";
+         ", NBUF = " + std::to_string(out.ssbos.size()) + ", UBO = " + std::to_string(out.ubo_bytes) + ", RADIUS = " + std::to_string(out.radius < 0 ? 0 : out.radius) + ", NREAD = " + std::to_string(n_read) + ";\n    static constexpr bool GROUPED = " +
+         (out.grouped ? "true" : "false") + ", TILED = " + (!out.grouped && out.radius >= 1 && out.radius <= 15 && n_read >= 1 ? "true" : "false") + ";\n    static constexpr int READ[" + std::to_string(n_read > 0 ? n_read : 1) + "] = {" +
+         (n_read ? read_list : std::string("0")) + "};\n};\n} }\n";
     out.source = s;
     return true;
 }

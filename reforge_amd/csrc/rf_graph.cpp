@@ -210,6 +210,9 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     fr.groups_y = (fr.H + 15) / 16;
     fr.row_origin = y_org;
     fr.pad = 0;
+    // the launch that runs the frame's last row also runs the invocations below it that the dispatch covers (they exist in the
+    // reference; their image accesses fall outside the frame and are dropped, their storage-block writes are not)
+    if (fr.y1 == fr.H) fr.y1 = std::max(fr.H, fr.groups_y * u->glsl_groups[1]);
     std::vector<unsigned char> args(sizeof(Frame));
     std::memcpy(args.data(), &fr, sizeof(Frame));
     auto push = [&](const void* p, size_t n) { args.insert(args.end(), static_cast<const unsigned char*>(p), static_cast<const unsigned char*>(p) + n); };
@@ -258,6 +261,11 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     if (u->glsl_grouped) {
         const unsigned threads = (unsigned)(u->glsl_groups[0] * u->glsl_groups[1] * u->glsl_groups[2]);
         return jit_launch(*k, (unsigned)fr.groups_x * (unsigned)fr.groups_y, threads, args.data(), args.size(), stream);
+    }
+    const UserTile tile = user_tile((int)bytes_per_pixel(g->opt.format), u->radius, u->glsl_reads);
+    if (u->glsl_tiled && tile.lds) {      // 64 x TH invocations per workgroup, their neighbourhood staged in LDS (rf_glsl_dev.h)
+        const unsigned long tx = ((unsigned)(fr.groups_x * u->glsl_groups[0]) + 63u) / 64u, ty = ((unsigned)(fr.y1 - fr.y0) + (unsigned)tile.th - 1u) / (unsigned)tile.th;
+        return jit_launch(*k, (unsigned)((tx * ty + 7) / 8 * 8), 256, args.data(), args.size(), stream);
     }
     // 64 x 4 invocations per workgroup over x < groups_x * LX, the rows of this launch (the kernel aligns the first to 4)
     const unsigned tiles_x = ((unsigned)(fr.groups_x * u->glsl_groups[0]) + 63u) / 64u;

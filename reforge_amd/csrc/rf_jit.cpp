@@ -187,7 +187,7 @@ std::string node_expression(int fmt, const UserStage& u)
 {
     if (u.glsl) {      // {type}.comp: rfglsl::glsl_node_kernel<Shader<texel format>, Info> (rf_glsl_dev.h)
         const std::string ns = "rfglsl::" + u.ident + "::";
-        return "rfglsl::glsl_node_kernel<" + ns + "Shader<" + (fmt == kFmtRGBA8 ? "rfglsl::GPxU8" : "rfglsl::GPxF32") + ">, " + ns + "Info>";
+        return "rfglsl::glsl_node_kernel<" + ns + "Shader, " + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", " + ns + "Info>";
     }
     return std::string("rf::user_node_kernel<") + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", rfuser::" + u.ident + "::Stage>";
 }

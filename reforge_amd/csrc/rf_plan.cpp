@@ -873,6 +873,11 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
                             if (b.binding == binding) return b.name;
                     return std::string("?");
                 };
+                // a block type name wired on the wrong side (the planner looked it up without regard to direction)
+                for (int bb : L.in_buffer_bindings)
+                    if (!has(unode->buf_in, bb)) { err = "node '" + unit + "': " + block_of(bb) + " is the buffer " + unode->type_name + " writes, the graph wires it as an input"; return false; }
+                for (int bb : L.out_buffer_bindings)
+                    if (!has(unode->buf_out, bb)) { err = "node '" + unit + "': " + block_of(bb) + " is the buffer " + unode->type_name + " reads, the graph wires it as an output"; return false; }
                 // every block the node only READS must be wired (a block it fills may stay unwired: a stage file's is then not filled, a .comp file's is private to the node)
                 for (const auto& b : unode->buf_in) {
                     if (has(unode->buf_out, b.binding)) continue;      // updated in place: wired on either side, or private to the node (rf_graph.cpp allocates it)
@@ -881,11 +886,6 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
                         return false;
                     }
                 }
-                // a block type name wired on the wrong side (the planner looked it up without regard to direction)
-                for (int bb : L.in_buffer_bindings)
-                    if (!has(unode->buf_in, bb)) { err = "node '" + unit + "': " + block_of(bb) + " is the buffer " + unode->type_name + " writes, the graph wires it as an input"; return false; }
-                for (int bb : L.out_buffer_bindings)
-                    if (!has(unode->buf_out, bb)) { err = "node '" + unit + "': " + block_of(bb) + " is the buffer " + unode->type_name + " reads, the graph wires it as an output"; return false; }
             }
             for (const auto& s : L.src) {
                 if (std::find(plan.images.begin(), plan.images.end(), s) == plan.images.end()) {

@@ -1,0 +1,269 @@
+"""CPU: filter types that are GLSL compute shaders -- {shader_path}/{type}.comp, the reference's own plugin form
+(src/config/config.rs:59-75; compiled and reflected there by shaderc + spirv-reflect, src/vulkan/shader.rs:73-160).
+
+* reflection: what rf_glsl.cpp reads off a file is what the reference's reflection gives -- image variables by name, storage blocks by
+  block type name, uniform members by member name -- and, for the shipped shaders, what the built-in registry says of the same type;
+* semantics without a GPU: the translation of every shaders/*.comp, compiled for the HOST (tests/glsl_host.py), gives the bits of
+  oracle/rf_oracle.c for the same node -- translator and GLSL prelude against code that shares nothing with them;
+* the gfx950 code objects build (hiprtc, no device needed); files outside the subset are refused with file:line.
+tests/test_gpu_glsl.py runs the same files on the GPU."""
+import os
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+import reforge_amd as rf
+from oracle import graph as ograph
+from oracle import pixel
+from tests import util
+from tests.glsl_host import HostShader
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHADERS = os.path.join(ROOT, "shaders")
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import glsl_weights  # noqa: E402
+
+COMP = sorted(f[:-5] for f in os.listdir(SHADERS) if f.endswith(".comp"))
+
+
+def text_of(t):
+    return open(os.path.join(SHADERS, t + ".comp")).read()
+
+
+@pytest.fixture
+def glsl_dir(tmp_path):
+    old = rf.shader_path()
+    rf.set_shader_path(str(tmp_path))
+    rf.set_type_lookup(True)
+    yield tmp_path
+    rf.set_type_lookup(False)
+    rf.set_shader_path(old)
+
+
+# ---- reflection ---------------------------------------------------------------------------------------------------------------------
+def test_every_shipped_shader_translates_and_reflects_like_the_registry():
+    assert len(COMP) >= 15
+    for t in COMP:
+        r = rf.glsl_reflect(t, text_of(t))
+        assert r["local_size"] == [16, 16, 1] and not r["grouped"], t
+        if t in rf.registry_types():
+            for im in r["images"]:      # same variable on the same binding as the hand-written type (shader.rs:151-153)
+                assert rf.registry_binding(t, im["name"]) == im["binding"], (t, im)
+        src = rf.glsl_translate(t, text_of(t))
+        assert "struct Shader" in src and "RFG void main()" in src and "#line 1 \"%s.comp\"" % t in src
+
+
+def test_uniform_blocks_follow_std140_and_storage_blocks_std430():
+    src = """#version 450
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform image2D image;
+#define N 3
+const int M = N + 1;
+layout (binding = 1) uniform Params { float a; vec2 b; vec3 c; float d; float w[N]; mat3 m; int k; bool on; uvec4 u; } ;
+layout (binding = 2) uniform More { float z; } more;
+layout (std430, binding = 3) buffer Data { float f[M]; vec2 g; vec3 h[2]; vec4 i; mat2 j; uint n; } ;
+layout (std430, binding = 4) readonly buffer Named { vec4 v[4]; float s; } named;
+void main() { }
+"""
+    r = rf.glsl_reflect("layouts", src)
+    p = {m["name"]: (m["offset"], m["stride"], m["bytes"]) for m in r["uniform_blocks"][0]["members"]}
+    assert p == {"a": (0, 4, 4), "b": (8, 8, 8), "c": (16, 12, 12), "d": (28, 4, 4), "w": (32, 16, 48), "m": (80, 48, 48), "k": (128, 4, 4), "on": (132, 4, 4), "u": (144, 16, 16)}
+    assert r["uniform_blocks"][0]["bytes"] == 160 and r["uniform_blocks"][1]["base"] == 160 and r["uniform_bytes"] == 176
+    assert [m["name"] for m in r["uniform_blocks"][1]["members"]] == ["more.z"]      # the key of the reference's UBO map (pipeline_graph.rs:276-292)
+    d = {m["name"]: (m["offset"], m["stride"], m["bytes"]) for m in r["storage_blocks"][0]["members"]}
+    assert d == {"f": (0, 4, 16), "g": (16, 8, 8), "h": (32, 16, 32), "i": (64, 16, 16), "j": (80, 16, 16), "n": (96, 4, 4)}
+    assert r["storage_blocks"][0]["bytes"] == 112 and not r["storage_blocks"][0]["readonly"]
+    assert r["storage_blocks"][1]["readonly"] and r["storage_blocks"][1]["instance"] == "named" and r["storage_blocks"][1]["bytes"] == 80
+    assert r["images"] == [{"name": "image", "binding": 0, "readonly": False, "writeonly": False}]
+    src2 = rf.glsl_translate("layouts", src)
+    assert "static constexpr int M = N + 1 ;" in src2 and "Named_t* named;" in src2 and "float* f;" in src2 and "vec2* rfg_p_g;" in src2
+
+
+def test_what_the_translator_rewrites():
+    src = rf.glsl_translate("tt", """#version 450
+#extension GL_EXT_something : enable
+precision highp float;
+layout (local_size_x = 8, local_size_y = 8) in;
+layout (binding = 0, rgba8) uniform readonly image2D input_image;
+layout (binding = 1, rgba8) uniform writeonly image2D output_image;
+struct Light { vec3 dir; float power; };
+float helper(in float a, out float b, inout vec2 c, const in float d[2]);
+#define HALF(v) ((v) * vec4(0.5))
+float helper(in float a, out float b, inout vec2 c, const in float d[2]) { b = a * 2.; c.ts = c.st; return 1e-3 + d[1] + .5 + 3.0lf; }
+void main()
+{
+    highp float x = 1.0; precise vec4 o = vec4(x, 0, 1u, true);
+    float arr[2] = float[2](1.0, 2.0);
+    Light l = Light(vec3(0.0, 1.0, 0.0), 2.0);
+    vec2 c = vec2(0.25); float b;
+    o.r = helper(x, b, c, arr) + l.power + float(0x1F);
+    if (any(not(lessThan(o, vec4(0.5))))) o = HALF(o);
+    imageStore(output_image, ivec2(gl_GlobalInvocationID.xy), o.bgra);
+}
+""")
+    assert "#extension" not in src and "precision" not in src and "highp" not in src and "precise" not in src
+    assert src.count("helper(") == 2      # the prototype is gone (a member function is declared once); definition + call remain
+    assert "RFG float helper( float a,  float &b,  vec2 &c, const  float d[2])" in src
+    assert "b = a * 2.f; c.yx = c.xy; return 1e-3f + d[1] + .5f + 3.0;" in src
+    assert "float x = 1.0f;  vec4 o = mk_vec4(x, 0, 1u, true);" in src
+    assert "float arr[2] = {1.0f, 2.0f};" in src
+    assert "Light l = Light{mk_vec3(0.0f, 1.0f, 0.0f), 2.0f};" in src
+    assert "#define HALF(v) ((v) * mk_vec4(0.5f))" in src and "#undef HALF" in src
+    assert "rfg_not(lessThan(o, mk_vec4(0.5f)))" in src and "float(0x1F)" in src and "o.bgra" in src
+    assert "LX = 8, LY = 8, LZ = 1, NIMG = 2, NBUF = 0, UBO = 0" in src and "GROUPED = false" in src
+
+
+REFUSED = [
+    ("layout (binding = 0) uniform sampler2D tex;\nvoid main() {}", "bad.comp:1", "sampler2D"),
+    ("void main() { double x = 1.0; }", "bad.comp:1", "double"),
+    ("layout (std430, binding = 0) buffer Data { float v[]; };\nvoid main() {}", "bad.comp:1", "unsized"),
+    ("struct S { float a; };\nlayout (binding = 0) uniform P { S s; };\nvoid main() {}", "bad.comp:2", "nested structs"),
+    ("layout (rgba32f) uniform image2D image;\nvoid main() {}", "bad.comp:1", "binding"),
+    ("layout (binding = 1, rgba32f) uniform image2D aa;\nlayout (binding = 1, rgba32f) uniform image2D bb;\nvoid main() {}", "bad.comp:2", "used twice"),
+    ("layout (binding = 0, rgba32f) uniform image2D image;\nfloat f() { return 1.0; }", "bad.comp", "no `void main()`"),
+    ("#include \"common.glsl\"\nvoid main() {}", "bad.comp:1", "#include"),
+    ("layout (set = 1, binding = 0, rgba32f) uniform image2D image;\nvoid main() {}", "bad.comp:1", "set 0"),
+    ("layout (binding = 0, rgba32f) uniform image2D image;\nlayout (binding = 1) uniform P { float w[9]; float v[60]; };\nvoid main() {}", "bad.comp:2", "limit is 256"),
+    ("layout (local_size_x = 64, local_size_y = 32) in;\nlayout (binding = 0, rgba32f) uniform image2D image;\nvoid main() {}", "bad.comp", "out of range"),
+    ("layout (binding = 0, rgba32f) uniform readonly image2D image;\nvoid main() {}", "bad.comp", "nothing it does can be observed"),
+    ("#pragma rf radius 1\nlayout (binding = 0, rgba32f) uniform image2D image;\nvoid main() {}", "bad.comp", "cannot run in place"),
+]
+
+
+@pytest.mark.parametrize("k", range(len(REFUSED)))
+def test_files_outside_the_subset_are_refused_with_file_and_line(k):
+    body, where, what = REFUSED[k]
+    with pytest.raises(rf.RfError) as e:
+        rf.glsl_translate("bad", body)
+    assert where in str(e.value) and what in str(e.value), str(e.value)
+
+
+# ---- semantics on the host: the shipped shaders against oracle/rf_oracle.c -----------------------------------------------------------------
+def host_node(t, images, params=None, buffers=None):
+    HostShader(t, text_of(t)).run(images, params, buffers)
+
+
+def gparams(sigma, radius):
+    return dict({"sigma": sigma}, **{"w%d" % i: w for i, w in enumerate(glsl_weights.weights(sigma, radius))})
+
+
+@pytest.mark.parametrize("fmt", [util.F32, util.U8], ids=["rgba32f", "rgba8"])
+def test_the_shipped_shaders_run_on_the_host_give_the_oracles_bits(fmt):
+    W, H = 37, 23
+    img = util.synthetic(W, H, fmt)
+    other = util.synthetic(W, H, fmt, seed=77)
+
+    def out():
+        return np.zeros_like(img)
+
+    o = out()
+    host_node("gaussian5", {"input_image": img, "output_image": o}, gparams(1.0, 2))
+    util.assert_same(o, pixel.gaussian(img, 2, sigma=1.0), "gaussian5")
+    o = out()
+    host_node("gaussian9", {"input_image": img, "output_image": o}, gparams(2.0, 4))
+    util.assert_same(o, pixel.gaussian(img, 4, sigma=2.0), "gaussian9")
+    o = out()
+    host_node("gaussian", {"input_image": img, "output_image": o}, dict(gparams(2.5, 7), radius=7))
+    util.assert_same(o, pixel.gaussian(img, 7, sigma=2.5), "gaussian radius 7")
+    o = out()
+    host_node("colour_grade", {"input_image": img, "output_image": o}, {"slope": 1.1, "offset": -0.02, "saturation": 1.2})
+    util.assert_same(o, pixel.colour_grade(img, 1.1, -0.02, 1.2), "colour_grade")
+    o = img.copy()
+    host_node("colour_grade_inplace", {"image": o}, {"slope": 0.9, "offset": 0.03, "saturation": 0.4})
+    util.assert_same(o, pixel.colour_grade(img, 0.9, 0.03, 0.4), "colour_grade_inplace")
+    o = out()
+    host_node("sharpen", {"input_image": img, "output_image": o}, {"amount": 0.75})
+    util.assert_same(o, pixel.sharpen(img, 0.75), "sharpen")
+    o = out()
+    host_node("combination", {"input_image0": img, "input_image1": other, "output_image": o}, {"mix": 0.3})
+    util.assert_same(o, pixel.mix(img, other, 0.3), "combination")
+    luma, chroma = out(), out()
+    host_node("split_luma", {"input_image": img, "luma_image": luma, "chroma_image": chroma})
+    wl, wc = pixel.split_luma(img, np.zeros_like(img), np.zeros_like(img))
+    util.assert_same(luma, wl, "split_luma luma")
+    util.assert_same(chroma, wc, "split_luma chroma")
+    K = 7
+    w = ograph.default_conv_weights(K, 1.5).astype(np.float32)
+    buf = np.zeros(961, np.float32)
+    buf[:K * K] = w.ravel()
+    o = out()
+    host_node("conv2d", {"input_image": img, "output_image": o}, {"ksize": K}, {"ConvWeights": buf})
+    util.assert_same(o, pixel.conv2d(img, w.reshape(K, K)), "conv2d 7x7 through its ConvWeights block")
+
+
+def test_the_user_type_twins_run_on_the_host_match_their_stage_files():
+    """edge_detect / invert / unsharp_mask / local_contrast exist as .stage.hip (what the oracle compiles for the host,
+    oracle/user_stage.py) and as .comp: one config, the same bits"""
+    old = util.register_user_types()
+    try:
+        W, H = 41, 19
+        img = util.synthetic(W, H, util.F32)
+        for t, params in (("invert", {"enabled": 1, "strength": 0.7}), ("edge_detect", {"scale": 1.5}), ("local_contrast", {"amount": 0.8})):
+            text = "input -> nn -> output\nnn: %s { %s }" % (t, ", ".join("%s: %s" % (k, ("true" if v == 1 and k == "enabled" else v)) for k, v in params.items()))
+            want = util.run_oracle(text, img)
+            o = np.zeros_like(img)
+            host_node(t, {"input_image": img, "output_image": o}, params)
+            util.assert_same(o, want, t)
+        blurred = pixel.gaussian(img, 4, sigma=2.0)
+        want = util.run_oracle("input -> bl -> um:blurred_image\ninput -> um:input_image\num -> output\nbl: gaussian9 { sigma: 2.0 }\num: unsharp_mask { amount: 1.5, threshold: 0.02 }", img)
+        o, m = np.zeros_like(img), np.zeros_like(img)
+        host_node("unsharp_mask", {"input_image": img, "blurred_image": blurred, "output_image": o, "mask_image": m}, {"amount": 1.5, "threshold": 0.02})
+        util.assert_same(o, want, "unsharp_mask")
+    finally:
+        rf.set_shader_path(old)
+
+
+def test_conv2d_weights_fills_its_block_from_invocations_beyond_a_small_frame():
+    """the reference dispatches whole 16 x 16 workgroups (command.rs:167-168): on a 5 x 3 frame the 7 x 7 weights are written by
+    invocations that lie outside the frame -- they must exist here too"""
+    img = util.synthetic(5, 3, util.F32)
+    o = np.zeros_like(img)
+    buf = np.zeros(961, np.float32)
+    host_node("conv2d_weights", {"input_image": img, "output_image": o}, {"ksize": 7, "sigma": 0.0}, {"ConvWeights": buf})
+    want = np.zeros(49, np.float32)
+    want[24] = 1.0      # sigma <= 0: the delta kernel
+    assert np.array_equal(buf[:49], want) and np.array_equal(o, img)
+
+
+# ---- planning and the gfx950 code objects ---------------------------------------------------------------------------------------------
+def test_a_type_that_is_a_comp_file_plans_as_a_node_of_its_own(glsl_dir):
+    for t in ("gaussian5", "colour_grade", "sharpen"):
+        shutil.copy(os.path.join(SHADERS, t + ".comp"), glsl_dir / (t + ".comp"))
+    assert rf.Plan(rf.Config(util.CHAIN3)).launches() == ["blur", "grade", "sharp"]      # the FILES are the types (the reference's rule)
+    rf.set_type_lookup(False)
+    assert rf.Plan(rf.Config(util.CHAIN3)).launches() == ["blur+grade+sharp"]             # default: the hand-written kernels, fused
+    (glsl_dir / "wobble.comp").write_text(text_of("invert").replace("strength", "depth"))
+    p = rf.Plan(rf.Config("input -> ww -> output\nww: wobble { enabled: true, depth: 0.5 }"))      # a name the registry lacks: found as a file either way
+    assert p.launches() == ["ww"] and p.needs_jit() == [True]
+
+
+def test_storage_blocks_of_a_shader_are_wired_by_block_type_name(glsl_dir):
+    for t in ("conv2d", "conv2d_weights"):
+        shutil.copy(os.path.join(SHADERS, t + ".comp"), glsl_dir / (t + ".comp"))
+    p = rf.Plan(rf.Config("input -> kw -> cv -> output\nkw:ConvWeights -> cv:ConvWeights\nkw: conv2d_weights { ksize: 5, sigma: 1.0 }\ncv: conv2d { ksize: 5 }"))
+    assert p.buffers() == {"kw:ConvWeights": 961 * 4}
+    with pytest.raises(rf.RfError) as e:      # a block the shader only reads must be wired
+        rf.Plan(rf.Config("input -> cv -> output\ncv: conv2d { ksize: 5 }")).halo_schedule()
+    assert "needs a storage buffer wired to ConvWeights" in str(e.value)
+    with pytest.raises(rf.RfError) as e:      # ... and on the side the shader's qualifier allows
+        rf.Plan(rf.Config("input -> cv -> kw -> output\ncv:ConvWeights -> kw:ConvWeights\nkw: conv2d_weights { ksize: 5 }\ncv: conv2d { ksize: 5 }")).halo_schedule()
+    assert "ConvWeights is the buffer conv2d" in str(e.value) and "the graph wires it as an" in str(e.value)
+
+
+@pytest.mark.parametrize("t", COMP)
+def test_every_shipped_shader_compiles_for_gfx950(glsl_dir, t):
+    shutil.copy(os.path.join(SHADERS, t + ".comp"), glsl_dir / (t + ".comp"))
+    r = rf.glsl_reflect(t, text_of(t))
+    ins = [im["name"] for im in r["images"] if not im["writeonly"]]
+    outs = [im["name"] for im in r["images"] if not im["readonly"]]
+    lines = ["input -> nn:%s" % n for n in ins if n not in outs] + ["input -> nn:%s" % n for n in ins if n in outs]
+    lines += ["nn:%s -> output" % outs[0]]
+    for b in r["storage_blocks"]:
+        if b["readonly"]:
+            shutil.copy(os.path.join(SHADERS, "conv2d_weights.comp"), glsl_dir / "conv2d_weights.comp")
+            lines = ["input -> kw -> nn:%s" % ins[0], "kw:%s -> nn:%s" % (b["type_name"], b["type_name"]), "nn:%s -> output" % outs[0], "kw: conv2d_weights { ksize: 3 }"]
+    text = "\n".join(lines + ["nn: %s {}" % t])
+    p = rf.Plan(rf.Config(text))
+    assert p.jit_compile(rf.RF_FORMAT_RGBA32F) > 2048 and p.jit_compile(rf.RF_FORMAT_RGBA8) > 2048

@@ -279,11 +279,8 @@ kk: kitchen { gain: 1.5, shift: 3, flip: %s, mask: 5, bias: 0.25 }
 
 # ---- row strips: the launch split into interior and boundary rows (the geometry of the halo exchange, one GPU) ----------------------------
 def test_a_stencil_shader_split_into_row_ranges_gives_the_same_frame(ctx, glsl_dir, monkeypatch):
+    """both files state `#pragma rf radius 2`: the launch radius of a row-strip partition, and LDS tiles"""
     use(glsl_dir, "local_contrast", "gaussian5")
-    lc = (glsl_dir / "local_contrast.comp").read_text()
-    (glsl_dir / "local_contrast.comp").write_text(lc.replace("layout (local_size_x", "#pragma rf radius 2\nlayout (local_size_x", 1))
-    g5 = (glsl_dir / "gaussian5.comp").read_text()
-    (glsl_dir / "gaussian5.comp").write_text(g5.replace("#define RADIUS 2", "#define RADIUS 2\n#pragma rf radius 2", 1))
     text = "input -> gg -> lc -> output\ngg: gaussian5 { sigma: 1.0, %s }\nlc: local_contrast { amount: 0.8 }" % G5
     assert [l["radius"] for l in rf.Plan(rf.Config(text)).launch_info()] == [2, 2]
     img = util.synthetic(200, 90, util.F32)
