@@ -780,15 +780,16 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
          "    const uvec3 gl_WorkGroupSize = uvec3{" + std::to_string(out.lx) + "u, " + std::to_string(out.ly) + "u, " + std::to_string(out.lz) + "u};\n";
     s += tr.members;
     // readable images get a tile of the workgroup's neighbourhood in LDS when the file states its radius (rf_glsl_dev.h)
-    std::string tiles, read_list;
+    std::string tiles, read_list, beyond = "0ull";
     int n_read = 0;
     for (size_t i = 0; i < out.images.size(); ++i)
         if (!out.images[i].writeonly) {
-            tiles += "        " + out.images[i].name + ".set_tile(lds0 + " + std::to_string(n_read) + "u * bytes_each, tx0, ty0, tw, th);\n";
+            tiles += "        " + out.images[i].name + ".set_tile(lds0 + " + std::to_string(n_read) + "u * bytes_each, zero, tx0, ty0, tw, th);\n";
             read_list += (n_read ? ", " : "") + std::to_string(i);
+            beyond += " | " + out.images[i].name + ".beyond";
             ++n_read;
         }
-    s += "    typedef Px PxT;\n    RFG void rfg_tiles(unsigned lds0, unsigned bytes_each, int tx0, int ty0, int tw, int th)\n    {\n        (void)lds0; (void)bytes_each; (void)tx0; (void)ty0; (void)tw; (void)th;\n" + tiles + "    }\n";
+    s += "    typedef Px PxT;\n    RFG void rfg_tiles(unsigned lds0, unsigned bytes_each, unsigned zero, int tx0, int ty0, int tw, int th)\n    {\n        (void)lds0; (void)bytes_each; (void)zero; (void)tx0; (void)ty0; (void)tw; (void)th;\n" + tiles + "    }\n    RFG unsigned long long rfg_beyond() const { return " + beyond + "; }\n";
     s += "    RFG void rfg_bind(const GlslFrame& f, const GlslImage* img, void* const* buf, const unsigned char* ubo)\n    {\n        (void)f; (void)img; (void)buf; (void)ubo;\n" + tr.bind + "    }\n";
     s += "#line 1 \"" + type + ".comp\"\n";
     s += emit(tr.v, 0, tr.v.size());

@@ -304,7 +304,9 @@ template <class Px> struct image2D {
     // the workgroup's TILE of this image in LDS (kernel below; 0 = none): raw texels of frame columns [tx0, tx0 + tw) x rows [ty0, ty0 + th)
     unsigned lds = 0u;
     int tx0 = 0, ty0 = 0, tw = 0, th = 0;
-    RFG void set_tile(unsigned a, int x0, int y0, int w, int h) { lds = a; tx0 = x0; ty0 = y0; tw = w; th = h; }
+    unsigned lds_zero = 0u;       // LDS address of a zero texel (what a load outside the frame reads)
+    mutable unsigned long long beyond = 0ull; // lanes that did: set by a load inside the frame and outside the tile: the shader read further than its `#pragma rf radius` says
+    RFG void set_tile(unsigned a, unsigned zero, int x0, int y0, int w, int h) { lds = a; lds_zero = zero; tx0 = x0; ty0 = y0; tw = w; th = h; }
 };
 template <class Px> RFG ivec2 imageSize(const image2D<Px>& im) { return ivec2{im.W, im.H}; }
 // BRANCH-FREE: the coordinates are clamped into what may be read, the texel is loaded whatever they were, and a load outside
@@ -313,20 +315,27 @@ template <class Px> RFG ivec2 imageSize(const image2D<Px>& im) { return ivec2{im
 template <class Px> RFG vec4 imageLoad(const image2D<Px>& im, ivec2 p)
 {
     const vec4 zero = vec4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (!im.base) return zero;                                   // an image the graph does not wire (uniform: the same for every invocation)
+    // (a readable image is always wired: the planner refuses a graph that leaves one open, rf_plan.cpp -- no test of `base` here, a
+    // branch per load, even a uniform one, makes the loads of a filter wait for one another)
     const bool in_frame = (unsigned)p.x < (unsigned)im.W && p.y >= im.row_lo && p.y <= im.row_hi;
     typename Px::Raw raw;
 #ifdef RFGLSL_LDS_TILES
     if constexpr (Px::TILED) {
         const int rx = p.x - im.tx0, ry = p.y - im.ty0;
         const bool in_tile = (unsigned)rx < (unsigned)im.tw && (unsigned)ry < (unsigned)im.th;
-        const unsigned a = im.lds + (in_tile ? (unsigned)(ry * im.tw + rx) * (unsigned)sizeof(typename Px::Raw) : 0u);
+        // one LDS read at an address that is always valid: the texel's place in the tile, or -- outside the frame -- the zero texel
+        // the kernel keeps behind the tiles (so "a load outside the image returns zero" costs one select on the address, not four
+        // on the result); 24-bit multiply-add: one full-rate instruction (the operands are tile coordinates)
+        const unsigned at = im.lds + ((unsigned)__umul24((unsigned)ry, (unsigned)im.tw) + (unsigned)rx) * (unsigned)sizeof(typename Px::Raw);
+        const unsigned a = in_frame && in_tile ? at : im.lds_zero;
         raw = *reinterpret_cast<const __attribute__((address_space(3))) typename Px::Raw*>(a);
-        // a shader that reads further than its `#pragma rf radius` said: those texels come from memory.  One wave-wide test; never
-        // taken when the pragma is right.
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(in_frame && !in_tile) != 0ull, 0)) {
-            if (in_frame && !in_tile) raw = Px::load(im.base + (long long)p.y * (long long)im.pitch, (unsigned)p.x * (unsigned)Px::BPP);
-        }
+        // A shader that reads further than its `#pragma rf radius` said gets the zero texel here -- and the launch reports it: the
+        // flag ends up in the graph's status word and rf_graph_wait fails with the node's name (a fallback load under a branch of
+        // its own would make every one of the 25 or 81 loads of a filter wait for the one before it).  A wave-wide mask: scalar
+        // instructions only.
+        im.beyond |= __builtin_amdgcn_ballot_w64(in_frame && !in_tile);
+        const auto t = Px::decode(raw);
+        return vec4{t.x, t.y, t.z, t.w};
     } else
 #endif
     {
@@ -354,8 +363,8 @@ struct GlslFrame {
                               // the rows below it that the dispatch covers (y1 = groups_y * local_size_y): they exist in the reference too and
                               // may write storage blocks
     int groups_x, groups_y;   // the dispatch: ceil(W/16) x ceil(H/16) workgroups (command.rs:167-168) whatever local_size says
-    int row_origin;           // frame row of the images' local row 0
-    int pad;
+    unsigned* status;         // the graph's status word (host-visible): bit `status_bit` is set by a launch whose shader read beyond its stated radius
+    unsigned status_bit, pad;
 };
 
 }  // namespace rfglsl
@@ -396,10 +405,10 @@ template <class I> struct GlslArgs {
     unsigned char ubo[I::UBO > 0 ? (I::UBO + 7) / 8 * 8 : 8];
 };
 
-template <template <class> class SH, class P, class I>
+template <template <class> class SH, class P, class I, bool TILES>
 __global__ __launch_bounds__(I::GROUPED ? I::LX * I::LY * I::LZ : 256) void glsl_node_kernel(GlslArgs<I> A)
 {
-    constexpr bool kTiled = !I::GROUPED && I::TILED && rf::user_tile(P::BPP, I::RADIUS, I::NREAD).lds;
+    constexpr bool kTiled = TILES && !I::GROUPED && I::TILED && rf::user_tile(P::BPP, I::RADIUS, I::NREAD).lds;
     typedef SH<GPx<P, kTiled>> S;
     S s;
     uvec3 wg, lid;
@@ -422,6 +431,8 @@ __global__ __launch_bounds__(I::GROUPED ? I::LX * I::LY * I::LZ : 256) void glsl
         constexpr rf::UserTile kT = rf::user_tile(Px::BPP, I::RADIUS, I::NREAD);
         constexpr int R = I::RADIUS, RW = 64 + 2 * R, RH = kT.th + 2 * R;
         __shared__ __attribute__((aligned(16))) typename Px::Raw tile[I::NREAD][RH][RW];
+        __shared__ __attribute__((aligned(16))) typename Px::Raw zero_texel;
+        if (threadIdx.x == 0) __builtin_memset(&zero_texel, 0, sizeof(zero_texel));
         const unsigned tiles_x = ((unsigned)(A.f.groups_x * I::LX) + 63u) / 64u;
         const unsigned tiles_y = ((unsigned)(A.f.y1 - A.f.y0) + (unsigned)kT.th - 1u) / (unsigned)kT.th;
         const unsigned per_xcd = gridDim.x >> 3;
@@ -439,9 +450,11 @@ __global__ __launch_bounds__(I::GROUPED ? I::LX * I::LY * I::LZ : 256) void glsl
         __syncthreads();
         s.gl_NumWorkGroups = uvec3{(unsigned)A.f.groups_x, (unsigned)A.f.groups_y, 1u};
         s.rfg_bind(A.f, A.img, A.buf, A.ubo);
-        s.rfg_tiles((unsigned)(size_t)(__attribute__((address_space(3))) char*)(&tile[0][0][0]), (unsigned)(RW * RH * (int)sizeof(typename Px::Raw)), bx0 - R, by0 - R, RW, RH);
+        s.rfg_tiles((unsigned)(size_t)(__attribute__((address_space(3))) char*)(&tile[0][0][0]), (unsigned)(RW * RH * (int)sizeof(typename Px::Raw)),
+                    (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&zero_texel), bx0 - R, by0 - R, RW, RH);
         const unsigned gx = (unsigned)bx0 + (threadIdx.x & 63u);
         if (gx >= (unsigned)(A.f.groups_x * I::LX)) return;
+        unsigned long long beyond = 0ull;
 #pragma unroll 1
         for (int j = 0; j < kT.ty; ++j) {
             const unsigned gy = (unsigned)by0 + (threadIdx.x >> 6) * (unsigned)kT.ty + (unsigned)j;
@@ -452,7 +465,9 @@ __global__ __launch_bounds__(I::GROUPED ? I::LX * I::LY * I::LZ : 256) void glsl
             t.gl_GlobalInvocationID = uvec3{gx, gy, 0u};
             t.gl_LocalInvocationIndex = t.gl_LocalInvocationID.y * (unsigned)I::LX + t.gl_LocalInvocationID.x;
             t.main();
+            beyond |= t.rfg_beyond();
         }
+        if (beyond != 0ull && A.f.status) atomicOr(A.f.status, 1u << (A.f.status_bit & 31u));
         return;
     } else {
         // the same invocations -- x < groups_x * LX, y < groups_y * LY -- in tiles of 64 x 4, every XCD a contiguous range of tiles in

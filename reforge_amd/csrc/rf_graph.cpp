@@ -198,8 +198,8 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
 {
     const Op& op = L.ops[0];
     const int y_org = g->strip_y0;
-    struct Frame { int W, H, row_lo, row_hi, y0, y1, groups_x, groups_y, row_origin, pad; } fr;
-    static_assert(sizeof(Frame) == 40, "GlslFrame of rf_glsl_dev.h");
+    struct Frame { int W, H, row_lo, row_hi, y0, y1, groups_x, groups_y; unsigned* status; unsigned status_bit, pad; } fr;
+    static_assert(sizeof(Frame) == 48, "GlslFrame of rf_glsl_dev.h");
     fr.W = geo.W;
     fr.H = g->opt.height;
     fr.row_lo = geo.row_lo + y_org;
@@ -208,7 +208,8 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     fr.y1 = geo.y1 + y_org;
     fr.groups_x = (fr.W + 15) / 16;
     fr.groups_y = (fr.H + 15) / 16;
-    fr.row_origin = y_org;
+    fr.status = g->glsl_status_dev;
+    fr.status_bit = (unsigned)(&L - g->launches.data()) & 31u;
     fr.pad = 0;
     // the launch that runs the frame's last row also runs the invocations below it that the dispatch covers (they exist in the
     // reference; their image accesses fall outside the frame and are dropped, their storage-block writes are not)
@@ -227,6 +228,7 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
                 auto at = std::find(u->inputs.begin(), u->inputs.end(), u->glsl_images[i]);
                 if (at != u->inputs.end() && (size_t)(at - u->inputs.begin()) < L.src.size()) di = &f.images.at(L.src[(size_t)(at - u->inputs.begin())]);
             }
+            if (!di && std::find(u->inputs.begin(), u->inputs.end(), u->glsl_images[i]) != u->inputs.end()) return hipErrorInvalidValue;      // a readable image is always wired (build_launches)
             if (di) {      // address of FRAME row 0 (an address this rank may not own: the shader's loads and stores are bounded by row_lo .. row_hi)
                 im.base = di->base - (ptrdiff_t)y_org * (ptrdiff_t)di->pitch;
                 im.pitch = di->pitch;
@@ -263,7 +265,7 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
         return jit_launch(*k, (unsigned)fr.groups_x * (unsigned)fr.groups_y, threads, args.data(), args.size(), stream);
     }
     const UserTile tile = user_tile((int)bytes_per_pixel(g->opt.format), u->radius, u->glsl_reads);
-    if (u->glsl_tiled && tile.lds) {      // 64 x TH invocations per workgroup, their neighbourhood staged in LDS (rf_glsl_dev.h)
+    if (u->glsl_tiled && tile.lds && glsl_tiles_enabled()) {      // 64 x TH invocations per workgroup, their neighbourhood staged in LDS (rf_glsl_dev.h)
         const unsigned long tx = ((unsigned)(fr.groups_x * u->glsl_groups[0]) + 63u) / 64u, ty = ((unsigned)(fr.y1 - fr.y0) + (unsigned)tile.th - 1u) / (unsigned)tile.th;
         return jit_launch(*k, (unsigned)((tx * ty + 7) / 8 * 8), 256, args.data(), args.size(), stream);
     }
@@ -787,6 +789,12 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
             if (ctx->world > 1 && !u->radius_stated)
                 return fail(RF_ERR_UNSUPPORTED, "node '" + L.label + "': " + u->file_name() + " does not say `#pragma rf radius N` (rows an invocation reads above / below its own); "
                                                 "without it the node cannot be split into row strips");
+            if (u->glsl_tiled && !g->glsl_status) {
+                // a word the kernels can reach and the host can read without a copy: a launch whose shader read beyond its stated radius sets its bit
+                HIP_TRY(hipHostMalloc((void**)&g->glsl_status, sizeof(unsigned), hipHostMallocMapped));
+                *g->glsl_status = 0u;
+                HIP_TRY(hipHostGetDevicePointer((void**)&g->glsl_status_dev, g->glsl_status, 0));
+            }
             // the blocks it declares and the graph leaves unwired: the shader writes them all the same
             for (const auto* list : {&u->buf_in, &u->buf_out})
                 for (const auto& b : *list) {
@@ -904,6 +912,7 @@ extern "C" void rf_graph_destroy(rf_graph* g)
     }
     for (auto& kv : g->dev_weights) (void)hipFree(kv.second);
     for (auto& kv : g->dev_buffers) (void)hipFree(kv.second);
+    if (g->glsl_status) (void)hipHostFree(g->glsl_status);
     if (g->buffers_idle) (void)hipEventDestroy(g->buffers_idle);
     if (g->d_staging) (void)hipFree(g->d_staging);
     delete g;
@@ -1179,6 +1188,18 @@ extern "C" rf_status rf_graph_wait(rf_graph* g, int frame_slot)
     rf_status st = slot_of(g, frame_slot, &f, "rf_graph_wait");
     if (st != RF_OK) return st;
     HIP_TRY(hipStreamSynchronize(f->stream));
+    if (g->glsl_status && *g->glsl_status != 0u) {
+        // a .comp node whose shader read further than its `#pragma rf radius N` says (rf_glsl_dev.h: those loads got a wrong texel)
+        const unsigned bits = *g->glsl_status;
+        *g->glsl_status = 0u;
+        std::string who;
+        for (size_t i = 0; i < g->launches.size(); ++i)
+            if ((bits >> (i & 31u)) & 1u) {
+                const UserStage* u = g->launches[i].ops.size() == 1 && g->launches[i].ops[0].kind == OP_USERN ? user_stage_by_id(g->launches[i].ops[0].user_id) : nullptr;
+                if (u && u->glsl_tiled) who += (who.empty() ? "'" : ", '") + g->launches[i].label + "' (" + u->file_name() + ", radius " + std::to_string(u->radius) + ")";
+            }
+        return fail(RF_ERR_GRAPH, "node " + who + " read texels further from its invocation than its `#pragma rf radius` states: the frame is wrong; correct the pragma");
+    }
     return RF_OK;
 }
 

@@ -34,9 +34,12 @@ for f in os.listdir(os.path.join(ROOT, "shaders")):
         shutil.copy(os.path.join(ROOT, "shaders", f), d)
 open(os.path.join(d, "passthrough.comp"), "w").write(PASSTHROUGH)
 rf.set_shader_path(d)
+ONLY = sys.argv[1:]
 for fmt, fname, bpp in ((util.F32, "rgba32f", 16), (util.U8, "rgba8", 4)):
     for name, types, text, images in CASES:
-        row = {"type": name, "fmt": fname}
+        if ONLY and name not in ONLY:
+            continue
+        row = {"type": name, "fmt": fname, "tiles": os.environ.get("RF_GLSL_TILES", "1")}
         for mode in ("glsl", "built_in"):
             rf.set_type_lookup(mode == "glsl")
             g = rf.Graph(ctx, rf.Config(text), W, H, fmt)
