@@ -101,7 +101,38 @@ WORKLOADS["user_types_4k"] = dict(text=USER_TYPES_4K, W=3840, H=2160, fmt=F32, n
 # a user type that reads a NEIGHBOURHOOD (RADIUS 2, Window::at): the LDS-tiled kernel of rf_user_dev.h
 WORKLOADS["user_window_4k"] = dict(text="input -> lc -> output\nlc: local_contrast { amount: 0.8 }", W=3840, H=2160, fmt=F32, nodes=1, seed=0x5EED0008, radius=2, strong=False,
                                    user_types=("local_contrast",), desc="user filter type reading a 5x5 window (local_contrast.stage.hip, LDS-tiled kernel), 3840x2160 rgba32f")
-SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "chain3_8k_u8", "gauss9_8k_u8", "diamond_4k", "user_types_4k", "user_window_4k"]
+# filter types in the REFERENCE'S OWN FILE FORM: the headline graph with every type taken from shaders/*.comp (GLSL 450 compute, translated
+# by rf_glsl.cpp, compiled by hiprtc at graph creation, one launch per node as in the reference: command.rs:194) -- what a reforge user's
+# shader directory costs when it is run as it is.  The gaussian's weights are given (w0..w2): GLSL exp() is not the host's.
+GLSL_CHAIN3 = CHAIN3.replace("sigma: 1.0 }", "sigma: 1.0, w0: 0.402619958, w1: 0.244201347, w2: 0.0544886850 }")
+WORKLOADS["glsl_chain3_4k"] = dict(text=GLSL_CHAIN3, W=3840, H=2160, fmt=F32, nodes=3, seed=0x5EED0009, radius=3, strong=False, files_first=True,
+                                   desc="the headline graph run from the GLSL files (shaders/gaussian5.comp, colour_grade.comp, sharpen.comp), 3840x2160 rgba32f")
+# a point filter from its GLSL file (two images in, two out): the plugin path at its best
+WORKLOADS["glsl_unsharp_4k"] = dict(text="input -> bl -> um:blurred_image\ninput -> um:input_image\num -> output\nbl: passthrough {}\num: unsharp_mask { amount: 1.5, threshold: 0.02 }",
+                                    W=3840, H=2160, fmt=F32, nodes=2, seed=0x5EED000A, radius=0, strong=False, files_first=True, glsl_only=("unsharp_mask",), user_types=("unsharp_mask",),
+                                    desc="unsharp_mask from shaders/unsharp_mask.comp (GLSL; two input images, one wired output), 3840x2160 rgba32f")
+SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "chain3_8k_u8", "gauss9_8k_u8", "diamond_4k", "user_types_4k", "user_window_4k", "glsl_chain3_4k", "glsl_unsharp_4k"]
+
+
+def shader_setup(rf, wl, oracle_too):
+    """{shader_path} and the type lookup a workload wants; with oracle_too the checker compiles the user types' stage files for the host
+    (oracle/user_stage.py).  A workload that takes its types from .comp files gets a directory that holds ONLY the .comp files (shaders/
+    also holds .stage.hip twins, which would win)."""
+    rf.set_type_lookup(bool(wl.get("files_first")))
+    if wl.get("files_first"):
+        import shutil
+        import tempfile
+        d = tempfile.mkdtemp(prefix="rf_glsl_")
+        for f in os.listdir(os.path.join(ROOT, "shaders")):
+            if f.endswith(".comp") and (not wl.get("glsl_only") or f[:-5] in wl["glsl_only"]):
+                shutil.copy(os.path.join(ROOT, "shaders", f), d)
+        rf.set_shader_path(d)
+    elif wl.get("user_types"):
+        rf.set_shader_path(os.path.join(ROOT, "shaders"))
+    if wl.get("user_types") and oracle_too:
+        from oracle import graph as ograph
+        for t in wl["user_types"]:
+            ograph.register_user_type(t, os.path.join(ROOT, "shaders", t + ".stage.hip"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak (spec)
 NO_POWER = False               # --no-power
@@ -421,13 +452,7 @@ def side_workload(rf, ctx, name, verify=True):
     stream, the dominant launch priced against its roofline, the result band-checked."""
     wl = WORKLOADS[name]
     out = {"workload": wl["desc"]}
-    if wl.get("user_types"):
-        # {shader_path} = shaders/ for the library; the checker compiles the same files for the host (oracle/user_stage.py)
-        rf.set_shader_path(os.path.join(ROOT, "shaders"))
-        if verify:
-            from oracle import graph as ograph
-            for t in wl["user_types"]:
-                ograph.register_user_type(t, os.path.join(ROOT, "shaders", t + ".stage.hip"))
+    shader_setup(rf, wl, verify)
     variants = CONV_PATHS if name == "conv31_8k" else (("", 0),)
     copy_ms = None if name == "conv31_8k" else stream_copy_ms(rf, ctx, wl["W"], wl["H"], wl["fmt"])      # before the graph: same blocks
     for vname, path in variants:
@@ -462,6 +487,7 @@ def side_workload(rf, ctx, name, verify=True):
             out[vname] = res
         else:
             out.update(res)
+    rf.set_type_lookup(False)
     if name == "conv31_8k":
         best = max((v for v, _ in CONV_PATHS), key=lambda v: out[v]["roofline"]["frac"])
         out["best"] = best
@@ -578,12 +604,7 @@ def main():
         torch.cuda.synchronize()
 
     wl = WORKLOADS[args.workload]
-    if wl.get("user_types"):
-        rf.set_shader_path(os.path.join(ROOT, "shaders"))
-        if not args.skip_cpu_baseline:
-            from oracle import graph as ograph
-            for t in wl["user_types"]:
-                ograph.register_user_type(t, os.path.join(ROOT, "shaders", t + ".stage.hip"))
+    shader_setup(rf, wl, not args.skip_cpu_baseline)
     text, W, Hper, fmt, n_nodes, seed, strong = wl["text"], wl["W"], wl["H"], wl["fmt"], wl["nodes"], wl["seed"], wl["strong"]
     H = Hper if (strong or world == 1) else Hper * world
     bpp = bpp_of(fmt)

@@ -667,7 +667,7 @@ struct Translator {
                     for (const auto& o : sh.images)
                         if (o.name == im.name) fail(v[k].line, "the image variable " + im.name + " is declared twice");
                     members += "    image2D<Px> " + im.name + ";\n";
-                    bind += "        " + im.name + " = image2D<Px>{img[" + std::to_string(sh.images.size()) + "].base, img[" + std::to_string(sh.images.size()) + "].pitch, f.W, f.H, f.row_lo, f.row_hi, f.y0, f.y1 - 1};\n";
+                    bind += "        " + im.name + " = image2D<Px>{img[" + std::to_string(sh.images.size()) + "].base, img[" + std::to_string(sh.images.size()) + "].pitch, f.W, f.H, f.row_lo, f.row_hi, f.y0, f.y1 - 1, f.zero};\n";
                     sh.images.push_back(im);
                     blank(v, first, k + 2);
                     i = k + 2;
@@ -779,17 +779,9 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
          "    uint gl_LocalInvocationIndex;\n"
          "    const uvec3 gl_WorkGroupSize = uvec3{" + std::to_string(out.lx) + "u, " + std::to_string(out.ly) + "u, " + std::to_string(out.lz) + "u};\n";
     s += tr.members;
-    // readable images get a tile of the workgroup's neighbourhood in LDS when the file states its radius (rf_glsl_dev.h)
-    std::string tiles, read_list, beyond = "0ull";
     int n_read = 0;
-    for (size_t i = 0; i < out.images.size(); ++i)
-        if (!out.images[i].writeonly) {
-            tiles += "        " + out.images[i].name + ".set_tile(lds0 + " + std::to_string(n_read) + "u * bytes_each, zero, tx0, ty0, tw, th);\n";
-            read_list += (n_read ? ", " : "") + std::to_string(i);
-            beyond += " | " + out.images[i].name + ".beyond";
-            ++n_read;
-        }
-    s += "    typedef Px PxT;\n    RFG void rfg_tiles(unsigned lds0, unsigned bytes_each, unsigned zero, int tx0, int ty0, int tw, int th)\n    {\n        (void)lds0; (void)bytes_each; (void)zero; (void)tx0; (void)ty0; (void)tw; (void)th;\n" + tiles + "    }\n    RFG unsigned long long rfg_beyond() const { return " + beyond + "; }\n";
+    for (const auto& im : out.images) n_read += im.writeonly ? 0 : 1;
+    s += "    typedef Px PxT;\n";
     s += "    RFG void rfg_bind(const GlslFrame& f, const GlslImage* img, void* const* buf, const unsigned char* ubo)\n    {\n        (void)f; (void)img; (void)buf; (void)ubo;\n" + tr.bind + "    }\n";
     s += "#line 1 \"" + type + ".comp\"\n";
     s += emit(tr.v, 0, tr.v.size());
@@ -797,8 +789,7 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
     for (const auto& m : tr.cx.macros) s += "#undef " + m + "\n";
     s += "struct Info {\n    static constexpr int LX = " + std::to_string(out.lx) + ", LY = " + std::to_string(out.ly) + ", LZ = " + std::to_string(out.lz) + ", NIMG = " + std::to_string(out.images.size()) +
          ", NBUF = " + std::to_string(out.ssbos.size()) + ", UBO = " + std::to_string(out.ubo_bytes) + ", RADIUS = " + std::to_string(out.radius < 0 ? 0 : out.radius) + ", NREAD = " + std::to_string(n_read) + ";\n    static constexpr bool GROUPED = " +
-         (out.grouped ? "true" : "false") + ", TILED = " + (!out.grouped && out.radius >= 1 && out.radius <= 15 && n_read >= 1 ? "true" : "false") + ";\n    static constexpr int READ[" + std::to_string(n_read > 0 ? n_read : 1) + "] = {" +
-         (n_read ? read_list : std::string("0")) + "};\n};\n} }\n";
+         (out.grouped ? "true" : "false") + ";\n};\n} }\n";
     out.source = s;
     return true;
 }

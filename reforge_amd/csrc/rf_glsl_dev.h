@@ -21,7 +21,6 @@
 
 #if defined(__HIPCC_RTC__) || defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 #define RFG __device__ __forceinline__
-#define RFGLSL_LDS_TILES 1
 #else
 #include <math.h>
 #include <string.h>
@@ -301,12 +300,7 @@ template <class Px> struct image2D {
     unsigned long long pitch;
     int W, H, row_lo, row_hi;     // frame size; frame rows this rank may read
     int wr_lo, wr_hi;             // frame rows this LAUNCH writes, inclusive (the whole frame on one GPU; a strip's rows, or one part of a split launch)
-    // the workgroup's TILE of this image in LDS (kernel below; 0 = none): raw texels of frame columns [tx0, tx0 + tw) x rows [ty0, ty0 + th)
-    unsigned lds = 0u;
-    int tx0 = 0, ty0 = 0, tw = 0, th = 0;
-    unsigned lds_zero = 0u;       // LDS address of a zero texel (what a load outside the frame reads)
-    mutable unsigned long long beyond = 0ull; // lanes that did: set by a load inside the frame and outside the tile: the shader read further than its `#pragma rf radius` says
-    RFG void set_tile(unsigned a, unsigned zero, int x0, int y0, int w, int h) { lds = a; lds_zero = zero; tx0 = x0; ty0 = y0; tw = w; th = h; }
+    const char* zero;             // 16 zero bytes: what a load outside the image reads
 };
 template <class Px> RFG ivec2 imageSize(const image2D<Px>& im) { return ivec2{im.W, im.H}; }
 // BRANCH-FREE: the coordinates are clamped into what may be read, the texel is loaded whatever they were, and a load outside
@@ -314,36 +308,14 @@ template <class Px> RFG ivec2 imageSize(const image2D<Px>& im) { return ivec2{im
 // is waited for before the next one is issued (the compiler cannot move a load across the branch that guards it).
 template <class Px> RFG vec4 imageLoad(const image2D<Px>& im, ivec2 p)
 {
-    const vec4 zero = vec4{0.0f, 0.0f, 0.0f, 0.0f};
-    // (a readable image is always wired: the planner refuses a graph that leaves one open, rf_plan.cpp -- no test of `base` here, a
+    // (a readable image is always wired: the planner refuses a graph that leaves one open, rf_plan.cpp -- no test of `base` here: a
     // branch per load, even a uniform one, makes the loads of a filter wait for one another)
-    const bool in_frame = (unsigned)p.x < (unsigned)im.W && p.y >= im.row_lo && p.y <= im.row_hi;
-    typename Px::Raw raw;
-#ifdef RFGLSL_LDS_TILES
-    if constexpr (Px::TILED) {
-        const int rx = p.x - im.tx0, ry = p.y - im.ty0;
-        const bool in_tile = (unsigned)rx < (unsigned)im.tw && (unsigned)ry < (unsigned)im.th;
-        // one LDS read at an address that is always valid: the texel's place in the tile, or -- outside the frame -- the zero texel
-        // the kernel keeps behind the tiles (so "a load outside the image returns zero" costs one select on the address, not four
-        // on the result); 24-bit multiply-add: one full-rate instruction (the operands are tile coordinates)
-        const unsigned at = im.lds + ((unsigned)__umul24((unsigned)ry, (unsigned)im.tw) + (unsigned)rx) * (unsigned)sizeof(typename Px::Raw);
-        const unsigned a = in_frame && in_tile ? at : im.lds_zero;
-        raw = *reinterpret_cast<const __attribute__((address_space(3))) typename Px::Raw*>(a);
-        // A shader that reads further than its `#pragma rf radius` said gets the zero texel here -- and the launch reports it: the
-        // flag ends up in the graph's status word and rf_graph_wait fails with the node's name (a fallback load under a branch of
-        // its own would make every one of the 25 or 81 loads of a filter wait for the one before it).  A wave-wide mask: scalar
-        // instructions only.
-        im.beyond |= __builtin_amdgcn_ballot_w64(in_frame && !in_tile);
-        const auto t = Px::decode(raw);
-        return vec4{t.x, t.y, t.z, t.w};
-    } else
-#endif
-    {
-        const int xx = p.x < 0 ? 0 : (p.x > im.W - 1 ? im.W - 1 : p.x), yy = p.y < im.row_lo ? im.row_lo : (p.y > im.row_hi ? im.row_hi : p.y);
-        raw = Px::load(im.base + (long long)yy * (long long)im.pitch, (unsigned)xx * (unsigned)Px::BPP);
-    }
-    const auto t = Px::decode(raw);
-    return in_frame ? vec4{t.x, t.y, t.z, t.w} : zero;
+    const bool in_frame = (unsigned)p.x < (unsigned)im.W && (unsigned)(p.y - im.row_lo) <= (unsigned)(im.row_hi - im.row_lo);
+    // rows are frame rows (>= 0 wherever they may be read) and a pitch is below 4 GiB: one 32 x 32 -> 64 bit multiply-add.  A load
+    // outside the image reads the zero texel the graph keeps for that (one select on the address; no clamps, no select on the result)
+    const char* at = im.base + ((unsigned long long)(unsigned)p.y * (unsigned long long)(unsigned)im.pitch + (unsigned long long)((unsigned)p.x * (unsigned)Px::BPP));
+    const auto t = Px::decode(Px::load(in_frame ? at : im.zero, 0u));
+    return vec4{t.x, t.y, t.z, t.w};
 }
 template <class Px> RFG void imageStore(const image2D<Px>& im, ivec2 p, vec4 v)
 {
@@ -363,8 +335,8 @@ struct GlslFrame {
                               // the rows below it that the dispatch covers (y1 = groups_y * local_size_y): they exist in the reference too and
                               // may write storage blocks
     int groups_x, groups_y;   // the dispatch: ceil(W/16) x ceil(H/16) workgroups (command.rs:167-168) whatever local_size says
-    unsigned* status;         // the graph's status word (host-visible): bit `status_bit` is set by a launch whose shader read beyond its stated radius
-    unsigned status_bit, pad;
+    const char* zero;         // 16 zero bytes in device memory (what imageLoad outside an image reads)
+    int pad[2];
 };
 
 }  // namespace rfglsl
@@ -375,12 +347,9 @@ struct GlslFrame {
 namespace rfglsl {
 
 // Texel formats with the constructor imageStore needs (rf_device.h)
-template <class P, bool T> struct GPx : P {
-    static constexpr bool TILED = T;      // the readable images have a tile of the workgroup's neighbourhood in LDS
+template <class P> struct GPx : P {      // the texel formats of rf_device.h with the constructor imageStore needs
     RFG static rf::f4 texel(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
 };
-typedef GPx<rf::PxF32, false> GPxF32;
-typedef GPx<rf::PxU8, false> GPxU8;
 
 RFG void barrier() { __syncthreads(); }
 RFG void memoryBarrier() { __threadfence(); }
@@ -405,11 +374,10 @@ template <class I> struct GlslArgs {
     unsigned char ubo[I::UBO > 0 ? (I::UBO + 7) / 8 * 8 : 8];
 };
 
-template <template <class> class SH, class P, class I, bool TILES>
+template <template <class> class SH, class P, class I>
 __global__ __launch_bounds__(I::GROUPED ? I::LX * I::LY * I::LZ : 256) void glsl_node_kernel(GlslArgs<I> A)
 {
-    constexpr bool kTiled = TILES && !I::GROUPED && I::TILED && rf::user_tile(P::BPP, I::RADIUS, I::NREAD).lds;
-    typedef SH<GPx<P, kTiled>> S;
+    typedef SH<GPx<P>> S;
     S s;
     uvec3 wg, lid;
     if constexpr (I::GROUPED) {
@@ -421,54 +389,6 @@ __global__ __launch_bounds__(I::GROUPED ? I::LX * I::LY * I::LZ : 256) void glsl
         // a strip: workgroups none of whose rows this launch writes do not run (a workgroup-uniform decision)
         const int gy0 = (int)wg.y * I::LY;
         if (gy0 + I::LY <= A.f.y0 || gy0 >= A.f.y1) return;
-    } else if constexpr (kTiled) {
-        // The file states how far an invocation reads (#pragma rf radius R): a workgroup computes a 64 x TH block of invocations
-        // (256 threads = 64 columns x 4 thread rows, TY = TH / 4 invocations each) and first stages the (64 + 2R) x (TH + 2R)
-        // texels of every readable image around it in LDS -- the 16 x 16 tile with halo of a classic stencil shader, wave-64 wide.
-        // imageLoad inside the tile is an LDS read; outside it (a shader that reads further than it said) it goes to memory, so the
-        // pragma can only be wrong about speed -- and about row strips, which is what it is for.
-        typedef typename S::PxT Px;
-        constexpr rf::UserTile kT = rf::user_tile(Px::BPP, I::RADIUS, I::NREAD);
-        constexpr int R = I::RADIUS, RW = 64 + 2 * R, RH = kT.th + 2 * R;
-        __shared__ __attribute__((aligned(16))) typename Px::Raw tile[I::NREAD][RH][RW];
-        __shared__ __attribute__((aligned(16))) typename Px::Raw zero_texel;
-        if (threadIdx.x == 0) __builtin_memset(&zero_texel, 0, sizeof(zero_texel));
-        const unsigned tiles_x = ((unsigned)(A.f.groups_x * I::LX) + 63u) / 64u;
-        const unsigned tiles_y = ((unsigned)(A.f.y1 - A.f.y0) + (unsigned)kT.th - 1u) / (unsigned)kT.th;
-        const unsigned per_xcd = gridDim.x >> 3;
-        const unsigned q = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-        if (q >= tiles_x * tiles_y) return;                                   // workgroup-uniform: in front of the barrier
-        const int bx0 = (int)(q % tiles_x) * 64, by0 = A.f.y0 + (int)(q / tiles_x) * kT.th;
-        for (int i = (int)threadIdx.x; i < RW * RH; i += 256) {
-            const int r = i / RW, c = i - r * RW;
-            const int gx = bx0 - R + c, gy = by0 - R + r;
-            if ((unsigned)gx >= (unsigned)A.f.W || gy < A.f.row_lo || gy > A.f.row_hi) continue;      // never read through the tile: imageLoad checks the frame first
-#pragma unroll
-            for (int k = 0; k < I::NREAD; ++k)
-                if (A.img[I::READ[k]].base) tile[k][r][c] = Px::load(A.img[I::READ[k]].base + (long long)gy * (long long)A.img[I::READ[k]].pitch, (unsigned)gx * (unsigned)Px::BPP);
-        }
-        __syncthreads();
-        s.gl_NumWorkGroups = uvec3{(unsigned)A.f.groups_x, (unsigned)A.f.groups_y, 1u};
-        s.rfg_bind(A.f, A.img, A.buf, A.ubo);
-        s.rfg_tiles((unsigned)(size_t)(__attribute__((address_space(3))) char*)(&tile[0][0][0]), (unsigned)(RW * RH * (int)sizeof(typename Px::Raw)),
-                    (unsigned)(size_t)(__attribute__((address_space(3))) char*)(&zero_texel), bx0 - R, by0 - R, RW, RH);
-        const unsigned gx = (unsigned)bx0 + (threadIdx.x & 63u);
-        if (gx >= (unsigned)(A.f.groups_x * I::LX)) return;
-        unsigned long long beyond = 0ull;
-#pragma unroll 1
-        for (int j = 0; j < kT.ty; ++j) {
-            const unsigned gy = (unsigned)by0 + (threadIdx.x >> 6) * (unsigned)kT.ty + (unsigned)j;
-            if ((int)gy >= A.f.y1) break;
-            S t(s);      // a fresh invocation: the file's global variables start from their initialisers every time
-            t.gl_WorkGroupID = uvec3{gx / (unsigned)I::LX, gy / (unsigned)I::LY, 0u};
-            t.gl_LocalInvocationID = uvec3{gx % (unsigned)I::LX, gy % (unsigned)I::LY, 0u};
-            t.gl_GlobalInvocationID = uvec3{gx, gy, 0u};
-            t.gl_LocalInvocationIndex = t.gl_LocalInvocationID.y * (unsigned)I::LX + t.gl_LocalInvocationID.x;
-            t.main();
-            beyond |= t.rfg_beyond();
-        }
-        if (beyond != 0ull && A.f.status) atomicOr(A.f.status, 1u << (A.f.status_bit & 31u));
-        return;
     } else {
         // the same invocations -- x < groups_x * LX, y < groups_y * LY -- in tiles of 64 x 4, every XCD a contiguous range of tiles in
         // raster order (workgroups are dealt round-robin over the 8 XCDs)

@@ -187,6 +187,8 @@ rf_status exchange_rows(rf_graph* g, const DeviceImage& img, int r, hipStream_t 
 
 bool exchange_mode(const rf_graph* g) { return g->ctx->world > 1 && !(g->opt.flags & RF_GRAPH_NO_HALO_XCHG); }
 
+// 16 zero bytes every .comp launch of a graph can point at: what an imageLoad outside an image reads (rf_glsl_dev.h)
+static const char kGlslZeroTexel[] = "\x01glsl:zero-texel";
 // name of the scratch block behind a storage buffer a .comp node declares and the graph leaves unwired (the shader writes it
 // whether anybody reads it or not): allocated with the graph's other buffers
 static std::string unwired_buffer_name(const std::string& label, const std::string& block) { return "\x01unwired:" + label + ":" + block; }
@@ -198,7 +200,7 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
 {
     const Op& op = L.ops[0];
     const int y_org = g->strip_y0;
-    struct Frame { int W, H, row_lo, row_hi, y0, y1, groups_x, groups_y; unsigned* status; unsigned status_bit, pad; } fr;
+    struct Frame { int W, H, row_lo, row_hi, y0, y1, groups_x, groups_y; const char* zero; int pad[2]; } fr;
     static_assert(sizeof(Frame) == 48, "GlslFrame of rf_glsl_dev.h");
     fr.W = geo.W;
     fr.H = g->opt.height;
@@ -208,9 +210,12 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     fr.y1 = geo.y1 + y_org;
     fr.groups_x = (fr.W + 15) / 16;
     fr.groups_y = (fr.H + 15) / 16;
-    fr.status = g->glsl_status_dev;
-    fr.status_bit = (unsigned)(&L - g->launches.data()) & 31u;
-    fr.pad = 0;
+    fr.pad[0] = fr.pad[1] = 0;
+    {
+        auto z = g->dev_buffers.find(kGlslZeroTexel);
+        if (z == g->dev_buffers.end()) return hipErrorInvalidValue;
+        fr.zero = reinterpret_cast<const char*>(z->second);
+    }
     // the launch that runs the frame's last row also runs the invocations below it that the dispatch covers (they exist in the
     // reference; their image accesses fall outside the frame and are dropped, their storage-block writes are not)
     if (fr.y1 == fr.H) fr.y1 = std::max(fr.H, fr.groups_y * u->glsl_groups[1]);
@@ -263,11 +268,6 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     if (u->glsl_grouped) {
         const unsigned threads = (unsigned)(u->glsl_groups[0] * u->glsl_groups[1] * u->glsl_groups[2]);
         return jit_launch(*k, (unsigned)fr.groups_x * (unsigned)fr.groups_y, threads, args.data(), args.size(), stream);
-    }
-    const UserTile tile = user_tile((int)bytes_per_pixel(g->opt.format), u->radius, u->glsl_reads);
-    if (u->glsl_tiled && tile.lds && glsl_tiles_enabled()) {      // 64 x TH invocations per workgroup, their neighbourhood staged in LDS (rf_glsl_dev.h)
-        const unsigned long tx = ((unsigned)(fr.groups_x * u->glsl_groups[0]) + 63u) / 64u, ty = ((unsigned)(fr.y1 - fr.y0) + (unsigned)tile.th - 1u) / (unsigned)tile.th;
-        return jit_launch(*k, (unsigned)((tx * ty + 7) / 8 * 8), 256, args.data(), args.size(), stream);
     }
     // 64 x 4 invocations per workgroup over x < groups_x * LX, the rows of this launch (the kernel aligns the first to 4)
     const unsigned tiles_x = ((unsigned)(fr.groups_x * u->glsl_groups[0]) + 63u) / 64u;
@@ -789,11 +789,11 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
             if (ctx->world > 1 && !u->radius_stated)
                 return fail(RF_ERR_UNSUPPORTED, "node '" + L.label + "': " + u->file_name() + " does not say `#pragma rf radius N` (rows an invocation reads above / below its own); "
                                                 "without it the node cannot be split into row strips");
-            if (u->glsl_tiled && !g->glsl_status) {
-                // a word the kernels can reach and the host can read without a copy: a launch whose shader read beyond its stated radius sets its bit
-                HIP_TRY(hipHostMalloc((void**)&g->glsl_status, sizeof(unsigned), hipHostMallocMapped));
-                *g->glsl_status = 0u;
-                HIP_TRY(hipHostGetDevicePointer((void**)&g->glsl_status_dev, g->glsl_status, 0));
+            if (!g->dev_buffers.count(kGlslZeroTexel)) {
+                float* z = nullptr;
+                HIP_TRY(hipMalloc((void**)&z, 16));
+                g->dev_buffers[kGlslZeroTexel] = z;
+                HIP_TRY(hipMemset(z, 0, 16));
             }
             // the blocks it declares and the graph leaves unwired: the shader writes them all the same
             for (const auto* list : {&u->buf_in, &u->buf_out})
@@ -912,7 +912,6 @@ extern "C" void rf_graph_destroy(rf_graph* g)
     }
     for (auto& kv : g->dev_weights) (void)hipFree(kv.second);
     for (auto& kv : g->dev_buffers) (void)hipFree(kv.second);
-    if (g->glsl_status) (void)hipHostFree(g->glsl_status);
     if (g->buffers_idle) (void)hipEventDestroy(g->buffers_idle);
     if (g->d_staging) (void)hipFree(g->d_staging);
     delete g;
@@ -1188,18 +1187,6 @@ extern "C" rf_status rf_graph_wait(rf_graph* g, int frame_slot)
     rf_status st = slot_of(g, frame_slot, &f, "rf_graph_wait");
     if (st != RF_OK) return st;
     HIP_TRY(hipStreamSynchronize(f->stream));
-    if (g->glsl_status && *g->glsl_status != 0u) {
-        // a .comp node whose shader read further than its `#pragma rf radius N` says (rf_glsl_dev.h: those loads got a wrong texel)
-        const unsigned bits = *g->glsl_status;
-        *g->glsl_status = 0u;
-        std::string who;
-        for (size_t i = 0; i < g->launches.size(); ++i)
-            if ((bits >> (i & 31u)) & 1u) {
-                const UserStage* u = g->launches[i].ops.size() == 1 && g->launches[i].ops[0].kind == OP_USERN ? user_stage_by_id(g->launches[i].ops[0].user_id) : nullptr;
-                if (u && u->glsl_tiled) who += (who.empty() ? "'" : ", '") + g->launches[i].label + "' (" + u->file_name() + ", radius " + std::to_string(u->radius) + ")";
-            }
-        return fail(RF_ERR_GRAPH, "node " + who + " read texels further from its invocation than its `#pragma rf radius` states: the frame is wrong; correct the pragma");
-    }
     return RF_OK;
 }
 

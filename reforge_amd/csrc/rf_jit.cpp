@@ -183,19 +183,11 @@ void cache_store(const std::string& stem, const Compiled& c)
     if (write_file_atomically(stem + ".hsaco", c.code.data(), c.code.size())) (void)write_file_atomically(stem + ".name", name.data(), name.size());
 }
 
-}  // namespace
-// RF_GLSL_TILES=0: .comp nodes that state their radius still run without LDS tiles (A/B measurements)
-bool glsl_tiles_enabled()
-{
-    static const bool on = [] { const char* e = std::getenv("RF_GLSL_TILES"); return !(e && std::atoi(e) == 0 && *e); }();
-    return on;
-}
-namespace {
 std::string node_expression(int fmt, const UserStage& u)
 {
     if (u.glsl) {      // {type}.comp: rfglsl::glsl_node_kernel<Shader<texel format>, Info> (rf_glsl_dev.h)
         const std::string ns = "rfglsl::" + u.ident + "::";
-        return "rfglsl::glsl_node_kernel<" + ns + "Shader, " + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", " + ns + "Info, " + (glsl_tiles_enabled() ? "true" : "false") + ">";
+        return "rfglsl::glsl_node_kernel<" + ns + "Shader, " + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", " + ns + "Info>";
     }
     return std::string("rf::user_node_kernel<") + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", rfuser::" + u.ident + "::Stage>";
 }

@@ -40,7 +40,6 @@ size_t jit_compile_only(int fmt, int pf, int texels, const StageList& sl, int wa
 // user NODES (a stage file that declares its images, rf_user.h): user_node_kernel<Px, Stage> of rf_user_dev.h, launched with
 // 256 threads per workgroup and a UserNodeArgs block
 bool jit_compile_user_node(int fmt, int user_id, std::string& err);
-bool glsl_tiles_enabled();      // false with env RF_GLSL_TILES=0: .comp nodes never stage LDS tiles (A/B)
 const JitKernel* jit_lookup_user_node(int fmt, int user_id);
 const JitKernel* jit_lookup_user_fill(int user_id);      // user_fill_kernel<Stage> of a node that declares RF_BUFFER_OUT
 size_t jit_compile_only_user_node(int fmt, int user_id, std::string& err);

@@ -112,8 +112,6 @@ struct rf_graph {
     bool exchanged_once = false;           // the first halo exchange of THIS graph is waited for with a deadline
     // A storage buffer a user node FILLS on the device (RF_BUFFER_OUT) is one per graph, where the reference has one per frame
     // slot: frames of such a graph on different slots are ordered one behind the other (submit_frame) instead of overlapping
-    unsigned* glsl_status = nullptr;       // host-mapped word: bit (launch index & 31) set by a .comp launch that read beyond its stated radius
-    unsigned* glsl_status_dev = nullptr;
     bool fills_buffers = false;
     hipEvent_t buffers_idle = nullptr;
     bool buffers_idle_set = false;

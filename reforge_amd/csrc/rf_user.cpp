@@ -215,8 +215,6 @@ bool parse_glsl_stage(const std::string& type, const std::string& text, UserStag
     out.radius = sh.radius < 0 ? 0 : sh.radius;
     out.radius_stated = sh.radius >= 0;
     out.glsl_grouped = sh.grouped;
-    for (const auto& im : sh.images) out.glsl_reads += im.writeonly ? 0 : 1;
-    out.glsl_tiled = !sh.grouped && sh.radius >= 1 && sh.radius <= 15 && out.glsl_reads >= 1;
     out.glsl_groups[0] = sh.lx; out.glsl_groups[1] = sh.ly; out.glsl_groups[2] = sh.lz;
     out.inputs.clear();
     out.outputs.clear();

@@ -56,8 +56,6 @@ struct UserStage {
     std::vector<bool> glsl_image_written;          // the variable is not readonly
     int glsl_buffers = 0, glsl_groups[3] = {1, 1, 1};
     bool glsl_grouped = false;
-    bool glsl_tiled = false;      // the file states a radius >= 1 and runs in the library's own workgroups: readable images are staged in LDS tiles (rf_glsl_dev.h)
-    int glsl_reads = 0;           // images that are not writeonly
     std::string glsl_source;      // the translation
     std::string file_name() const { return type_name + (glsl ? ".comp" : ".stage.hip"); }
     std::vector<UserParam> params;

@@ -39,7 +39,7 @@ for fmt, fname, bpp in ((util.F32, "rgba32f", 16), (util.U8, "rgba8", 4)):
     for name, types, text, images in CASES:
         if ONLY and name not in ONLY:
             continue
-        row = {"type": name, "fmt": fname, "tiles": os.environ.get("RF_GLSL_TILES", "1")}
+        row = {"type": name, "fmt": fname}
         for mode in ("glsl", "built_in"):
             rf.set_type_lookup(mode == "glsl")
             g = rf.Graph(ctx, rf.Config(text), W, H, fmt)

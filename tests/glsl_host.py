@@ -77,7 +77,7 @@ extern "C" void glsl_run(int u8, const GlslFrame* f, const GlslImage* img, void*
 
 
 class Frame(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("W", "H", "row_lo", "row_hi", "y0", "y1", "groups_x", "groups_y")] + [("status", C.c_void_p), ("status_bit", C.c_uint), ("pad", C.c_uint)]
+    _fields_ = [(n, C.c_int) for n in ("W", "H", "row_lo", "row_hi", "y0", "y1", "groups_x", "groups_y")] + [("zero", C.c_void_p), ("pad0", C.c_int), ("pad1", C.c_int)]
 
 
 class Image(C.Structure):
@@ -112,6 +112,7 @@ class HostShader:
         info = (C.c_int * 6)()
         self.lib.glsl_info(info)
         self.local_size, self.n_img, self.n_buf, self.ubo_bytes = tuple(info[:3]), info[3], info[4], info[5]
+        self._zero = np.zeros(16, np.uint8)
 
     def run(self, images, params=None, buffers=None, rows=None):
         """images: {variable name: (H, W, 4) array, float32 or uint8, modified in place if the shader writes it};
@@ -120,7 +121,7 @@ class HostShader:
         arrs = list(images.values())
         H, W, _ = arrs[0].shape
         u8 = arrs[0].dtype == np.uint8
-        fr = Frame(W, H, 0, H - 1, 0 if rows is None else rows[0], H if rows is None else rows[1], (W + 15) // 16, (H + 15) // 16, None, 0, 0)
+        fr = Frame(W, H, 0, H - 1, 0 if rows is None else rows[0], H if rows is None else rows[1], (W + 15) // 16, (H + 15) // 16, self._zero.ctypes.data, 0, 0)
         if fr.y1 == H:
             fr.y1 = max(H, ((H + 15) // 16) * self.local_size[1])      # the rows below the frame that the dispatch covers run too (rf_graph.cpp does the same)
         imgs = (Image * max(self.n_img, 1))()

@@ -279,7 +279,7 @@ kk: kitchen { gain: 1.5, shift: 3, flip: %s, mask: 5, bias: 0.25 }
 
 # ---- row strips: the launch split into interior and boundary rows (the geometry of the halo exchange, one GPU) ----------------------------
 def test_a_stencil_shader_split_into_row_ranges_gives_the_same_frame(ctx, glsl_dir, monkeypatch):
-    """both files state `#pragma rf radius 2`: the launch radius of a row-strip partition, and LDS tiles"""
+    """both files state `#pragma rf radius 2`: the launch radius of a row-strip partition"""
     use(glsl_dir, "local_contrast", "gaussian5")
     text = "input -> gg -> lc -> output\ngg: gaussian5 { sigma: 1.0, %s }\nlc: local_contrast { amount: 0.8 }" % G5
     assert [l["radius"] for l in rf.Plan(rf.Config(text)).launch_info()] == [2, 2]
@@ -296,25 +296,6 @@ def test_a_stencil_shader_split_into_row_ranges_gives_the_same_frame(ctx, glsl_d
     finally:
         rf.set_shader_path(old)
     util.assert_same(whole, want, "against the oracle (stage-file twin of local_contrast)")
-
-
-def test_a_shader_that_reads_beyond_its_stated_radius_is_reported(ctx, glsl_dir):
-    """`#pragma rf radius N` sizes the LDS tile a workgroup stages (and the halo of a row strip): a load beyond it cannot be served
-    from the tile -- the launch flags it and rf_graph_wait fails with the node's name instead of handing back a wrong frame"""
-    src = open(os.path.join(SHADERS, "local_contrast.comp")).read()
-    assert "#pragma rf radius 2" in src
-    (glsl_dir / "local_contrast.comp").write_text(src.replace("#pragma rf radius 2", "#pragma rf radius 1"))
-    img = util.synthetic(200, 90, util.F32)
-    with pytest.raises(rf.RfError) as e:
-        util.run_hip(ctx, "input -> lc -> output\nlc: local_contrast { amount: 0.8 }", img)
-    assert "'lc' (local_contrast.comp, radius 1)" in str(e.value) and "#pragma rf radius" in str(e.value)
-    (glsl_dir / "local_contrast.comp").write_text(src.replace("#pragma rf radius 2", "#pragma rf radius 3"))      # stating more than is read is only slower
-    os.utime(glsl_dir / "local_contrast.comp", ns=(2 * 10 ** 18, 2 * 10 ** 18))
-    wide = util.run_hip(ctx, "input -> lc -> output\nlc: local_contrast { amount: 0.8 }", img)
-    (glsl_dir / "local_contrast.comp").write_text(src.replace("#pragma rf radius 2", ""))      # no statement: no tiles, every load from memory
-    os.utime(glsl_dir / "local_contrast.comp", ns=(3 * 10 ** 18, 3 * 10 ** 18))
-    plain = util.run_hip(ctx, "input -> lc -> output\nlc: local_contrast { amount: 0.8 }", img)
-    util.assert_same(wide, plain, "tiles of radius 3 against no tiles")
 
 
 def test_an_edited_shader_is_translated_again(ctx, glsl_dir):
