@@ -44,6 +44,7 @@ struct Args {   // main.rs:43-71
     long synthetic_seed = -1;
     int frames = 1;
     bool no_fusion = false, hipgraph = false;
+    bool files_first = false;   // {shader_path}/{type}.comp | .stage.hip before the built-in registry (config.rs:59-75: the file is the type)
     bool watch = false;         // poll the config's mtime every frame and rebuild the graph when it changes
     int frame_interval_ms = 0;
 };
@@ -60,7 +61,8 @@ void usage()
         "      --height <HEIGHT>\n"
         "      --shader-format <rgba8|rgba32f>  Shader image format [default: rgba32f]\n"
         "      --config <config>              Path to the pipeline configuration file\n"
-        "      --shader-path <shader-path>    Where {type}.stage.hip is looked for when a node type is not built in [default: shaders]\n"
+        "      --shader-path <shader-path>    Where a node type that is not built in is looked for: {type}.stage.hip, else {type}.comp (GLSL) [default: shaders]\n"
+        "      --shader-files-first           A file in the shader path wins over a built-in type of the same name (the reference's rule)\n"
         "      --num-frames <NUM_FRAMES>      Frames in flight in the --watch loop (one headless frame forces 1) [default: 2]\n"
         "      --synthetic <SEED>             Generate the input on the GPU instead of reading a file\n"
         "      --frames <N>                   Execute the graph N times and report the mean frame time\n"
@@ -96,6 +98,7 @@ bool parse_args(int argc, char** argv, Args& a)
         else if (s == "--frames") { if (!val(v)) return false; a.frames = std::atoi(v.c_str()); }
         else if (s == "--decode-only") a.decode_only = true;
         else if (s == "--no-fusion") a.no_fusion = true;
+        else if (s == "--shader-files-first") a.files_first = true;
         else if (s == "--hipgraph") a.hipgraph = true;
         else if (s == "--watch") a.watch = true;
         else if (s == "--frame-interval-ms") { if (!val(v)) return false; a.frame_interval_ms = std::atoi(v.c_str()); }
@@ -272,6 +275,7 @@ static int run(int argc, char** argv)
 
     // create_config, render.rs:100-119 (nullptr + warning on a user error)
     (void)rf_set_shader_path(args.shader_path.c_str());       // Config::new(path, shader_path), config.rs:59-75
+    (void)rf_set_type_lookup(args.files_first ? 1 : 0);
     auto create_config = [&]() -> rf_config* {
         rf_config* c = nullptr;
         if (!args.config.empty()) {
@@ -322,7 +326,7 @@ static int run(int argc, char** argv)
     std::map<std::string, long long> stage_mtimes;
     auto stage_file_ns = [&](const std::string& type) -> long long {
         struct stat st;
-        if (::stat((args.shader_path + "/" + type + ".stage.hip").c_str(), &st) != 0) return -1;
+        if (::stat((args.shader_path + "/" + type + ".stage.hip").c_str(), &st) != 0 && ::stat((args.shader_path + "/" + type + ".comp").c_str(), &st) != 0) return -1;
         return (long long)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
     };
     auto note_stage_files = [&]() {

@@ -239,3 +239,46 @@ def test_cli_user_stage_files_and_their_live_reload(tmp_path):
                 p.kill()
     # the last frame came from the edited stage: a passthrough through the sRGB boundary = the input codes
     assert np.fromfile(dst, np.uint8).reshape(64, 96, 4).tobytes() == rgba.tobytes()
+
+
+@pytest.mark.gpu
+def test_cli_runs_a_directory_of_glsl_shaders_as_it_is(tmp_path):
+    """the reference's plugin contract end to end: --shader-path holds .comp files (GLSL 450 compute, config.rs:59-75), the config
+    names them, --shader-files-first lets them stand for built-in names too; an edit that no longer translates keeps the old graph"""
+    import shutil
+    import time
+    import reforge_amd as rf
+    rgba = pixel.fill_synthetic(96, 64, util.U8, 83)
+    rgba[..., 3] = 255
+    shaders = tmp_path / "sh"
+    shaders.mkdir()
+    for f in ("invert.comp", "sharpen.comp"):
+        shutil.copy(os.path.join(ROOT, "shaders", f), shaders / f)
+    src, dst, cfg, log = str(tmp_path / "in.png"), str(tmp_path / "out.rgba"), tmp_path / "live.cfg", tmp_path / "err.log"
+    write_png(src, rgba, lambda y: 0)
+    cfg.write_text("input -> neg -> sh -> output\nneg: invert { enabled: true, strength: 1.0 }\nsh: sharpen { amount: 0.5 }")
+    r = run_cli("-i", src, "--config", str(cfg), "-o", dst, "--shader-path", str(shaders), "--shader-files-first")
+    assert r.returncode == 0 and "GPU: {neg: " in r.stderr and "sh: " in r.stderr, r.stderr      # two launches: both types are files
+    got = np.fromfile(dst, np.uint8).reshape(64, 96, 4).copy()
+    r = run_cli("-i", src, "--config", str(cfg), "-o", dst, "--shader-path", str(shaders))      # default lookup: sharpen is the built-in kernel, invert the file
+    assert r.returncode == 0, r.stderr
+    assert np.fromfile(dst, np.uint8).reshape(64, 96, 4).tobytes() == got.tobytes()            # the same bits either way
+    with open(log, "wb") as err:
+        p = subprocess.Popen([CLI, "-i", src, "--config", str(cfg), "-o", dst, "--shader-path", str(shaders), "--shader-files-first", "--frames", "300", "--watch",
+                              "--frame-interval-ms", "25"], stderr=err)
+        try:
+            end = time.time() + 90
+            while time.time() < end and "GPU: {neg: " not in log.read_text(errors="replace"):
+                time.sleep(0.01)
+            good = (shaders / "invert.comp").read_text()
+            (shaders / "invert.comp").write_text(good.replace("uniform Params", "uniform sampler2D nope; uniform Params"))
+            end = time.time() + 90
+            while time.time() < end and "invert.comp:" not in log.read_text(errors="replace"):
+                time.sleep(0.01)
+            assert "invert.comp:" in log.read_text(errors="replace") and p.poll() is None      # refused with file:line, still rendering
+            (shaders / "invert.comp").write_text(good)
+            assert p.wait(timeout=180) == 0
+        finally:
+            if p.poll() is None:
+                p.kill()
+    assert np.fromfile(dst, np.uint8).reshape(64, 96, 4).tobytes() == got.tobytes()
