@@ -785,6 +785,9 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
         if (L.ops.size() != 1 || L.ops[0].kind != OP_USERN) continue;
         const UserStage* u = user_stage_by_id(L.ops[0].user_id);
         if (u && u->glsl) {
+            if (ctx->world > 1 && !u->buf_out.empty())
+                return fail(RF_ERR_UNSUPPORTED, "node '" + L.label + "': " + u->file_name() + " writes a storage block (" + u->buf_out[0].name + "); storage buffers are per rank, so a shader that "
+                                                "fills one from the invocations of some rows cannot be split into row strips");
             // a .comp node addresses the FRAME: split over ranks it needs to say how far it reads (#pragma rf radius N, rf_glsl.h)
             if (ctx->world > 1 && !u->radius_stated)
                 return fail(RF_ERR_UNSUPPORTED, "node '" + L.label + "': " + u->file_name() + " does not say `#pragma rf radius N` (rows an invocation reads above / below its own); "

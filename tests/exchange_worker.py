@@ -34,6 +34,9 @@ def main():
     device = rank if os.environ.get("RF_TEST_ONE_GPU_PER_RANK") == "1" else 0
     ctx = rf.Context(device, rank, world, uid)
     source = sys.argv[11] if len(sys.argv) > 11 else "fill"
+    if os.environ.get("RF_TEST_SHADER_PATH"):                        # filter types that are files (tests/test_gpu_glsl.py: .comp files on every rank)
+        rf.set_shader_path(os.environ["RF_TEST_SHADER_PATH"])
+        rf.set_type_lookup(os.environ.get("RF_TEST_FILES_FIRST") == "1")
     g = rf.Graph(ctx, rf.Config(text), W, H, fmt, flags=flags)       # exchange mode unless the caller set RF_GRAPH_NO_HALO_XCHG
     y0, y1 = g.strip
     if source == "fill":

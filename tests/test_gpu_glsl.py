@@ -298,6 +298,44 @@ def test_a_stencil_shader_split_into_row_ranges_gives_the_same_frame(ctx, glsl_d
     util.assert_same(whole, want, "against the oracle (stage-file twin of local_contrast)")
 
 
+# ---- row strips over several ranks (processes sharing GPU 0 over the RCCL test double of tests/test_gpu_exchange.py) ------------------------
+from tests.test_gpu_exchange import fake_rccl_dir, run_ranks  # noqa: E402,F401
+
+
+@pytest.mark.parametrize("flags", [0, rf.RF_GRAPH_NO_HALO_XCHG], ids=["exchange", "overfetch"])
+def test_glsl_nodes_split_into_row_strips(fake_rccl_dir, glsl_dir, tmp_path, monkeypatch, flags):
+    """the headline graph through its three .comp files on three ranks: each file states `#pragma rf radius` (2, 0, 1), which is
+    the halo a rank exchanges before -- or over-fetches for -- the node; shaders address the FRAME (imageSize, gl_GlobalInvocationID)"""
+    use(glsl_dir, "gaussian5", "colour_grade", "sharpen")
+    text = TWINS["chain3"][1]
+    monkeypatch.setenv("RF_TEST_SHADER_PATH", str(glsl_dir))
+    monkeypatch.setenv("RF_TEST_FILES_FIRST", "1")
+    W, H, seed = 333, 257, 0x5EED0011
+    for fmt in (util.F32, util.U8):
+        sub = tmp_path / ("fmt%d" % fmt)
+        sub.mkdir()
+        got = run_ranks(fake_rccl_dir, sub, text, 3, W, H, fmt, flags, seed)
+        from oracle import pixel
+        util.assert_same(got, util.run_oracle(text, pixel.fill_synthetic(W, H, fmt, seed)), "GLSL chain on 3 ranks, flags=%d fmt=%d" % (flags, fmt))
+
+
+def test_a_shader_that_does_not_state_its_radius_is_not_split(glsl_dir):
+    """one GPU: any shader runs; more than one rank: the node must say how far it reads -- and may not fill a storage block"""
+    (glsl_dir / "mystery.comp").write_text(open(os.path.join(SHADERS, "sharpen.comp")).read().replace("#pragma rf radius 1", ""))
+    use(glsl_dir, "conv2d_weights", "conv2d")
+    c2 = rf.Context(0, 0, 2, None)      # a rank of two without a communicator: over-fetch graphs only
+    try:
+        with pytest.raises(rf.RfError) as e:
+            rf.Graph(c2, rf.Config("input -> my -> output\nmy: mystery { amount: 0.5 }"), 64, 64, util.F32, flags=rf.RF_GRAPH_NO_HALO_XCHG)
+        assert "mystery.comp does not say `#pragma rf radius N`" in str(e.value)
+        with pytest.raises(rf.RfError) as e:
+            rf.Graph(c2, rf.Config("input -> kw -> cv -> output\nkw:ConvWeights -> cv:ConvWeights\nkw: conv2d_weights { ksize: 3 }\ncv: conv2d { ksize: 3 }"), 64, 64, util.F32,
+                     flags=rf.RF_GRAPH_NO_HALO_XCHG)
+        assert "conv2d_weights.comp writes a storage block (ConvWeights)" in str(e.value)
+    finally:
+        c2.close()
+
+
 def test_an_edited_shader_is_translated_again(ctx, glsl_dir):
     src = open(os.path.join(SHADERS, "invert.comp")).read()
     (glsl_dir / "invert.comp").write_text(src)
