@@ -220,7 +220,8 @@ long long   rf_user_stage_mtime(const char* type_name);
 /* Filter types in the reference's OWN file form: {shader_path}/T.comp, a GLSL 450 compute shader -- what a reforge user already
  * has (src/config/config.rs:59-75; shaders/passthrough.comp is the one the reference ships).  A type that is neither built in nor
  * a T.stage.hip is looked for as T.comp.  No GLSL compiler is needed: rf_glsl.cpp TRANSLATES the subset a compute filter uses to
- * HIP device source (vectors with swizzles, matrices, the built-in functions, image2D storage images by variable name, uniform
+ * HIP device source (vectors with swizzles, matrices, the built-in functions, image2D storage images and sampler2D combined image
+ * samplers by variable name -- texture() filters as the reference's one sampler does, src/vulkan/vkutils.rs:358-365 --, uniform
  * blocks -- their scalar members are the node's parameters, std140 --, storage blocks by block TYPE name -- std430 --, structs,
  * #define, shared variables and barrier()), hiprtc compiles it at rf_graph_create, and rfglsl::glsl_node_kernel runs one invocation
  * per thread over the reference's dispatch, ceil(W/16) x ceil(H/16) workgroups of the file's local_size (src/vulkan/command.rs:167-168).

@@ -147,7 +147,7 @@ const std::set<std::string>& dropped_qualifiers()
 const std::set<std::string>& unsupported_words()
 {
     static const std::set<std::string> s = {"double",      "dvec2",       "dvec3",       "dvec4",      "dmat2",       "dmat3",          "dmat4",        "sampler1D",
-                                            "sampler2D",   "sampler3D",   "samplerCube", "texture",    "texelFetch",  "image1D",        "image3D",      "imageCube",
+                                            "sampler3D",   "samplerCube", "sampler2DArray", "sampler2DShadow", "textureGather", "image1D",        "image3D",      "imageCube",
                                             "image2DArray", "iimage2D",   "uimage2D",    "atomicAdd",  "atomicMin",   "atomicMax",      "atomicExchange", "atomicCompSwap",
                                             "imageAtomicAdd", "subroutine", "mat2x2",    "mat2x3",     "mat2x4",      "mat3x2",         "mat3x3",       "mat3x4",
                                             "mat4x2",      "mat4x3",      "mat4x4",      "push_constant"};
@@ -653,27 +653,29 @@ struct Translator {
                 if (lq.count("set") && lq["set"] != "0") fail(v[first].line, "descriptor set " + lq["set"] + ": only set 0 is supported (shader.rs:125-127)");
                 const int binding = lq.count("binding") ? std::atoi(lq["binding"].c_str()) : -1;
                 if (v[i].k != T_ID) fail(v[i].line, "cannot read this declaration");
-                if (q_uniform && v[i].s == "image2D") {
+                if (q_uniform && (v[i].s == "image2D" || v[i].s == "sampler2D")) {
+                    const bool sampled = v[i].s == "sampler2D";
                     size_t k = i + 1;
                     if (v[k].k != T_ID) fail(v[k].line, "an image variable needs a name");
                     GlslImageVar im;
                     im.name = v[k].s;
                     im.binding = binding;
-                    im.readonly = q_ro;
-                    im.writeonly = q_wo;
+                    im.readonly = q_ro || sampled;
+                    im.writeonly = q_wo && !sampled;
+                    im.sampled = sampled;
                     if (!is(v[k + 1], ";")) fail(v[k + 1].line, is(v[k + 1], "[") ? "arrays of images are not supported" : "expected `;` after the image variable " + im.name);
-                    claim_binding(binding, v[first].line, "image2D " + im.name);
+                    claim_binding(binding, v[first].line, std::string(sampled ? "sampler2D " : "image2D ") + im.name);
                     if ((int)sh.images.size() >= kGlslMaxImages) fail(v[first].line, "more than " + std::to_string(kGlslMaxImages) + " image variables");
                     for (const auto& o : sh.images)
                         if (o.name == im.name) fail(v[k].line, "the image variable " + im.name + " is declared twice");
-                    members += "    image2D<Px> " + im.name + ";\n";
-                    bind += "        " + im.name + " = image2D<Px>{img[" + std::to_string(sh.images.size()) + "].base, img[" + std::to_string(sh.images.size()) + "].pitch, f.W, f.H, f.row_lo, f.row_hi, f.y0, f.y1 - 1, f.zero};\n";
+                    members += std::string("    ") + (sampled ? "sampler2D" : "image2D") + "<Px> " + im.name + ";\n";
+                    bind += "        " + im.name + (sampled ? ".im" : "") + " = image2D<Px>{img[" + std::to_string(sh.images.size()) + "].base, img[" + std::to_string(sh.images.size()) + "].pitch, f.W, f.H, f.row_lo, f.row_hi, f.y0, f.y1 - 1, f.zero};\n";
                     sh.images.push_back(im);
                     blank(v, first, k + 2);
                     i = k + 2;
                     continue;
                 }
-                if (!is(v[i + 1], "{")) fail(v[i].line, "`" + v[i].s + "`: a uniform is a storage image (image2D) or a block; a buffer is a block");
+                if (!is(v[i + 1], "{")) fail(v[i].line, "`" + v[i].s + "`: a uniform is a storage image (image2D), a combined image sampler (sampler2D) or a block; a buffer is a block");
                 GlslBlock blk;
                 blk.binding = binding;
                 blk.readonly = q_ro;
@@ -801,7 +803,7 @@ std::string glsl_reflection_json(const GlslShader& s)
                     ", \"radius\": " + std::to_string(s.radius) + ", \"uniform_bytes\": " + std::to_string(s.ubo_bytes) + ", \"images\": [";
     for (size_t i = 0; i < s.images.size(); ++i)
         j += std::string(i ? ", " : "") + "{\"name\": " + q(s.images[i].name) + ", \"binding\": " + std::to_string(s.images[i].binding) + ", \"readonly\": " + (s.images[i].readonly ? "true" : "false") +
-             ", \"writeonly\": " + (s.images[i].writeonly ? "true" : "false") + "}";
+             ", \"writeonly\": " + (s.images[i].writeonly ? "true" : "false") + (s.images[i].sampled ? ", \"sampled\": true" : "") + "}";
     auto blocks = [&](const std::vector<GlslBlock>& bl) {
         std::string o;
         for (size_t i = 0; i < bl.size(); ++i) {

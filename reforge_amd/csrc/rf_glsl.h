@@ -10,6 +10,7 @@
 //
 // Reflection (what spirv-reflect gives the reference) falls out of the same parse:
 //   layout(binding = B, <format>) uniform [readonly|writeonly] image2D name;      -> image variable `name`
+//   layout(binding = B) uniform sampler2D name;                                   -> the same, read through the graph's sampler (texture(), texelFetch())
 //   layout(binding = B) uniform Block { float|int|uint|bool|vecN|... members; } [instance];  -> uniform members (std140)
 //   layout(std430, binding = B) [readonly|writeonly] buffer Block { members } [instance];    -> storage buffer `Block` (std430)
 //   layout(local_size_x = X, local_size_y = Y, local_size_z = Z) in;
@@ -19,8 +20,8 @@
 // function sees every uniform, image and built-in variable, in any order); `vecN(...)` constructors become mk_vecN(...),
 // array constructors braces, `out` / `inout` parameters references, literals `float`; `shared` variables move in front of
 // the struct as LDS variables; `precise`, precision qualifiers and prototypes go.  Not translated (the file is refused with
-// a message, as the reference refuses a file that does not compile: Option::None + warning, shader.rs:92): samplers,
-// images other than image2D, nested structs in blocks, unsized arrays, double precision, vector == vector.
+// a message, as the reference refuses a file that does not compile: Option::None + warning, shader.rs:92): samplers other
+// than sampler2D, images other than image2D, nested structs in blocks, unsized arrays, double precision, vector == vector.
 #pragma once
 
 #include <string>
@@ -52,6 +53,7 @@ struct GlslImageVar {
     std::string name;
     int binding = -1;
     bool readonly = false, writeonly = false;
+    bool sampled = false;         // `uniform sampler2D`: bound as a combined image sampler (shader.rs:98), read through texture() / texelFetch()
 };
 
 struct GlslShader {

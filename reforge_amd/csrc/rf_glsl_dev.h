@@ -323,6 +323,33 @@ template <class Px> RFG void imageStore(const image2D<Px>& im, ivec2 p, vec4 v)
     Px::store(im.base + (long long)p.y * (long long)im.pitch, (unsigned)p.x * (unsigned)Px::BPP, Px::texel(v.x, v.y, v.z, v.w));
 }
 
+// `uniform sampler2D name`: the same allocated image bound as a COMBINED IMAGE SAMPLER (shader.rs:98; pipeline_graph.rs:98-105 writes
+// every image descriptor with the graph's one sampler).  That sampler is LINEAR / LINEAR, address mode U = CLAMP_TO_EDGE, and V = the
+// Vulkan default REPEAT: vkutils.rs:358-365 sets `address_mode_u` once and `address_mode_w` twice, never `address_mode_v` -- restated as
+// it is.  texture(): unnormalised coordinate = uv * size - 0.5, the four texels around it weighted (1-a)(1-b), a(1-b), (1-a)b, ab
+// (Vulkan 1.3, 16.8 "Texel filtering") in float; hardware filters with 8-bit fixed-point weights, so the low bits of a filtered sample
+// are the implementation's there (parity unpinned).  texelFetch(): the texel itself; outside the image: zero.
+template <class Px> struct sampler2D {
+    image2D<Px> im;
+};
+template <class Px> RFG ivec2 textureSize(const sampler2D<Px>& s, int) { return ivec2{s.im.W, s.im.H}; }
+template <class Px> RFG vec4 texelFetch(const sampler2D<Px>& s, ivec2 p, int) { return imageLoad(s.im, p); }
+template <class Px> RFG vec4 texture(const sampler2D<Px>& s, vec2 uv)
+{
+    const float u = uv.x * (float)s.im.W - 0.5f, v = uv.y * (float)s.im.H - 0.5f;
+    const float fu = ::floorf(u), fv = ::floorf(v);
+    const float a = u - fu, b = v - fv;
+    int i0 = (int)fu, j0 = (int)fv;
+    int i1 = i0 + 1, j1 = j0 + 1;
+    i0 = i0 < 0 ? 0 : (i0 > s.im.W - 1 ? s.im.W - 1 : i0);      // U: clamp to edge
+    i1 = i1 < 0 ? 0 : (i1 > s.im.W - 1 ? s.im.W - 1 : i1);
+    j0 %= s.im.H; j0 += j0 < 0 ? s.im.H : 0;                    // V: repeat
+    j1 %= s.im.H; j1 += j1 < 0 ? s.im.H : 0;
+    const vec4 t00 = imageLoad(s.im, ivec2{i0, j0}), t10 = imageLoad(s.im, ivec2{i1, j0}), t01 = imageLoad(s.im, ivec2{i0, j1}), t11 = imageLoad(s.im, ivec2{i1, j1});
+    return ((1.0f - a) * (1.0f - b)) * t00 + (a * (1.0f - b)) * t10 + ((1.0f - a) * b) * t01 + (a * b) * t11;
+}
+template <class Px> RFG vec4 textureLod(const sampler2D<Px>& s, vec2 uv, float) { return texture(s, uv); }      // one level
+
 // what the kernel hands a shader object (GlslArgs below, the oracle's driver on the host)
 struct GlslImage {
     char* base;

@@ -271,7 +271,7 @@ def test_cli_runs_a_directory_of_glsl_shaders_as_it_is(tmp_path):
             while time.time() < end and "GPU: {neg: " not in log.read_text(errors="replace"):
                 time.sleep(0.01)
             good = (shaders / "invert.comp").read_text()
-            (shaders / "invert.comp").write_text(good.replace("uniform Params", "uniform sampler2D nope; uniform Params"))
+            (shaders / "invert.comp").write_text(good.replace("uniform Params", "uniform samplerCube nope; uniform Params"))
             end = time.time() + 90
             while time.time() < end and "invert.comp:" not in log.read_text(errors="replace"):
                 time.sleep(0.01)

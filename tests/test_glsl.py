@@ -116,7 +116,7 @@ void main()
 
 
 REFUSED = [
-    ("layout (binding = 0) uniform sampler2D tex;\nvoid main() {}", "bad.comp:1", "sampler2D"),
+    ("layout (binding = 0) uniform samplerCube tex;\nvoid main() {}", "bad.comp:1", "samplerCube"),
     ("void main() { double x = 1.0; }", "bad.comp:1", "double"),
     ("layout (std430, binding = 0) buffer Data { float v[]; };\nvoid main() {}", "bad.comp:1", "unsized"),
     ("struct S { float a; };\nlayout (binding = 0) uniform P { S s; };\nvoid main() {}", "bad.comp:2", "nested structs"),
@@ -213,6 +213,58 @@ def test_the_user_type_twins_run_on_the_host_match_their_stage_files():
         util.assert_same(o, want, "unsharp_mask")
     finally:
         rf.set_shader_path(old)
+
+
+# ---- combined image samplers (shader.rs:98): texture() through the graph's one sampler (vkutils.rs:358-365) ----------------------------------
+RESAMPLE = """#version 450
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0) uniform sampler2D source;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+layout (binding = 2) uniform Params { float shift_x; float shift_y; float zoom; };
+void main()
+{
+    ivec2 size = textureSize(source, 0);
+    ivec2 p = ivec2(gl_GlobalInvocationID.xy);
+    if (p.x >= size.x || p.y >= size.y) return;
+    vec2 uv = ((vec2(p) + vec2(0.5)) * zoom + vec2(shift_x, shift_y)) / vec2(size);
+    vec4 filtered = texture(source, uv);
+    vec4 exact = texelFetch(source, ivec2(size.x - 1 - p.x, p.y), 0);
+    imageStore(output_image, p, vec4(filtered.rgb, exact.a));
+}
+"""
+
+
+def resample(img, shift_x, shift_y, zoom):
+    """texture() as rf_glsl_dev.h states it: unnormalised = uv * size - 0.5, four texels weighted (1-a)(1-b), a(1-b), (1-a)b, ab in
+    float32, U clamped to the edge, V REPEATED (the reference's sampler never sets address_mode_v, vkutils.rs:358-365)"""
+    f = np.float32
+    H, W, _ = img.shape
+    src = img.astype(f) if img.dtype == np.float32 else (img.astype(f) / f(255.0))
+    xs, ys = np.meshgrid(np.arange(W, dtype=f), np.arange(H, dtype=f))
+    uvx = ((xs + f(0.5)) * f(zoom) + f(shift_x)) / f(W)
+    uvy = ((ys + f(0.5)) * f(zoom) + f(shift_y)) / f(H)
+    u, v = uvx * f(W) - f(0.5), uvy * f(H) - f(0.5)
+    fu, fv = np.floor(u), np.floor(v)
+    a, b = (u - fu)[..., None], (v - fv)[..., None]
+    i0, j0 = fu.astype(np.int64), fv.astype(np.int64)
+    i1, j1 = np.clip(i0 + 1, 0, W - 1), np.mod(j0 + 1, H)
+    i0, j0 = np.clip(i0, 0, W - 1), np.mod(j0, H)
+    one = f(1.0)
+    out = ((((one - a) * (one - b)) * src[j0, i0] + (a * (one - b)) * src[j0, i1]) + ((one - a) * b) * src[j1, i0]) + (a * b) * src[j1, i1]
+    out[..., 3] = src[:, ::-1, 3]
+    return out.astype(f)
+
+
+@pytest.mark.parametrize("params", [(0.0, 0.0, 1.0), (0.37, -1.25, 1.0), (3.5, 40.0, 0.75)])
+def test_a_sampler2D_is_filtered_by_the_graphs_sampler_on_the_host(params):
+    r = rf.glsl_reflect("resample", RESAMPLE)
+    assert r["images"][0] == {"name": "source", "binding": 0, "readonly": True, "writeonly": False, "sampled": True}
+    img = util.synthetic(45, 23, util.F32)
+    o = np.zeros_like(img)
+    HostShader("resample", RESAMPLE).run({"source": img, "output_image": o}, {"shift_x": params[0], "shift_y": params[1], "zoom": params[2]})
+    util.assert_same(o, resample(img, *params), "texture() %r" % (params,))
+    if params == (0.0, 0.0, 1.0):      # sampled at the texel centres ((x + 0.5) / W * W - 0.5 rounds: the weights are 1, 0, 0, 0 up to an ulp or two)
+        assert np.allclose(o[..., :3], img[..., :3], rtol=0, atol=2e-6)
 
 
 def test_conv2d_weights_fills_its_block_from_invocations_beyond_a_small_frame():

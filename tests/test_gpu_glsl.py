@@ -298,6 +298,22 @@ def test_a_stencil_shader_split_into_row_ranges_gives_the_same_frame(ctx, glsl_d
     util.assert_same(whole, want, "against the oracle (stage-file twin of local_contrast)")
 
 
+# ---- combined image samplers ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt", [util.F32, util.U8], ids=["rgba32f", "rgba8"])
+def test_a_sampler2D_is_filtered_by_the_graphs_sampler(ctx, glsl_dir, fmt):
+    """`uniform sampler2D` (a combined image sampler, shader.rs:98) read with texture() / texelFetch(): LINEAR, U clamp-to-edge, V repeat
+    (vkutils.rs:358-365 as written), against the numpy restatement of tests/test_glsl.py"""
+    from tests.test_glsl import RESAMPLE, resample
+    (glsl_dir / "resample.comp").write_text(RESAMPLE)
+    img = util.synthetic(250, 131, fmt)
+    for sx, sy, zoom in ((0.0, 0.0, 1.0), (0.37, -1.25, 1.0), (3.5, 40.0, 0.75)):
+        got = util.run_hip(ctx, "input -> gg -> rs:source\nrs -> output\ngg: passthrough {}\nrs: resample { shift_x: %s, shift_y: %s, zoom: %s }" % (sx, sy, zoom), img)
+        want = resample(img, sx, sy, zoom)
+        if fmt == util.U8:      # imageStore's conversion of the restatement's floats: clamp, x 255, round to nearest even
+            want = np.rint(np.clip(want, 0, 1) * np.float32(255.0)).astype(np.uint8)
+        util.assert_same(got, want, "texture() shift %s %s zoom %s" % (sx, sy, zoom))
+
+
 # ---- row strips over several ranks (processes sharing GPU 0 over the RCCL test double of tests/test_gpu_exchange.py) ------------------------
 from tests.test_gpu_exchange import fake_rccl_dir, run_ranks  # noqa: E402,F401
 
@@ -353,7 +369,7 @@ def test_an_edited_shader_is_translated_again(ctx, glsl_dir):
 
 
 def test_a_file_outside_the_subset_is_refused_with_its_line(ctx, glsl_dir):
-    (glsl_dir / "bad.comp").write_text("#version 450\nlayout (local_size_x = 16, local_size_y = 16) in;\nlayout (binding = 0) uniform sampler2D tex;\nvoid main() {}\n")
+    (glsl_dir / "bad.comp").write_text("#version 450\nlayout (local_size_x = 16, local_size_y = 16) in;\nlayout (binding = 0) uniform samplerCube tex;\nvoid main() {}\n")
     with pytest.raises(rf.RfError) as e:
         rf.Plan(rf.Config("input -> bb -> output\nbb: bad {}"))
     assert "bad.comp:3" in str(e.value)
