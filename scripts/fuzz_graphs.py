@@ -10,6 +10,16 @@ from tests import util
 first, count = int(sys.argv[1]), int(sys.argv[2])
 W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1920, 1080)
 ctx = rf.Context(0)
+if os.environ.get("FUZZ_GLSL") == "1":
+    # the node types that have a bit-exact GLSL twin run FROM THEIR .comp FILES (file-first lookup, rf_glsl.cpp), the oracle runs its own
+    # restatement of the same types: needs FUZZ_GEN=dag_user.  (Not the gaussians -- a shader derives their weights with GLSL exp() -- nor
+    # conv2d / colour_grade, whose files lack the built-ins' optional bindings.)
+    import shutil, tempfile
+    gd = tempfile.mkdtemp(prefix="fuzz_glsl_")
+    for t in ("sharpen", "combination", "split_luma", "invert", "edge_detect", "unsharp_mask", "local_contrast"):
+        shutil.copy(os.path.join(util.SHADERS, t + ".comp"), gd)
+    for t in ("tone_curve", "apply_curve", "streak"):      # user types without a twin: their stage files
+        shutil.copy(os.path.join(util.SHADERS, t + ".stage.hip"), gd)
 pixel.set_threads(min(16, os.cpu_count() or 1))
 bad = 0
 t0 = time.time()
@@ -19,6 +29,9 @@ for seed in range(first, first + count):
     if gen == "dag_user":      # user types (shaders/*.stage.hip) mixed in; the oracle compiles the same files for the host
         if seed == first:
             util.register_user_types()
+            if os.environ.get("FUZZ_GLSL") == "1":
+                rf.set_shader_path(gd)
+                rf.set_type_lookup(True)
         text = util.random_dag(rng, split=seed % 2 == 0, user=True)
     else:
         text = (util.random_dag if gen == "dag" else util.random_graph)(rng)

@@ -59,5 +59,34 @@ int main(int argc, char** argv) {
         }
         std::printf("stages %d parsed %d\n", count, parsed);
     }
+    // argv[4]: how many generated GLSL files g0000.comp ... the same directory holds -- the translator and reflection of rf_glsl.cpp on
+    // untrusted text, directly (rf_glsl_translate / rf_glsl_reflect) and the way a config reaches them
+    if (argc > 4) {
+        int translated = 0, planned = 0;
+        const int count = std::atoi(argv[4]);
+        std::vector<char> buf(1 << 20);
+        for (int k = 0; k < count; ++k) {
+            char name[32];
+            std::snprintf(name, sizeof(name), "g%04d", k);
+            std::ifstream gf(std::string(argv[2]) + "/" + name + ".comp", std::ios::binary);
+            std::stringstream gs; gs << gf.rdbuf();
+            const std::string text = gs.str();
+            size_t len = 0;
+            if (rf_glsl_translate(name, text.c_str(), buf.data(), buf.size(), &len) == RF_OK) ++translated;
+            (void)rf_glsl_reflect(name, text.c_str(), buf.data(), buf.size(), &len);
+            (void)rf_glsl_translate(name, text.c_str(), buf.data(), 16, &len);      // a buffer that is too small
+            const std::string cfg = std::string("input -> nn -> output\nnn: ") + name + " { amount: 1.0 }";
+            rf_config* c = nullptr;
+            if (rf_config_parse(cfg.c_str(), 1, &c) != RF_OK) continue;
+            rf_plan* p = nullptr;
+            if (rf_plan_create(c, 0, &p) == RF_OK) {
+                int ns[8], nd[8], ni, gh;
+                if (rf_plan_halo_schedule(p, 0, ns, nd, 8, &ni, &gh) == RF_OK) ++planned;
+                rf_plan_destroy(p);
+            }
+            rf_config_destroy(c);
+        }
+        std::printf("glsl %d translated %d planned %d\n", count, translated, planned);
+    }
     return 0;
 }
