@@ -17,6 +17,7 @@ struct Tok {
     TokKind k = T_END;
     std::string s;       // the text that is emitted (rewritten in place)
     std::string ws;      // what stood in front of it: white space; comments are reduced to their line breaks
+    std::string pre, post;   // inserted around it (emitted even when the token itself is dropped)
     int line = 1;
     bool drop = false;   // emit the white space only
 };
@@ -177,6 +178,67 @@ size_t next_live(const std::vector<Tok>& v, size_t i, size_t end)
     return i;
 }
 
+// `a == b` / `a != b`: GLSL compares vectors, matrices and structs as wholes and gives ONE bool; a C++ comparison of clang vectors
+// gives a vector.  Every equality operator becomes a call -- rfg_eq(a, b) / rfg_ne(a, b), rf_glsl_dev.h: plain == for scalars, "all
+// components equal" for vectors and matrices -- around its operands, found by precedence: everything that binds tighter than ==
+// (postfix, unary, * / %, + -, << >>, < > <= >=) belongs to the operand; the scan stops at the enclosing bracket, at `,` `;` `?` `:`,
+// at & ^ | (and so && ||), at an assignment and at another equality operator.
+void rewrite_equality(std::vector<Tok>& v, size_t b, size_t e)
+{
+    auto live = [&](size_t i) { return !v[i].drop; };
+    auto punct = [&](size_t i, char c) { return live(i) && v[i].k == T_PUNCT && v[i].s.size() == 1 && v[i].s[0] == c; };
+    auto glued = [&](size_t i) { return v[i].ws.empty() && v[i].pre.empty(); };      // directly behind the token in front of it
+    for (size_t i = b; i + 1 < e; ++i) {
+        if (!(punct(i, '=') || punct(i, '!')) || !punct(i + 1, '=') || !glued(i + 1)) continue;
+        if (punct(i, '=') && i > b && glued(i) && v[i - 1].k == T_PUNCT && live(i - 1) && std::string("<>!=+-*/%&|^").find(v[i - 1].s[0]) != std::string::npos) continue;   // <=, >=, +=, ... or the tail of ==
+        const bool ne = v[i].s == "!";
+        // left operand: back to the first token that binds looser than ==
+        size_t lb = i;
+        int depth = 0;
+        while (lb > b) {
+            const size_t k = lb - 1;
+            if (!live(k)) { --lb; continue; }
+            if (v[k].k == T_PUNCT) {
+                const char c = v[k].s[0];
+                if (c == ')' || c == ']' || c == '}') ++depth;
+                else if (c == '(' || c == '[' || c == '{') { if (depth == 0) break; --depth; }
+                else if (depth == 0) {
+                    if (c == ',' || c == ';' || c == '?' || c == ':' || c == '&' || c == '|' || c == '^') break;
+                    if (c == '=') {
+                        const bool relational = k > b && live(k - 1) && v[k - 1].k == T_PUNCT && (v[k - 1].s == "<" || v[k - 1].s == ">") && glued(k);
+                        if (!relational) break;      // an assignment, a compound assignment, or another == / != (left-associative: it is the left operand's end)
+                    }
+                }
+            } else if (depth == 0 && v[k].k == T_ID && (v[k].s == "return" || v[k].s == "case")) break;
+            --lb;
+        }
+        while (lb < i && !live(lb)) ++lb;
+        // right operand
+        size_t re = i + 2;
+        depth = 0;
+        while (re < e) {
+            if (live(re) && v[re].k == T_PUNCT) {
+                const char c = v[re].s[0];
+                if (c == '(' || c == '[' || c == '{') ++depth;
+                else if (c == ')' || c == ']' || c == '}') { if (depth == 0) break; --depth; }
+                else if (depth == 0) {
+                    if (c == ',' || c == ';' || c == '?' || c == ':' || c == '&' || c == '|' || c == '^') break;
+                    if ((c == '=' || c == '!') && re + 1 < e && punct(re + 1, '=') && glued(re + 1)) break;      // the next equality operator
+                    if (c == '=' && !(re > 0 && live(re - 1) && (v[re - 1].s == "<" || v[re - 1].s == ">") && glued(re))) break;
+                }
+            }
+            ++re;
+        }
+        if (lb >= i || re <= i + 2) throw Fail{v[i].line, "cannot find the operands of this comparison"};
+        size_t last = re - 1;
+        while (last > i + 1 && !live(last)) --last;
+        v[lb].pre = (ne ? "rfg_ne(" : "rfg_eq(") + v[lb].pre;
+        v[i].s = ",";
+        v[i + 1].drop = true;
+        v[last].post += ")";
+    }
+}
+
 // the rewrites that need no knowledge of where a token stands: [b, e)
 void rewrite(std::vector<Tok>& v, size_t b, size_t e, const Ctx& cx)
 {
@@ -219,14 +281,16 @@ void rewrite(std::vector<Tok>& v, size_t b, size_t e, const Ctx& cx)
         if (cx.ssbo_scalars.count(t.s)) { t.s = "(*rfg_p_" + t.s + ")"; continue; }
         if (cx.ssbo_instances.count(t.s) && n < e && is(v[n], ".")) { v[n].s = "->"; continue; }
     }
+    rewrite_equality(v, b, e);
 }
 
 std::string emit(const std::vector<Tok>& v, size_t b, size_t e)
 {
     std::string o;
     for (size_t i = b; i < e; ++i) {
-        o += v[i].ws;
+        o += v[i].ws + v[i].pre;
         if (!v[i].drop) o += v[i].s;
+        o += v[i].post;
     }
     return o;
 }

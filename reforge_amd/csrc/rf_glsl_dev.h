@@ -290,6 +290,56 @@ template <class V, int N> RFG matN<V, N> transpose(const matN<V, N>& a)
     return r;
 }
 
+// ---- == and != (the translator writes every one as a call): one bool, also for vectors and matrices --------------------------------------
+template <class A, class B> RFG bool rfg_eq(A a, B b) { return a == b; }
+#define RFG_EQ(V, N) \
+    RFG bool rfg_eq(V a, V b) { bool r = true; for (int i = 0; i < N; ++i) r = r && a[i] == b[i]; return r; }
+RFG_EQ(vec2, 2) RFG_EQ(vec3, 3) RFG_EQ(vec4, 4) RFG_EQ(ivec2, 2) RFG_EQ(ivec3, 3) RFG_EQ(ivec4, 4) RFG_EQ(uvec2, 2) RFG_EQ(uvec3, 3) RFG_EQ(uvec4, 4)
+#undef RFG_EQ
+template <class V, int N> RFG bool rfg_eq(const matN<V, N>& a, const matN<V, N>& b) { bool r = true; for (int i = 0; i < N; ++i) r = r && rfg_eq(a.c[i], b.c[i]); return r; }
+template <class A, class B> RFG bool rfg_ne(A a, B b) { return !rfg_eq(a, b); }
+
+// ---- integer and packing built-ins --------------------------------------------------------------------------------------------------------
+RFG int bitCount(uint x) { return __builtin_popcount(x); }
+RFG int bitCount(int x) { return __builtin_popcount((unsigned)x); }
+RFG int findLSB(uint x) { return x == 0u ? -1 : __builtin_ctz(x); }
+RFG int findLSB(int x) { return findLSB((uint)x); }
+RFG int findMSB(uint x) { return x == 0u ? -1 : 31 - __builtin_clz(x); }
+RFG int findMSB(int x) { return x < 0 ? findMSB(~(uint)x) : findMSB((uint)x); }
+RFG uint bitfieldExtract(uint v, int offset, int bits) { return bits == 0 ? 0u : (v >> offset) & (bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u)); }
+RFG int bitfieldExtract(int v, int offset, int bits) { return bits == 0 ? 0 : (int)((uint)v << (32 - offset - bits)) >> (32 - bits); }
+RFG uint bitfieldInsert(uint base, uint ins, int offset, int bits)
+{
+    const uint m = bits >= 32 ? 0xffffffffu : (((1u << bits) - 1u) << offset);
+    return bits == 0 ? base : (base & ~m) | ((ins << offset) & m);
+}
+RFG uint packUnorm4x8(vec4 v)
+{
+    uint r = 0u;
+    for (int i = 0; i < 4; ++i) r |= (uint)::rintf(clamp(v[i], 0.0f, 1.0f) * 255.0f) << (8 * i);
+    return r;
+}
+RFG vec4 unpackUnorm4x8(uint p) { return vec4{(float)(p & 255u), (float)((p >> 8) & 255u), (float)((p >> 16) & 255u), (float)(p >> 24)} / 255.0f; }
+RFG float determinant(const mat2& m) { return m.c[0].x * m.c[1].y - m.c[1].x * m.c[0].y; }
+RFG float determinant(const mat3& m) { return dot(m.c[0], cross(m.c[1], m.c[2])); }
+RFG mat2 inverse(const mat2& m)
+{
+    const float d = determinant(m);
+    mat2 r;
+    r.c[0] = vec2{m.c[1].y, -m.c[0].y} / d;
+    r.c[1] = vec2{-m.c[1].x, m.c[0].x} / d;
+    return r;
+}
+RFG mat3 inverse(const mat3& m)
+{
+    const float d = determinant(m);
+    mat3 t;      // rows of the inverse = cross products of the columns, over the determinant
+    t.c[0] = cross(m.c[1], m.c[2]) / d;
+    t.c[1] = cross(m.c[2], m.c[0]) / d;
+    t.c[2] = cross(m.c[0], m.c[1]) / d;
+    return transpose(t);
+}
+
 // ---- storage images -------------------------------------------------------------------------------------------------------------
 // `uniform image2D name`: the allocated image the graph wires to the variable's binding.  Coordinates are FRAME coordinates
 // (imageSize = the whole frame); a rank of a row-strip partition holds rows [y_first - ghost, y_last + ghost] of it

@@ -215,6 +215,61 @@ def test_the_user_type_twins_run_on_the_host_match_their_stage_files():
         rf.set_shader_path(old)
 
 
+# ---- == / != on vectors, specialisation constants, integer and packing built-ins --------------------------------------------------------------
+EQUALITY = """#version 450
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform image2D image;
+layout (constant_id = 3) const int MODE = 2;
+#define SAME(a, b) ((a) == (b))
+void main()
+{
+    ivec2 p = ivec2(gl_GlobalInvocationID.xy);
+    if (any(greaterThanEqual(p, imageSize(image)))) return;
+    vec4 c = imageLoad(image, p);
+    bool corner = p == ivec2(0) || p + 1 == imageSize(image);
+    bool e = c.rgb != vec3(0.0) && MODE == 2 ? c.a <= 0.5 == false : SAME(c.r, c.g);
+    int k = (p.x & 1) == 0 ? 1 : 2;
+    if (corner != e) c.a = float(k);
+    for (int i = 0; i != 3; ++i) c[i] += 0.25;
+    if (mat2(1.0) == mat2(1.0, 0.0, 0.0, 1.0)) c.b = 1.0;
+    uint packed = packUnorm4x8(vec4(c.r - 0.25, 0.5, 2.0, -1.0));
+    c.g = unpackUnorm4x8(packed).x + float(bitCount(packed & 0xFFu)) + float(findMSB(uint(p.x + 1))) + float(bitfieldExtract(uint(p.y), 1, 3));
+    imageStore(image, p, c);
+}
+"""
+
+
+def equality(img):
+    f = np.float32
+    H, W, _ = img.shape
+    out = img.copy()
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H))
+    corner = ((xs == 0) & (ys == 0)) | ((xs + 1 == W) & (ys + 1 == H))
+    e = np.where(~np.all(img[..., :3] == 0, axis=-1), ~(img[..., 3] <= f(0.5)), img[..., 0] == img[..., 1])      # a vector != is "any component differs"
+    k = np.where((xs & 1) == 0, 1, 2).astype(f)
+    out[..., 3] = np.where(corner != e, k, img[..., 3])
+    out[..., :3] = img[..., :3] + f(0.25)
+    out[..., 2] = f(1.0)
+    code = np.rint(np.clip(out[..., 0] - f(0.25), 0, 1) * f(255.0)).astype(np.int64)
+    bits = np.array([bin(int(v)).count("1") for v in code.ravel()], f).reshape(code.shape)
+    msb = np.floor(np.log2(xs + 1)).astype(f)
+    out[..., 1] = ((code.astype(f) / f(255.0) + bits) + msb) + ((ys >> 1) & 7).astype(f)
+    return out
+
+
+def test_equality_of_vectors_is_one_bool_and_the_integer_built_ins_work():
+    src = rf.glsl_translate("equality", EQUALITY)
+    assert "rfg_eq(p , mk_ivec2(0)) || rfg_eq(p + 1 , imageSize(image))" in src
+    assert "rfg_ne(c.rgb , mk_vec3(0.0f)) && rfg_eq(MODE , 2) ? rfg_eq(c.a <= 0.5f , false) : SAME(c.r, c.g)" in src
+    assert "#define SAME(a, b) (rfg_eq((a) , (b)))" in src and "static constexpr int MODE = 2 ;" in src and "rfg_ne(i , 3)" in src
+    img = util.synthetic(37, 21, util.F32)
+    img[3, 5, :3] = 0.0
+    img[4, 6, 0] = img[4, 6, 1]
+    o = img.copy()
+    HostShader("equality", EQUALITY).run({"image": o})
+    util.assert_same(o, equality(img), "equality")
+
+
 # ---- combined image samplers (shader.rs:98): texture() through the graph's one sampler (vkutils.rs:358-365) ----------------------------------
 RESAMPLE = """#version 450
 layout (local_size_x = 16, local_size_y = 16) in;

@@ -298,6 +298,16 @@ def test_a_stencil_shader_split_into_row_ranges_gives_the_same_frame(ctx, glsl_d
     util.assert_same(whole, want, "against the oracle (stage-file twin of local_contrast)")
 
 
+def test_equality_of_vectors_and_the_integer_built_ins_on_the_gpu(ctx, glsl_dir):
+    from tests.test_glsl import EQUALITY, equality
+    (glsl_dir / "equality.comp").write_text(EQUALITY)
+    img = util.synthetic(250, 131, util.F32)
+    img[3, 5, :3] = 0.0
+    img[4, 6, 0] = img[4, 6, 1]
+    got = util.run_hip(ctx, "input -> pp -> eq:image -> output\npp: passthrough {}\neq: equality {}", img)
+    util.assert_same(got, equality(img), "equality.comp")
+
+
 # ---- combined image samplers ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("fmt", [util.F32, util.U8], ids=["rgba32f", "rgba8"])
 def test_a_sampler2D_is_filtered_by_the_graphs_sampler(ctx, glsl_dir, fmt):
