@@ -543,15 +543,15 @@ struct Translator {
             const std::string lv = pre + m.name;
             if (m.base == 'b') {
                 if (m.comps != 1) fail(line, "boolean vectors in a uniform block are not supported");
-                bind += "        for (int i = 0; i < " + std::to_string(count) + "; ++i) { unsigned t; __builtin_memcpy(&t, ubo + " + std::to_string(at) + " + i * " + std::to_string(m.stride) +
-                        ", 4); reinterpret_cast<bool*>(&" + lv + ")[i] = t != 0u; }\n";
+                bind += "        for (int rfg_i = 0; rfg_i < " + std::to_string(count) + "; ++rfg_i) { unsigned rfg_t; __builtin_memcpy(&rfg_t, rfg_ubo + " + std::to_string(at) + " + rfg_i * " + std::to_string(m.stride) +
+                        ", 4); reinterpret_cast<bool*>(&" + lv + ")[rfg_i] = rfg_t != 0u; }\n";
             } else if (m.cols > 1) {
                 // a matrix: `cols` columns per element, a column every (stride / cols) bytes
-                bind += "        for (int i = 0; i < " + std::to_string(count * m.cols) + "; ++i) __builtin_memcpy(reinterpret_cast<char*>(&" + lv + ") + i * " + std::to_string(m.comps == 2 ? 8 : 16) + ", ubo + " +
-                        std::to_string(at) + " + i * " + std::to_string(m.stride / m.cols) + ", " + std::to_string(m.comps * 4) + ");\n";
+                bind += "        for (int rfg_i = 0; rfg_i < " + std::to_string(count * m.cols) + "; ++rfg_i) __builtin_memcpy(reinterpret_cast<char*>(&" + lv + ") + rfg_i * " + std::to_string(m.comps == 2 ? 8 : 16) + ", rfg_ubo + " +
+                        std::to_string(at) + " + rfg_i * " + std::to_string(m.stride / m.cols) + ", " + std::to_string(m.comps * 4) + ");\n";
             } else {
-                bind += "        for (int i = 0; i < " + std::to_string(count) + "; ++i) __builtin_memcpy(reinterpret_cast<char*>(&" + lv + ") + i * " + std::to_string(cpp_elem_bytes(m)) + ", ubo + " + std::to_string(at) +
-                        " + i * " + std::to_string(m.dims.empty() ? 0 : m.stride) + ", " + std::to_string(m.comps * 4) + ");\n";
+                bind += "        for (int rfg_i = 0; rfg_i < " + std::to_string(count) + "; ++rfg_i) __builtin_memcpy(reinterpret_cast<char*>(&" + lv + ") + rfg_i * " + std::to_string(cpp_elem_bytes(m)) + ", rfg_ubo + " + std::to_string(at) +
+                        " + rfg_i * " + std::to_string(m.dims.empty() ? 0 : m.stride) + ", " + std::to_string(m.comps * 4) + ");\n";
             }
             m.name = pre + m.name;      // the key the reference's UBO map carries (pipeline_graph.rs:276-292)
         }
@@ -570,7 +570,7 @@ struct Translator {
             for (const auto& m : blk.members)
                 members += "    static_assert(__builtin_offsetof(" + blk.type_name + "_t, " + m.name + ") == " + std::to_string(m.offset) + ", \"" + type + ".comp: the member " + m.name + " of the storage block " +
                            blk.type_name + " does not lie where " + (std140 ? "std140" : "std430") + " puts it (a scalar behind a vec3?): not supported\");\n";
-            bind += "        " + blk.instance + " = static_cast<" + blk.type_name + "_t*>(buf[" + slot + "]);\n";
+            bind += "        " + blk.instance + " = static_cast<" + blk.type_name + "_t*>(rfg_buf[" + slot + "]);\n";
             cx.ssbo_instances.insert(blk.instance);
         }
         for (const auto& m : blk.members) {
@@ -579,7 +579,7 @@ struct Translator {
             if ((arrayish || m.cols > 1) && m.stride != cpp_elem_bytes(m))
                 fail(line, "the member " + m.name + " of the storage block " + blk.type_name + " has a " + std::to_string(m.stride) + "-byte array stride (std140); declare the block std430");
             if (!blk.instance.empty()) continue;
-            const std::string ty = cpp_type(m), at = "static_cast<char*>(buf[" + slot + "]) + " + std::to_string(m.offset);
+            const std::string ty = cpp_type(m), at = "static_cast<char*>(rfg_buf[" + slot + "]) + " + std::to_string(m.offset);
             if (!arrayish) {
                 members += "    " + ty + "* rfg_p_" + m.name + ";\n";
                 bind += "        rfg_p_" + m.name + " = reinterpret_cast<" + ty + "*>(" + at + ");\n";
@@ -732,8 +732,8 @@ struct Translator {
                     if ((int)sh.images.size() >= kGlslMaxImages) fail(v[first].line, "more than " + std::to_string(kGlslMaxImages) + " image variables");
                     for (const auto& o : sh.images)
                         if (o.name == im.name) fail(v[k].line, "the image variable " + im.name + " is declared twice");
-                    members += std::string("    ") + (sampled ? "sampler2D" : "image2D") + "<Px> " + im.name + ";\n";
-                    bind += "        " + im.name + (sampled ? ".im" : "") + " = image2D<Px>{img[" + std::to_string(sh.images.size()) + "].base, img[" + std::to_string(sh.images.size()) + "].pitch, f.W, f.H, f.row_lo, f.row_hi, f.y0, f.y1 - 1, f.zero};\n";
+                    members += std::string("    ") + (sampled ? "sampler2D" : "image2D") + "<RfgPx> " + im.name + ";\n";
+                    bind += "        " + im.name + (sampled ? ".im" : "") + " = image2D<RfgPx>{rfg_img[" + std::to_string(sh.images.size()) + "].base, rfg_img[" + std::to_string(sh.images.size()) + "].pitch, rfg_f.W, rfg_f.H, rfg_f.row_lo, rfg_f.row_hi, rfg_f.y0, rfg_f.y1 - 1, rfg_f.zero};\n";
                     sh.images.push_back(im);
                     blank(v, first, k + 2);
                     i = k + 2;
@@ -840,20 +840,20 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
     }
     std::string s = "\nnamespace rfglsl { namespace " + ident + " {\n";
     s += tr.hoisted;
-    s += "template <class Px> struct Shader {\n"
+    s += "template <class RfgPx> struct RfgShader {\n"
          "    uvec3 gl_NumWorkGroups, gl_WorkGroupID, gl_LocalInvocationID, gl_GlobalInvocationID;\n"
          "    uint gl_LocalInvocationIndex;\n"
          "    const uvec3 gl_WorkGroupSize = uvec3{" + std::to_string(out.lx) + "u, " + std::to_string(out.ly) + "u, " + std::to_string(out.lz) + "u};\n";
     s += tr.members;
     int n_read = 0;
     for (const auto& im : out.images) n_read += im.writeonly ? 0 : 1;
-    s += "    typedef Px PxT;\n";
-    s += "    RFG void rfg_bind(const GlslFrame& f, const GlslImage* img, void* const* buf, const unsigned char* ubo)\n    {\n        (void)f; (void)img; (void)buf; (void)ubo;\n" + tr.bind + "    }\n";
+    s += "    typedef RfgPx PxT;\n";
+    s += "    RFG void rfg_bind(const GlslFrame& rfg_f, const GlslImage* rfg_img, void* const* rfg_buf, const unsigned char* rfg_ubo)\n    {\n        (void)rfg_f; (void)rfg_img; (void)rfg_buf; (void)rfg_ubo;\n" + tr.bind + "    }\n";
     s += "#line 1 \"" + type + ".comp\"\n";
     s += emit(tr.v, 0, tr.v.size());
     s += "\n};\n";
     for (const auto& m : tr.cx.macros) s += "#undef " + m + "\n";
-    s += "struct Info {\n    static constexpr int LX = " + std::to_string(out.lx) + ", LY = " + std::to_string(out.ly) + ", LZ = " + std::to_string(out.lz) + ", NIMG = " + std::to_string(out.images.size()) +
+    s += "struct RfgInfo {\n    static constexpr int LX = " + std::to_string(out.lx) + ", LY = " + std::to_string(out.ly) + ", LZ = " + std::to_string(out.lz) + ", NIMG = " + std::to_string(out.images.size()) +
          ", NBUF = " + std::to_string(out.ssbos.size()) + ", UBO = " + std::to_string(out.ubo_bytes) + ", RADIUS = " + std::to_string(out.radius < 0 ? 0 : out.radius) + ", NREAD = " + std::to_string(n_read) + ";\n    static constexpr bool GROUPED = " +
          (out.grouped ? "true" : "false") + ";\n};\n} }\n";
     out.source = s;

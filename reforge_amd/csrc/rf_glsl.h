@@ -16,7 +16,7 @@
 //   layout(local_size_x = X, local_size_y = Y, local_size_z = Z) in;
 //   #pragma rf radius N     (ignored by a GLSL compiler) rows above / below its own that an invocation reads: what a row-strip
 //                           partition must exchange or over-fetch for the node.  A file without it runs on one GPU only.
-// Translation: globals become members of `template <class Px> struct Shader`, functions its member functions (so every
+// Translation: globals become members of `template <class RfgPx> struct RfgShader`, functions its member functions (so every
 // function sees every uniform, image and built-in variable, in any order); `vecN(...)` constructors become mk_vecN(...),
 // array constructors braces, `out` / `inout` parameters references, literals `float`, `a == b` a call (one bool also for vectors); `shared` variables move in front of
 // the struct as LDS variables; `precise`, precision qualifiers and prototypes go.  Not translated (the file is refused with
@@ -63,7 +63,7 @@ struct GlslShader {
     bool grouped = false;                  // uses workgroup built-ins, shared variables or barrier(): dispatched in the file's own workgroups
     int radius = -1;                       // #pragma rf radius N; -1 = not stated
     int ubo_bytes = 0;
-    std::string source;                    // namespace rfglsl { namespace <ident> { ... Shader<Px> ... Info ... } }
+    std::string source;                    // namespace rfglsl { namespace <ident> { ... RfgShader<Px> ... RfgInfo ... } }
 };
 
 constexpr int kGlslMaxImages = 32, kGlslMaxBuffers = 32, kGlslMaxUniformBytes = 256;

@@ -4,7 +4,7 @@
 // In the reference a filter type IS such a file: shaderc compiles it to SPIR-V (src/vulkan/shader.rs:73-93), spirv-reflect
 // finds its bindings (shader.rs:106-160) and vkCmdDispatch runs ceil(W/16) x ceil(H/16) workgroups of it
 // (src/vulkan/command.rs:166-194).  Here the translator (rf_glsl.cpp) rewrites the shader into a C++ struct template --
-// `template <class Px> struct Shader { <globals as members> <functions as member functions> void main(); }` inside
+// `template <class RfgPx> struct RfgShader { <globals as members> <functions as member functions> void main(); }` inside
 // namespace rfglsl, so that every GLSL name below is found before anything of the HIP headers -- and hiprtc compiles
 // glsl_node_kernel<Px, Shader> at rf_graph_create (rf_jit.cpp), Px = the graph's texel format (rf_device.h: imageLoad /
 // imageStore convert as DESIGN.md 3 says, whatever format qualifier the file carries -- shaders/passthrough.comp:4-5 says
@@ -435,7 +435,7 @@ RFG void memoryBarrierImage() { __threadfence(); }
 RFG void memoryBarrierBuffer() { __threadfence(); }
 RFG void groupMemoryBarrier() { __threadfence_block(); }
 
-// One invocation per thread.  SH = the translated shader (`Shader` of its namespace, a template over the texel format), P = rf::PxF32 /
+// One invocation per thread.  SH = the translated shader (`RfgShader` of its namespace, a template over the texel format), P = rf::PxF32 /
 // rf::PxU8, I = its Info:
 //   I::LX, LY, LZ   local_size of the file
 //   I::GROUPED      the file uses workgroup built-ins, shared variables or barrier(): workgroups are exactly the file's, dispatched

@@ -185,9 +185,9 @@ void cache_store(const std::string& stem, const Compiled& c)
 
 std::string node_expression(int fmt, const UserStage& u)
 {
-    if (u.glsl) {      // {type}.comp: rfglsl::glsl_node_kernel<Shader<texel format>, Info> (rf_glsl_dev.h)
+    if (u.glsl) {      // {type}.comp: rfglsl::glsl_node_kernel<RfgShader, texel format, RfgInfo> (rf_glsl_dev.h)
         const std::string ns = "rfglsl::" + u.ident + "::";
-        return "rfglsl::glsl_node_kernel<" + ns + "Shader, " + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", " + ns + "Info>";
+        return "rfglsl::glsl_node_kernel<" + ns + "RfgShader, " + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", " + ns + "RfgInfo>";
     }
     return std::string("rf::user_node_kernel<") + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", rfuser::" + u.ident + "::Stage>";
 }

@@ -53,11 +53,11 @@ struct PxU8 {
 using namespace rfglsl;
 template <class Px> static void run_all(const GlslFrame& f, const GlslImage* img, void* const* buf, const unsigned char* ubo)
 {
-    typedef @NS@::Info I;
+    typedef @NS@::RfgInfo I;
     for (unsigned gy = 0; gy < (unsigned)(f.groups_y * I::LY); ++gy)
         for (unsigned gx = 0; gx < (unsigned)(f.groups_x * I::LX); ++gx) {
             if ((int)gy < f.y0 || (int)gy >= f.y1) continue;
-            @NS@::Shader<Px> s;
+            @NS@::RfgShader<Px> s;
             s.gl_WorkGroupID = uvec3{gx / I::LX, gy / I::LY, 0u};
             s.gl_LocalInvocationID = uvec3{gx % I::LX, gy % I::LY, 0u};
             s.gl_NumWorkGroups = uvec3{(unsigned)f.groups_x, (unsigned)f.groups_y, 1u};
@@ -67,7 +67,7 @@ template <class Px> static void run_all(const GlslFrame& f, const GlslImage* img
             s.main();
         }
 }
-extern "C" int glsl_info(int* v) { typedef @NS@::Info I; v[0] = I::LX; v[1] = I::LY; v[2] = I::LZ; v[3] = I::NIMG; v[4] = I::NBUF; v[5] = I::UBO; return I::GROUPED ? 1 : 0; }
+extern "C" int glsl_info(int* v) { typedef @NS@::RfgInfo I; v[0] = I::LX; v[1] = I::LY; v[2] = I::LZ; v[3] = I::NIMG; v[4] = I::NBUF; v[5] = I::UBO; return I::GROUPED ? 1 : 0; }
 extern "C" void glsl_run(int u8, const GlslFrame* f, const GlslImage* img, void* const* buf, const unsigned char* ubo)
 {
     if (u8) run_all<host::PxU8>(*f, img, buf, ubo);

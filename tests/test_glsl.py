@@ -52,7 +52,7 @@ def test_every_shipped_shader_translates_and_reflects_like_the_registry():
             for im in r["images"]:      # same variable on the same binding as the hand-written type (shader.rs:151-153)
                 assert rf.registry_binding(t, im["name"]) == im["binding"], (t, im)
         src = rf.glsl_translate(t, text_of(t))
-        assert "struct Shader" in src and "RFG void main()" in src and "#line 1 \"%s.comp\"" % t in src
+        assert "struct RfgShader" in src and "RFG void main()" in src and "#line 1 \"%s.comp\"" % t in src
 
 
 def test_uniform_blocks_follow_std140_and_storage_blocks_std430():
@@ -268,6 +268,33 @@ def test_equality_of_vectors_is_one_bool_and_the_integer_built_ins_work():
     o = img.copy()
     HostShader("equality", EQUALITY).run({"image": o})
     util.assert_same(o, equality(img), "equality")
+
+
+def test_a_shaders_own_names_do_not_meet_the_generated_ones():
+    """the translation wraps the file in a struct with members and a bind function of its own: their names are reserved ones (rfg_*,
+    Rfg*), so a file may call its things Shader, Info, Px, f, img, buf, ubo, i, t, T"""
+    src = """#version 450
+#define f 2.0
+#define T 4
+#define img input_image
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform readonly image2D input_image;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+layout (binding = 2) uniform Params { float ubo; float buf[T]; bool t; };
+struct Shader { float Px; };
+struct Info { vec2 i; };
+void main()
+{
+    ivec2 p = ivec2(gl_GlobalInvocationID.xy);
+    Shader s = Shader(ubo);
+    Info info = Info(vec2(buf[0], t ? 1.0 : 0.0));
+    imageStore(output_image, p, imageLoad(img, p) * f + vec4(s.Px, info.i, 0.0));
+}
+"""
+    img = util.synthetic(33, 17, util.F32)
+    o = np.zeros_like(img)
+    HostShader("names", src).run({"input_image": img, "output_image": o}, {"ubo": 0.5, "t": 1})
+    util.assert_same(o, img * np.float32(2.0) + np.array([0.5, 0.0, 1.0, 0.0], np.float32), "names")
 
 
 # ---- combined image samplers (shader.rs:98): texture() through the graph's one sampler (vkutils.rs:358-365) ----------------------------------
