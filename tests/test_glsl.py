@@ -401,3 +401,39 @@ def test_every_shipped_shader_compiles_for_gfx950(glsl_dir, t):
     text = "\n".join(lines + ["nn: %s {}" % t])
     p = rf.Plan(rf.Config(text))
     assert p.jit_compile(rf.RF_FORMAT_RGBA32F) > 2048 and p.jit_compile(rf.RF_FORMAT_RGBA8) > 2048
+
+
+# ---- the code objects: what makes a many-tap shader fast is that its loads are not waited for one by one ------------------------------------------
+@pytest.mark.parametrize("compiler", ["this process", "a process that imported torch first"])
+def test_glsl_kernels_have_no_scratch_and_batch_their_loads(tmp_path, compiler):
+    """imageLoad is branch-free (rf_glsl_dev.h): a 25-tap shader keeps several loads in flight (counted waits) and drains the queue a handful of times -- under a
+    bounds branch per load every load was waited for before the next one issued (profiles/EXPERIMENTS.md R4.7).  Checked on the
+    disassembled code objects of both compiler builds a process may get (its own libhiprtc, or the one PyTorch bundles)."""
+    import glob
+    import subprocess
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import isa_obj
+    cmd = [_sys.executable, os.path.join(ROOT, "tests", "glsl_isa_compile.py"), str(tmp_path)] + (["torch"] if "torch" in compiler else [])
+    if "torch" in compiler:
+        import importlib.util
+        if importlib.util.find_spec("torch") is None:
+            pytest.skip("no PyTorch here")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "compiled with" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    files = sorted(glob.glob(str(tmp_path / "*.hsaco")))
+    assert len(files) == 10, files      # five graphs x two formats, one GLSL kernel each (passthrough is in the catalogue)
+    many = 0
+    for f in files:
+        notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f], capture_output=True, text=True, check=True).stdout
+        assert ".private_segment_fixed_size: 0" in notes, "a GLSL kernel uses scratch: " + f
+        for name, ins in isa_obj.functions(f).items():
+            if "glsl_node_kernel" not in name:
+                continue
+            loads = [i for i in ins if i.op.startswith("global_load")]
+            waits = [i for i in ins if i.op == "s_waitcnt" and "vmcnt(0)" in i.text]      # full drains (a counted wait leaves younger loads in flight)
+            assert not any(i.op.startswith(("scratch_", "s_barrier")) for i in ins), name
+            if len(loads) >= 20:      # gaussian5 (25 loads) and local_contrast (26): a handful of waits, not one per load
+                many += 1
+                assert len(waits) <= len(loads) // 3, (name, len(loads), len(waits))
+    assert many == 4, many
