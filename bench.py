@@ -107,11 +107,15 @@ WORKLOADS["user_window_4k"] = dict(text="input -> lc -> output\nlc: local_contra
 GLSL_CHAIN3 = CHAIN3.replace("sigma: 1.0 }", "sigma: 1.0, w0: 0.402619958, w1: 0.244201347, w2: 0.0544886850 }")
 WORKLOADS["glsl_chain3_4k"] = dict(text=GLSL_CHAIN3, W=3840, H=2160, fmt=F32, nodes=3, seed=0x5EED0009, radius=3, strong=False, files_first=True,
                                    desc="the headline graph run from the GLSL files (shaders/gaussian5.comp, colour_grade.comp, sharpen.comp), 3840x2160 rgba32f")
+# the headline graph with ONE of its types taken from a GLSL file: colour_grade.comp is recognised as a point shader and becomes a row stage
+# of the stream kernel -- it FUSES with the hand-written gaussian5 and sharpen around it: one launch, as in the headline
+WORKLOADS["glsl_fused_chain3_4k"] = dict(text=CHAIN3, W=3840, H=2160, fmt=F32, nodes=3, seed=0x5EED000B, radius=3, strong=False, files_first=True, glsl_only=("colour_grade",),
+                                         desc="the headline graph with colour_grade taken from shaders/colour_grade.comp (a GLSL point shader fused between hand-written stages), 3840x2160 rgba32f")
 # a point filter from its GLSL file (two images in, two out): the plugin path at its best
 WORKLOADS["glsl_unsharp_4k"] = dict(text="input -> bl -> um:blurred_image\ninput -> um:input_image\num -> output\nbl: passthrough {}\num: unsharp_mask { amount: 1.5, threshold: 0.02 }",
                                     W=3840, H=2160, fmt=F32, nodes=2, seed=0x5EED000A, radius=0, strong=False, files_first=True, glsl_only=("unsharp_mask",), user_types=("unsharp_mask",),
                                     desc="unsharp_mask from shaders/unsharp_mask.comp (GLSL; two input images, one wired output), 3840x2160 rgba32f")
-SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "chain3_8k_u8", "gauss9_8k_u8", "diamond_4k", "user_types_4k", "user_window_4k", "glsl_chain3_4k", "glsl_unsharp_4k"]
+SIDE_WORKLOADS = ["gauss9_8k", "chain5_16k", "conv31_8k", "chain3_4k_u8", "chain3_8k_u8", "gauss9_8k_u8", "diamond_4k", "user_types_4k", "user_window_4k", "glsl_chain3_4k", "glsl_unsharp_4k", "glsl_fused_chain3_4k"]
 
 
 def shader_setup(rf, wl, oracle_too):

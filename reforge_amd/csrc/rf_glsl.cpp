@@ -413,7 +413,7 @@ struct Translator {
     Ctx cx;
     std::vector<Tok> v;
     std::string hoisted;                       // in front of the struct: directives, constants, shared variables
-    std::string members, bind;                 // generated members of Shader and the body of rfg_bind
+    std::string members, bind, bind_ubo;       // generated members of Shader, the body of rfg_bind; bind_ubo: its uniform-block part (shared with rfg_bind_point)
     std::map<std::string, long> int_consts;    // object-like macros and const ints whose value is a literal expression
     std::set<int> bindings;
     bool has_main = false;
@@ -543,14 +543,14 @@ struct Translator {
             const std::string lv = pre + m.name;
             if (m.base == 'b') {
                 if (m.comps != 1) fail(line, "boolean vectors in a uniform block are not supported");
-                bind += "        for (int rfg_i = 0; rfg_i < " + std::to_string(count) + "; ++rfg_i) { unsigned rfg_t; __builtin_memcpy(&rfg_t, rfg_ubo + " + std::to_string(at) + " + rfg_i * " + std::to_string(m.stride) +
+                bind_ubo += "        for (int rfg_i = 0; rfg_i < " + std::to_string(count) + "; ++rfg_i) { unsigned rfg_t; __builtin_memcpy(&rfg_t, rfg_ubo + " + std::to_string(at) + " + rfg_i * " + std::to_string(m.stride) +
                         ", 4); reinterpret_cast<bool*>(&" + lv + ")[rfg_i] = rfg_t != 0u; }\n";
             } else if (m.cols > 1) {
                 // a matrix: `cols` columns per element, a column every (stride / cols) bytes
-                bind += "        for (int rfg_i = 0; rfg_i < " + std::to_string(count * m.cols) + "; ++rfg_i) __builtin_memcpy(reinterpret_cast<char*>(&" + lv + ") + rfg_i * " + std::to_string(m.comps == 2 ? 8 : 16) + ", rfg_ubo + " +
+                bind_ubo += "        for (int rfg_i = 0; rfg_i < " + std::to_string(count * m.cols) + "; ++rfg_i) __builtin_memcpy(reinterpret_cast<char*>(&" + lv + ") + rfg_i * " + std::to_string(m.comps == 2 ? 8 : 16) + ", rfg_ubo + " +
                         std::to_string(at) + " + rfg_i * " + std::to_string(m.stride / m.cols) + ", " + std::to_string(m.comps * 4) + ");\n";
             } else {
-                bind += "        for (int rfg_i = 0; rfg_i < " + std::to_string(count) + "; ++rfg_i) __builtin_memcpy(reinterpret_cast<char*>(&" + lv + ") + rfg_i * " + std::to_string(cpp_elem_bytes(m)) + ", rfg_ubo + " + std::to_string(at) +
+                bind_ubo += "        for (int rfg_i = 0; rfg_i < " + std::to_string(count) + "; ++rfg_i) __builtin_memcpy(reinterpret_cast<char*>(&" + lv + ") + rfg_i * " + std::to_string(cpp_elem_bytes(m)) + ", rfg_ubo + " + std::to_string(at) +
                         " + rfg_i * " + std::to_string(m.dims.empty() ? 0 : m.stride) + ", " + std::to_string(m.comps * 4) + ");\n";
             }
             m.name = pre + m.name;      // the key the reference's UBO map carries (pipeline_graph.rs:276-292)
@@ -824,6 +824,143 @@ struct Translator {
     }
 };
 
+// Is the shader a POINT operation on one image -- every invocation reads only its own texel of one image and writes only its own
+// texel of one image (or of the same one), and nothing it computes depends on where the invocation is?  Then it can run as a ROW
+// STAGE of the stream kernel (StUser, rf_stream_dev.h) and fuse with its neighbours, as a {type}.stage.hip of RADIUS 0 does.
+// Decided on the file's own tokens, conservatively (a file that is not recognised is simply a node with a kernel of its own):
+//   * one readonly + one writeonly image2D, or one image2D that is neither; no storage block, no sampler, no workgroup built-in;
+//     local_size at least 16 x 16 (the reference's dispatch then covers the frame);
+//   * imageLoad / imageStore / imageSize / gl_GlobalInvocationID / the image variables appear in main() only, and not in a #define;
+//   * the coordinate of every imageLoad and imageStore is `ivec2(gl_GlobalInvocationID.xy)` or a variable declared as exactly that;
+//   * such a variable, and one declared `ivec2 S = imageSize(image);`, is otherwise used only in the frame guard
+//     `if (C.x >= S.x || C.y >= S.y) return;` / `if (any(greaterThanEqual(C, S))) return;`.
+bool point_shader(const std::string& text, const GlslShader& sh, std::string& in_name, std::string& out_name)
+{
+    if (sh.grouped || !sh.ssbos.empty() || sh.radius > 0) return false;
+    if (sh.lx < 16 || sh.ly < 16) return false;      // the reference dispatches ceil(W/16) x ceil(H/16) workgroups: a smaller local_size covers part of the frame only
+    for (const auto& im : sh.images)
+        if (im.sampled) return false;
+    if (sh.images.size() == 1 && !sh.images[0].readonly && !sh.images[0].writeonly) in_name = out_name = sh.images[0].name;
+    else if (sh.images.size() == 2 && sh.images[0].readonly != sh.images[1].readonly && sh.images[0].writeonly != sh.images[1].writeonly &&
+             (sh.images[0].readonly || sh.images[0].writeonly) && (sh.images[1].readonly || sh.images[1].writeonly)) {
+        in_name = sh.images[sh.images[0].readonly ? 0 : 1].name;
+        out_name = sh.images[sh.images[0].readonly ? 1 : 0].name;
+    } else return false;
+    std::vector<Tok> t;
+    try {
+        t = lex(text);
+    } catch (const Fail&) {
+        return false;
+    }
+    auto special = [&](const std::string& s) {
+        return s == "gl_GlobalInvocationID" || s == "imageLoad" || s == "imageStore" || s == "imageSize" || s == in_name || s == out_name;
+    };
+    static const char* forbidden[] = {"gl_WorkGroupID", "gl_LocalInvocationID", "gl_LocalInvocationIndex", "gl_NumWorkGroups", "gl_WorkGroupSize"};
+    size_t mb = 0, me = 0;
+    for (size_t i = 0; i + 4 < t.size(); ++i)
+        if (t[i].k == T_ID && t[i].s == "main" && is(t[i + 1], "(") && i > 0 && is(t[i - 1], "void")) {
+            size_t k = match(t, i + 1, t.size()) + 1;
+            if (!is(t[k], "{")) return false;
+            mb = k + 1;
+            me = match(t, k, t.size());
+        }
+    if (me == 0) return false;
+    for (size_t i = 0; i < t.size(); ++i) {
+        if (t[i].k == T_PP) {
+            std::vector<Tok> d = lex(t[i].s.substr(1));
+            for (const auto& q : d)
+                if (q.k == T_ID && special(q.s)) return false;
+            continue;
+        }
+        if (t[i].k != T_ID) continue;
+        for (const char* f : forbidden)
+            if (t[i].s == f) return false;
+        if ((i < mb || i >= me) && special(t[i].s)) {
+            // outside main(): only the declarations of the images themselves (`uniform ... image2D name;`)
+            if ((t[i].s == in_name || t[i].s == out_name) && i > 0 && is(t[i - 1], "image2D")) continue;
+            return false;
+        }
+    }
+    std::vector<char> ok(t.size(), 0);
+    std::set<std::string> coord, size;
+    auto seq = [&](size_t i, std::initializer_list<const char*> pat) {
+        size_t k = i;
+        for (const char* p : pat) {
+            if (k >= me) return false;
+            if (std::string(p) == "$ID") { if (t[k].k != T_ID) return false; }
+            else if (!is(t[k], p)) return false;
+            ++k;
+        }
+        return true;
+    };
+    auto mark = [&](size_t a, size_t b) { for (size_t k = a; k < b; ++k) ok[k] = 1; };
+    // inline coordinate `ivec2 ( gl_GlobalInvocationID . xy )` or `ivec2 ( gl_GlobalInvocationID )` at i: its length, 0 if none
+    auto inline_coord = [&](size_t i) -> size_t {
+        if (seq(i, {"ivec2", "(", "gl_GlobalInvocationID", ".", "xy", ")"})) return 6;
+        if (seq(i, {"ivec2", "(", "gl_GlobalInvocationID", ")"})) return 4;
+        return 0;
+    };
+    for (size_t i = mb; i < me; ++i) {      // declarations of coordinate and size variables
+        if (!is(t[i], "ivec2") || t[i + 1].k != T_ID || !is(t[i + 2], "=")) continue;
+        const size_t n = inline_coord(i + 3);
+        if (n && is(t[i + 3 + n], ";")) { coord.insert(t[i + 1].s); mark(i, i + 4 + n); continue; }
+        if (seq(i + 3, {"imageSize", "(", "$ID", ")", ";"}) && (t[i + 5].s == in_name || t[i + 5].s == out_name)) { size.insert(t[i + 1].s); mark(i, i + 8); }
+    }
+    // a coordinate operand at i: a coordinate variable or the inline form; returns its length
+    auto coord_at = [&](size_t i) -> size_t { return (t[i].k == T_ID && coord.count(t[i].s)) ? 1 : inline_coord(i); };
+    auto size_at = [&](size_t i) -> size_t {
+        if (t[i].k == T_ID && size.count(t[i].s)) return 1;
+        return (seq(i, {"imageSize", "(", "$ID", ")"}) && (t[i + 2].s == in_name || t[i + 2].s == out_name)) ? 4 : 0;
+    };
+    for (size_t i = mb; i < me; ++i) {
+        if (t[i].k != T_ID) continue;
+        if ((t[i].s == "imageLoad" || t[i].s == "imageStore") && is(t[i + 1], "(") && t[i + 2].k == T_ID && is(t[i + 3], ",")) {
+            const bool load = t[i].s == "imageLoad";
+            if (t[i + 2].s != (load ? in_name : out_name)) return false;
+            const size_t n = coord_at(i + 4);
+            if (!n || !is(t[i + 4 + n], load ? ")" : ",")) return false;
+            mark(i, i + 4 + n);
+        } else if (t[i].s == "if" && is(t[i + 1], "(")) {
+            // the frame guard, in one of its two spellings, followed by `return;` or `{ return; }`
+            const size_t close = match(t, i + 1, me);
+            size_t k = close + 1;
+            const bool braces = is(t[k], "{");
+            if (braces) ++k;
+            if (!(is(t[k], "return") && is(t[k + 1], ";") && (!braces || is(t[k + 2], "}")))) continue;
+            size_t q = i + 2;
+            bool guard = false;
+            if (seq(q, {"any", "(", "greaterThanEqual", "("})) {
+                size_t a = q + 4;
+                const size_t n1 = coord_at(a);
+                if (n1 && is(t[a + n1], ",")) {
+                    const size_t n2 = size_at(a + n1 + 1);
+                    guard = n2 && seq(a + n1 + 1 + n2, {")", ")", ")"}) && a + n1 + 1 + n2 + 2 == close;
+                }
+            } else {
+                // C.x >= S.x || C.y >= S.y (either order)
+                auto half = [&](size_t a, char want, size_t& end) {
+                    const size_t n1 = coord_at(a);
+                    if (!n1 || !is(t[a + n1], ".") || t[a + n1 + 1].s != std::string(1, want)) return false;
+                    size_t b = a + n1 + 2;
+                    if (!(is(t[b], ">") && is(t[b + 1], "=") && t[b + 1].ws.empty())) return false;
+                    const size_t n2 = size_at(b + 2);
+                    if (!n2 || !is(t[b + 2 + n2], ".") || t[b + 2 + n2 + 1].s != std::string(1, want)) return false;
+                    end = b + 2 + n2 + 2;
+                    return true;
+                };
+                for (int order = 0; order < 2 && !guard; ++order) {
+                    size_t e1 = 0, e2 = 0;
+                    if (half(q, order ? 'y' : 'x', e1) && is(t[e1], "|") && is(t[e1 + 1], "|") && half(e1 + 2, order ? 'x' : 'y', e2) && e2 == close) guard = true;
+                }
+            }
+            if (guard) mark(i, close + 1);
+        }
+    }
+    for (size_t i = mb; i < me; ++i)
+        if (!ok[i] && t[i].k == T_ID && (special(t[i].s) || coord.count(t[i].s) || size.count(t[i].s))) return false;
+    return true;
+}
+
 }  // namespace
 
 bool glsl_translate(const std::string& type, const std::string& text, const std::string& ident, GlslShader& out, std::string& err)
@@ -848,7 +985,14 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
     int n_read = 0;
     for (const auto& im : out.images) n_read += im.writeonly ? 0 : 1;
     s += "    typedef RfgPx PxT;\n";
-    s += "    RFG void rfg_bind(const GlslFrame& rfg_f, const GlslImage* rfg_img, void* const* rfg_buf, const unsigned char* rfg_ubo)\n    {\n        (void)rfg_f; (void)rfg_img; (void)rfg_buf; (void)rfg_ubo;\n" + tr.bind + "    }\n";
+    s += "    RFG void rfg_bind(const GlslFrame& rfg_f, const GlslImage* rfg_img, void* const* rfg_buf, const unsigned char* rfg_ubo)\n    {\n        (void)rfg_f; (void)rfg_img; (void)rfg_buf; (void)rfg_ubo;\n" + tr.bind_ubo + tr.bind + "    }\n";
+    std::string pin, pout;
+    out.point = point_shader(text, out, pin, pout);
+    if (out.point) {
+        // the shader as a row stage: its image variables hold one texel (image2D<PointPx>, rf_glsl_dev.h)
+        s += "    RFG void rfg_bind_point(const unsigned char* rfg_ubo, vec4 rfg_c)\n    {\n        (void)rfg_ubo;\n" + tr.bind_ubo + "        " + pout + ".value = vec4{0.0f, 0.0f, 0.0f, 0.0f};\n        " + pin +
+             ".value = rfg_c;\n    }\n    RFG vec4 rfg_result() const { return " + pout + ".value; }\n";
+    }
     s += "#line 1 \"" + type + ".comp\"\n";
     s += emit(tr.v, 0, tr.v.size());
     s += "\n};\n";
@@ -856,6 +1000,14 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
     s += "struct RfgInfo {\n    static constexpr int LX = " + std::to_string(out.lx) + ", LY = " + std::to_string(out.ly) + ", LZ = " + std::to_string(out.lz) + ", NIMG = " + std::to_string(out.images.size()) +
          ", NBUF = " + std::to_string(out.ssbos.size()) + ", UBO = " + std::to_string(out.ubo_bytes) + ", RADIUS = " + std::to_string(out.radius < 0 ? 0 : out.radius) + ", NREAD = " + std::to_string(n_read) + ";\n    static constexpr bool GROUPED = " +
          (out.grouped ? "true" : "false") + ";\n};\n} }\n";
+    if (out.point) {
+        const std::string n = std::to_string(out.ubo_bytes > 0 ? out.ubo_bytes : 1);
+        s += "#ifdef RFGLSL_KERNEL\nnamespace rfglsl { namespace " + ident + " {\nstruct RfgParams { unsigned char b[" + n + "]; };\nstruct RfgStage {\n    typedef RfgParams P;\n    static constexpr int R = 0;\n"
+             "    template <class Q> static RFG rf::f4 point(const Q& p, rf::f4 c)\n    {\n        RfgShader<PointPx> s;\n        s.gl_NumWorkGroups = s.gl_WorkGroupID = s.gl_LocalInvocationID = s.gl_GlobalInvocationID = uvec3{0u, 0u, 0u};\n"
+             "        s.gl_LocalInvocationIndex = 0u;\n        s.rfg_bind_point(p.b, vec4{c.x, c.y, c.z, c.w});\n        s.main();\n        const vec4 r = s.rfg_result();\n        return make_float4(r.x, r.y, r.z, r.w);\n    }\n"
+             "    template <class Q> static RFG rf::f4 box(const Q&, const rf::f4 (&n)[3][3]) { return n[1][1]; }\n};\n} }\n"
+             "namespace rfuser { namespace " + ident + " { typedef rfglsl::" + ident + "::RfgStage Stage; } }\n#endif\n";
+    }
     out.source = s;
     return true;
 }
@@ -863,7 +1015,7 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
 std::string glsl_reflection_json(const GlslShader& s)
 {
     auto q = [](const std::string& x) { return "\"" + x + "\""; };
-    std::string j = "{\"local_size\": [" + std::to_string(s.lx) + ", " + std::to_string(s.ly) + ", " + std::to_string(s.lz) + "], \"grouped\": " + (s.grouped ? "true" : "false") +
+    std::string j = std::string("{\"point\": ") + (s.point ? "true" : "false") + ", \"local_size\": [" + std::to_string(s.lx) + ", " + std::to_string(s.ly) + ", " + std::to_string(s.lz) + "], \"grouped\": " + (s.grouped ? "true" : "false") +
                     ", \"radius\": " + std::to_string(s.radius) + ", \"uniform_bytes\": " + std::to_string(s.ubo_bytes) + ", \"images\": [";
     for (size_t i = 0; i < s.images.size(); ++i)
         j += std::string(i ? ", " : "") + "{\"name\": " + q(s.images[i].name) + ", \"binding\": " + std::to_string(s.images[i].binding) + ", \"readonly\": " + (s.images[i].readonly ? "true" : "false") +

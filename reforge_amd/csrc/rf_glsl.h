@@ -62,6 +62,7 @@ struct GlslShader {
     int lx = 1, ly = 1, lz = 1;
     bool grouped = false;                  // uses workgroup built-ins, shared variables or barrier(): dispatched in the file's own workgroups
     int radius = -1;                       // #pragma rf radius N; -1 = not stated
+    bool point = false;                    // recognised as a point operation on one image: also a row stage of the stream kernel (fuses)
     int ubo_bytes = 0;
     std::string source;                    // namespace rfglsl { namespace <ident> { ... RfgShader<Px> ... RfgInfo ... } }
 };

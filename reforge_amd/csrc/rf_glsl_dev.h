@@ -400,6 +400,16 @@ template <class Px> RFG vec4 texture(const sampler2D<Px>& s, vec2 uv)
 }
 template <class Px> RFG vec4 textureLod(const sampler2D<Px>& s, vec2 uv, float) { return texture(s, uv); }      // one level
 
+// A shader the translator recognises as a POINT operation (rf_glsl.cpp, point_shader) also runs as a row stage of the stream kernel:
+// its image variables then hold ONE texel -- the one the stage is handed, the one it hands on -- and the frame guard never fires.
+struct PointPx {};
+template <> struct image2D<PointPx> {
+    mutable vec4 value;
+};
+RFG ivec2 imageSize(const image2D<PointPx>&) { return ivec2{0x7fffffff, 0x7fffffff}; }
+RFG vec4 imageLoad(const image2D<PointPx>& im, ivec2) { return im.value; }
+RFG void imageStore(const image2D<PointPx>& im, ivec2, vec4 v) { im.value = v; }
+
 // what the kernel hands a shader object (GlslArgs below, the oracle's driver on the host)
 struct GlslImage {
     char* base;

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cctype>
 #include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <fstream>
 #include <map>
@@ -212,6 +213,10 @@ bool parse_glsl_stage(const std::string& type, const std::string& text, UserStag
     GlslShader sh;
     if (!glsl_translate(type, text, out.ident, sh, err)) return false;
     out.glsl_source = sh.source;
+    // a point operation on one image: a ROW STAGE of the stream kernel like a {type}.stage.hip of RADIUS 0 -- it fuses with its neighbours
+    // (RF_GLSL_NO_FUSE=1: every .comp file stays a node with a kernel of its own, for A/B measurements and tests of that path)
+    static const bool no_fuse = [] { const char* e = std::getenv("RF_GLSL_NO_FUSE"); return e && std::atoi(e) != 0; }();
+    if (sh.point && !no_fuse) out.multi = false;
     out.radius = sh.radius < 0 ? 0 : sh.radius;
     out.radius_stated = sh.radius >= 0;
     out.glsl_grouped = sh.grouped;

@@ -9,7 +9,7 @@
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 TAG="$1"; shift
-WORKLOADS="${@:-chain3_4k chain3_4k_cold chain3_4k_unfused gauss9_8k chain5_16k conv31_8k_valu conv31_8k_mfma chain3_4k_u8 chain3_8k_u8 gauss9_8k_u8 diamond_4k user_types_4k user_window_4k glsl_chain3_4k glsl_unsharp_4k}"
+WORKLOADS="${@:-chain3_4k chain3_4k_cold chain3_4k_unfused gauss9_8k chain5_16k conv31_8k_valu conv31_8k_mfma chain3_4k_u8 chain3_8k_u8 gauss9_8k_u8 diamond_4k user_types_4k user_window_4k glsl_chain3_4k glsl_unsharp_4k glsl_fused_chain3_4k}"
 export TMPDIR=/tmp
 OUT="$ROOT/gpurun_out/prof"
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -23,7 +23,7 @@ for wl in $WORKLOADS; do
     conv31_8k_mfma)   name=conv31_8k; extra="$extra --conv-path 2" ;;
   esac
   case "$name" in
-    chain3_4k|chain3_4k_u8|diamond_4k|user_types_4k|user_window_4k|glsl_chain3_4k|glsl_unsharp_4k)  steps=40; fps=8; psteps=4 ;;
+    chain3_4k|chain3_4k_u8|diamond_4k|user_types_4k|user_window_4k|glsl_chain3_4k|glsl_unsharp_4k|glsl_fused_chain3_4k)  steps=40; fps=8; psteps=4 ;;
     gauss9_8k|chain3_8k_u8|gauss9_8k_u8)  steps=20; fps=4; psteps=3 ;;
     chain5_16k) steps=5;  fps=2; psteps=2 ;;
     conv31_8k)  steps=5;  fps=1; psteps=2 ;;

@@ -215,6 +215,58 @@ def test_the_user_type_twins_run_on_the_host_match_their_stage_files():
         rf.set_shader_path(old)
 
 
+# ---- point shaders are row stages: they fuse with their neighbours ----------------------------------------------------------------------------
+GAIN = """#version 450
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform readonly image2D input_image;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+layout (binding = 2) uniform Params { float gain; float bias; };
+void main()
+{
+    ivec2 size = imageSize(output_image);
+    ivec2 p = ivec2(gl_GlobalInvocationID.xy);
+    if (p.x >= size.x || p.y >= size.y) return;
+    vec4 c = imageLoad(input_image, p);
+    imageStore(output_image, p, vec4(c.rgb * gain + bias, c.a));
+}
+"""
+NOT_POINT = {
+    "reads a neighbour": GAIN.replace("imageLoad(input_image, p)", "imageLoad(input_image, p + ivec2(1, 0))"),
+    "uses its position": GAIN.replace("c.rgb * gain + bias", "c.rgb * gain + bias * float(p.x)"),
+    "returns early by position": GAIN.replace("    vec4 c =", "    if (p.x < 10) return;\n    vec4 c ="),
+    "coordinate through a macro": GAIN.replace("void main()", "#define HERE ivec2(gl_GlobalInvocationID.xy)\nvoid main()").replace("imageLoad(input_image, p)", "imageLoad(input_image, HERE)"),
+    "loads in a helper": GAIN.replace("void main()", "vec4 get(ivec2 q) { return imageLoad(input_image, q); }\nvoid main()").replace("imageLoad(input_image, p);", "get(p);"),
+    "stores elsewhere": GAIN.replace("imageStore(output_image, p,", "imageStore(output_image, size - 1 - p,"),
+    "uses the frame size": GAIN.replace("c.rgb * gain + bias", "c.rgb * gain + bias / float(size.x)"),
+    "a local_size that covers part of the frame": GAIN.replace("local_size_x = 16", "local_size_x = 8"),
+    "a second input": GAIN.replace("layout (binding = 2)", "layout (binding = 3, rgba32f) uniform readonly image2D other_image;\nlayout (binding = 2)"),
+}
+
+
+def test_point_shaders_are_recognised_conservatively():
+    assert rf.glsl_reflect("gain", GAIN)["point"]
+    assert rf.glsl_reflect("gain", GAIN.replace("if (p.x >= size.x || p.y >= size.y) return;", "if (any(greaterThanEqual(p, imageSize(input_image)))) { return; }"))["point"]
+    assert rf.glsl_reflect("gain", GAIN.replace("    ivec2 size = imageSize(output_image);\n", "").replace("    if (p.x >= size.x || p.y >= size.y) return;\n", ""))["point"]      # the reference's passthrough has no guard
+    for why, text in NOT_POINT.items():
+        assert not rf.glsl_reflect("gain", text)["point"], why
+    point = {t for t in COMP if rf.glsl_reflect(t, text_of(t))["point"]}
+    assert point == {"colour_grade", "colour_grade_inplace", "invert", "pulse"}, point
+
+
+def test_a_point_shader_fuses_with_its_neighbours(glsl_dir):
+    rf.set_type_lookup(False)
+    (glsl_dir / "gain.comp").write_text(GAIN)
+    shutil.copy(os.path.join(SHADERS, "invert.comp"), glsl_dir / "invert.comp")
+    (glsl_dir / "shifted.comp").write_text(NOT_POINT["reads a neighbour"])
+    text = "input -> gg -> gn -> iv -> sh -> output\ngg: gaussian5 { sigma: 1.0 }\ngn: gain { gain: 1.25, bias: -0.125 }\niv: invert { enabled: true, strength: 0.5 }\nsh: sharpen { amount: 0.5 }"
+    p = rf.Plan(rf.Config(text))
+    assert p.launches() == ["gg+gn+iv+sh"] and p.needs_jit() == [True]      # ONE launch: two GLSL files between two hand-written stencils
+    assert p.jit_compile(rf.RF_FORMAT_RGBA32F) > 8192 and p.jit_compile(rf.RF_FORMAT_RGBA8) > 8192
+    q = rf.Plan(rf.Config(text.replace("gn: gain", "gn: shifted")))
+    assert q.launches() == ["gg", "gn", "iv+sh"]                             # a shader that is not a point operation keeps a kernel of its own
+    assert rf.Plan(rf.Config(text), rf.RF_GRAPH_NO_FUSION).launches() == ["gg", "gn", "iv", "sh"]
+
+
 # ---- == / != on vectors, specialisation constants, integer and packing built-ins --------------------------------------------------------------
 EQUALITY = """#version 450
 layout (local_size_x = 16, local_size_y = 16) in;

@@ -298,6 +298,34 @@ def test_a_stencil_shader_split_into_row_ranges_gives_the_same_frame(ctx, glsl_d
     util.assert_same(whole, want, "against the oracle (stage-file twin of local_contrast)")
 
 
+@pytest.mark.parametrize("fmt", [util.F32, util.U8], ids=["rgba32f", "rgba8"])
+def test_point_shaders_fused_between_hand_written_stages(ctx, glsl_dir, fmt):
+    """gaussian5 -> gain.comp -> invert.comp -> sharpen as ONE launch (the two files are row stages of the stream kernel), against the
+    same graph node by node and against the oracle's restatement of each node (invert: its stage-file twin compiled for the host)"""
+    from oracle import pixel
+    from tests.test_glsl import GAIN
+    rf.set_type_lookup(False)
+    (glsl_dir / "gain.comp").write_text(GAIN)
+    use(glsl_dir, "invert")
+    text = "input -> gg -> gn -> iv -> sh -> output\ngg: gaussian5 { sigma: 1.0 }\ngn: gain { gain: 1.25, bias: -0.125 }\niv: invert { enabled: true, strength: 0.5 }\nsh: sharpen { amount: 0.5 }"
+    assert rf.Plan(rf.Config(text)).launches() == ["gg+gn+iv+sh"]
+    if "user" not in ograph.NODE_TYPES.get("invert", {}):
+        ograph.register_user_type("invert", os.path.join(SHADERS, "invert.stage.hip"))
+    f = np.float32
+    for W, H in ((250, 131), (64, 4), (17, 13), (1, 1)):
+        img = util.synthetic(W, H, fmt, seed=0x71 + W)
+        a = pixel.gaussian(img, 2, sigma=1.0)
+        af = a.astype(f) / f(255.0) if fmt == util.U8 else a
+        b = af.copy()
+        b[..., :3] = af[..., :3] * f(1.25) + f(-0.125)
+        if fmt == util.U8:      # the node boundary of an rgba8 graph: store as UNORM8 (clamp, x 255, round to nearest even)
+            b = np.rint(np.clip(b, 0, 1) * f(255.0)).astype(np.uint8)
+        want = util.run_oracle("input -> iv -> sh -> output\niv: invert { enabled: true, strength: 0.5 }\nsh: sharpen { amount: 0.5 }", b)
+        fused = util.run_hip(ctx, text, img)
+        util.assert_same(fused, want, "fused %dx%d" % (W, H))
+        util.assert_same(util.run_hip(ctx, text, img, flags=rf.RF_GRAPH_NO_FUSION), want, "node by node %dx%d" % (W, H))
+
+
 def test_equality_of_vectors_and_the_integer_built_ins_on_the_gpu(ctx, glsl_dir):
     from tests.test_glsl import EQUALITY, equality
     (glsl_dir / "equality.comp").write_text(EQUALITY)
