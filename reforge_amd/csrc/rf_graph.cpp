@@ -11,6 +11,7 @@
 #include "rf_rccl_abi.h"
 #include "rf_runtime.h"
 #include "rf_user.h"
+#include "rf_glsl.h"
 #include "rf_user_dev.h"
 
 using namespace rf;
@@ -219,9 +220,20 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     // the launch that runs the frame's last row also runs the invocations below it that the dispatch covers (they exist in the
     // reference; their image accesses fall outside the frame and are dropped, their storage-block writes are not)
     if (fr.y1 == fr.H) fr.y1 = std::max(fr.H, fr.groups_y * u->glsl_groups[1]);
-    std::vector<unsigned char> args(sizeof(Frame));
-    std::memcpy(args.data(), &fr, sizeof(Frame));
-    auto push = [&](const void* p, size_t n) { args.insert(args.end(), static_cast<const unsigned char*>(p), static_cast<const unsigned char*>(p) + n); };
+    // the kernel's argument block (GlslArgs): 48 + 16 x 32 + 8 x 32 + 256 bytes at most, built on the stack every frame
+    struct ArgBlock {
+        alignas(8) unsigned char b[sizeof(Frame) + 16 * kGlslMaxImages + 8 * kGlslMaxBuffers + kGlslMaxUniformBytes + 8];
+        size_t n = 0;
+        unsigned char* data() { return b; }
+        size_t size() const { return n; }
+    } args;
+    bool fits = true;
+    auto push = [&](const void* p, size_t n) {
+        if (args.n + n > sizeof(args.b)) { fits = false; return; }
+        std::memcpy(args.b + args.n, p, n);
+        args.n += n;
+    };
+    push(&fr, sizeof(Frame));
     const size_t n_img = std::max<size_t>(u->glsl_images.size(), 1);
     for (size_t i = 0; i < n_img; ++i) {
         struct { char* base; unsigned long long pitch; } im{nullptr, 0ull};
@@ -265,6 +277,7 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     const size_t ubo = std::max<size_t>(((size_t)u->params_size + 7) / 8 * 8, 8);
     if (ubo > sizeof(op.user_params)) return hipErrorInvalidValue;
     push(op.user_params, ubo);
+    if (!fits) return hipErrorInvalidValue;
     if (u->glsl_grouped) {
         const unsigned threads = (unsigned)(u->glsl_groups[0] * u->glsl_groups[1] * u->glsl_groups[2]);
         return jit_launch(*k, (unsigned)fr.groups_x * (unsigned)fr.groups_y, threads, args.data(), args.size(), stream);
