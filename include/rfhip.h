@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RF_ABI_VERSION 3
+#define RF_ABI_VERSION 4
 
 typedef enum rf_status {
     RF_OK              = 0,

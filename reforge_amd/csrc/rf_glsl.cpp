@@ -987,7 +987,11 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
     s += "    typedef RfgPx PxT;\n";
     s += "    RFG void rfg_bind(const GlslFrame& rfg_f, const GlslImage* rfg_img, void* const* rfg_buf, const unsigned char* rfg_ubo)\n    {\n        (void)rfg_f; (void)rfg_img; (void)rfg_buf; (void)rfg_ubo;\n" + tr.bind_ubo + tr.bind + "    }\n";
     std::string pin, pout;
-    out.point = point_shader(text, out, pin, pout);
+    try {
+        out.point = point_shader(text, out, pin, pout);
+    } catch (const Fail&) {      // (a bracket the analysis could not pair: not recognised, that is all)
+        out.point = false;
+    }
     if (out.point) {
         // the shader as a row stage: its image variables hold one texel (image2D<PointPx>, rf_glsl_dev.h)
         s += "    RFG void rfg_bind_point(const unsigned char* rfg_ubo, vec4 rfg_c)\n    {\n        (void)rfg_ubo;\n" + tr.bind_ubo + "        " + pout + ".value = vec4{0.0f, 0.0f, 0.0f, 0.0f};\n        " + pin +

@@ -895,7 +895,7 @@ bool build_launches(const Plan& plan, std::vector<LaunchDesc>& out, std::string&
             }
             bool all_point = true;
             std::vector<Op> ops = ops_of_members(plan, L.members, L.member_slot, nullptr);
-            for (const auto& o : ops) all_point = all_point && point_kind(o.kind) && !(o.kind == OP_USERN && o.radius > 0);
+            for (const auto& o : ops) all_point = all_point && (point_kind(o.kind) || (o.kind == OP_USER && o.radius == 0)) && !(o.kind == OP_USERN && o.radius > 0);      // (OP_USER of radius 0: a point stage -- a .comp point shader may be declared in place)
             L.radius = ops_radius(ops.data(), (int)ops.size());
             bool reads_what_it_writes = false;
             for (const auto& sname : L.src)

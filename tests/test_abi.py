@@ -43,7 +43,7 @@ def test_library_does_not_depend_on_the_oracle_or_torch():
 
 
 def test_abi_version_and_error_channel():
-    assert rf.lib().rf_abi_version() == 3
+    assert rf.lib().rf_abi_version() == 4
     with pytest.raises(rf.RfError) as e:
         rf.Config("input -> aa")
     assert e.value.status == 2 and "'output' is never used" in str(e.value)

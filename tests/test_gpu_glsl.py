@@ -72,6 +72,8 @@ def test_a_graph_run_through_the_glsl_files_matches_the_oracle(ctx, glsl_dir, na
         want = util.run_oracle(text, img)
         got = util.run_hip(ctx, text, img)
         util.assert_same(got, want, "%s %dx%d" % (name, W, H))
+        if W == 250:      # node by node: a point shader alone in its launch (colour_grade_inplace: the stream kernel reading and writing one image)
+            util.assert_same(util.run_hip(ctx, text, img, flags=rf.RF_GRAPH_NO_FUSION), want, "%s node by node" % name)
 
 
 def test_the_files_are_what_ran(ctx, glsl_dir):
