@@ -733,7 +733,7 @@ struct Translator {
                     for (const auto& o : sh.images)
                         if (o.name == im.name) fail(v[k].line, "the image variable " + im.name + " is declared twice");
                     members += std::string("    ") + (sampled ? "sampler2D" : "image2D") + "<RfgPx> " + im.name + ";\n";
-                    bind += "        " + im.name + (sampled ? ".im" : "") + " = image2D<RfgPx>{rfg_img[" + std::to_string(sh.images.size()) + "].base, rfg_img[" + std::to_string(sh.images.size()) + "].pitch, rfg_f.W, rfg_f.H, rfg_f.row_lo, rfg_f.row_hi, rfg_f.y0, rfg_f.y1 - 1, rfg_f.zero};\n";
+                    bind += "        " + im.name + (sampled ? ".im" : "") + " = image2D<RfgPx>{rfg_img[" + std::to_string(sh.images.size()) + "].base, rfg_img[" + std::to_string(sh.images.size()) + "].pitch, rfg_f.W, rfg_f.H, rfg_f.row_lo, rfg_f.row_hi, rfg_f.y0, rfg_f.y1 - 1, rfg_f.zero};\n        " + im.name + (sampled ? ".im" : "") + ".finish();\n";
                     sh.images.push_back(im);
                     blank(v, first, k + 2);
                     i = k + 2;

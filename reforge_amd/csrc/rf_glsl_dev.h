@@ -21,6 +21,7 @@
 
 #if defined(__HIPCC_RTC__) || defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 #define RFG __device__ __forceinline__
+#define RFGLSL_BUFFER_LOADS 1
 #else
 #include <math.h>
 #include <string.h>
@@ -351,6 +352,18 @@ template <class Px> struct image2D {
     int W, H, row_lo, row_hi;     // frame size; frame rows this rank may read
     int wr_lo, wr_hi;             // frame rows this LAUNCH writes, inclusive (the whole frame on one GPU; a strip's rows, or one part of a split launch)
     const char* zero;             // 16 zero bytes: what a load outside the image reads
+#ifdef RFGLSL_BUFFER_LOADS
+    // the image as a BUFFER RESOURCE: base = frame row 0, range = up to the last readable row.  A load is then one 32-bit byte
+    // offset (no 64-bit address arithmetic), and an offset outside the range -- which is where a load outside the image is sent --
+    // returns zero by the hardware's own range check: what Vulkan's robust access gives.  Images below 4 GiB only (Px::BUFFER).
+    __amdgpu_buffer_rsrc_t rsrc;
+    RFG void finish()
+    {
+        if constexpr (Px::BUFFER) rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (unsigned)((unsigned)(row_hi + 1) * (unsigned)pitch), 0x00020000);
+    }
+#else
+    RFG void finish() {}
+#endif
 };
 template <class Px> RFG ivec2 imageSize(const image2D<Px>& im) { return ivec2{im.W, im.H}; }
 // BRANCH-FREE: the coordinates are clamped into what may be read, the texel is loaded whatever they were, and a load outside
@@ -363,6 +376,21 @@ template <class Px> RFG vec4 imageLoad(const image2D<Px>& im, ivec2 p)
     const bool in_frame = (unsigned)p.x < (unsigned)im.W && (unsigned)(p.y - im.row_lo) <= (unsigned)(im.row_hi - im.row_lo);
     // rows are frame rows (>= 0 wherever they may be read) and a pitch is below 4 GiB: one 32 x 32 -> 64 bit multiply-add.  A load
     // outside the image reads the zero texel the graph keeps for that (one select on the address; no clamps, no select on the result)
+#ifdef RFGLSL_BUFFER_LOADS
+    if constexpr (Px::BUFFER) {
+        const unsigned off = in_frame ? (unsigned)p.y * (unsigned)im.pitch + (unsigned)p.x * (unsigned)Px::BPP : 0xffffffffu;
+        typename Px::Raw raw;
+        if constexpr (Px::BPP == 16) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(im.rsrc, (int)off, 0, 0);
+            __builtin_memcpy(&raw, &v, 16);
+        } else {
+            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(im.rsrc, (int)off, 0, 0);
+            __builtin_memcpy(&raw, &v, 4);
+        }
+        const auto t = Px::decode(raw);
+        return vec4{t.x, t.y, t.z, t.w};
+    }
+#endif
     const char* at = im.base + ((unsigned long long)(unsigned)p.y * (unsigned long long)(unsigned)im.pitch + (unsigned long long)((unsigned)p.x * (unsigned)Px::BPP));
     const auto t = Px::decode(Px::load(in_frame ? at : im.zero, 0u));
     return vec4{t.x, t.y, t.z, t.w};
@@ -434,7 +462,8 @@ struct GlslFrame {
 namespace rfglsl {
 
 // Texel formats with the constructor imageStore needs (rf_device.h)
-template <class P> struct GPx : P {      // the texel formats of rf_device.h with the constructor imageStore needs
+template <class P, bool BUF> struct GPx : P {      // the texel formats of rf_device.h with the constructor imageStore needs
+    static constexpr bool BUFFER = BUF;            // imageLoad through buffer resources (images below 4 GiB)
     RFG static rf::f4 texel(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
 };
 
@@ -461,10 +490,10 @@ template <class I> struct GlslArgs {
     unsigned char ubo[I::UBO > 0 ? (I::UBO + 7) / 8 * 8 : 8];
 };
 
-template <template <class> class SH, class P, class I>
+template <template <class> class SH, class P, class I, bool BUF>
 __global__ __launch_bounds__(I::GROUPED ? I::LX * I::LY * I::LZ : 256) void glsl_node_kernel(GlslArgs<I> A)
 {
-    typedef SH<GPx<P>> S;
+    typedef SH<GPx<P, BUF>> S;
     S s;
     uvec3 wg, lid;
     if constexpr (I::GROUPED) {

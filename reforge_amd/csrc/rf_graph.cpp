@@ -290,6 +290,12 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     return jit_launch(*k, (unsigned)((tiles + 7) / 8 * 8), 256, args.data(), args.size(), stream);
 }
 
+// an image of this graph spans 4 GiB or more (16384^2 rgba32f): beyond a 32-bit byte offset
+static bool wide_images(const rf_graph* g)
+{
+    return image_pitch((size_t)g->opt.width * bytes_per_pixel(g->opt.format)) * (size_t)g->opt.height >= 0xFFFFFFF0ull;
+}
+
 // a user NODE (rf_user.h, a stage file that declares its images): user_node_kernel of rf_user_dev.h, compiled at graph creation
 static hipError_t launch_user_node(rf_graph* g, const Launch& L, FrameSlot& f, const Geom& geo, hipStream_t stream)
 {
@@ -297,7 +303,7 @@ static hipError_t launch_user_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     const int fmt = g->opt.format;
     const Op& op = L.ops[0];
     const UserStage* u = user_stage_by_id(op.user_id);
-    const JitKernel* k = jit_lookup_user_node(fmt, op.user_id);
+    const JitKernel* k = jit_lookup_user_node(fmt, op.user_id, wide_images(g));
     if (!u || !k || L.src.size() != u->inputs.size()) return hipErrorInvalidDeviceFunction;      // graph_build compiled it: cannot happen
     if (u->glsl) return launch_glsl_node(g, L, f, geo, stream, u, k);
     UserNodeArgs A;
@@ -694,7 +700,7 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
             for (const auto& o : ops) has_user = has_user || o.kind == OP_USER;
             if (ops.size() == 1 && ops[0].kind == OP_USERN) {
                 // a user NODE (its file declares its images): a kernel of its own, rf_user_dev.h
-                if (user_only && !jit_compile_user_node(opt.format, ops[0].user_id, jerr)) return false;
+                if (user_only && !jit_compile_user_node(opt.format, ops[0].user_id, jerr, wide_images(g))) return false;
                 continue;
             }
             if (user_only ? !has_user : (ops.size() < 2 && !has_user)) continue;      // single built-in nodes are in the catalogue

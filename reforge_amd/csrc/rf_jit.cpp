@@ -183,11 +183,18 @@ void cache_store(const std::string& stem, const Compiled& c)
     if (write_file_atomically(stem + ".hsaco", c.code.data(), c.code.size())) (void)write_file_atomically(stem + ".name", name.data(), name.size());
 }
 
-std::string node_expression(int fmt, const UserStage& u)
+// RF_GLSL_BUFFER_LOADS=0: .comp nodes address their texels with 64-bit pointers whatever the image size (A/B measurements)
+bool glsl_buffer_loads()
+{
+    static const bool on = [] { const char* e = std::getenv("RF_GLSL_BUFFER_LOADS"); return !(e && *e && std::atoi(e) == 0); }();
+    return on;
+}
+
+std::string node_expression(int fmt, const UserStage& u, bool wide = false)
 {
     if (u.glsl) {      // {type}.comp: rfglsl::glsl_node_kernel<RfgShader, texel format, RfgInfo> (rf_glsl_dev.h)
         const std::string ns = "rfglsl::" + u.ident + "::";
-        return "rfglsl::glsl_node_kernel<" + ns + "RfgShader, " + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", " + ns + "RfgInfo>";
+        return "rfglsl::glsl_node_kernel<" + ns + "RfgShader, " + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", " + ns + "RfgInfo, " + (wide || !glsl_buffer_loads() ? "false" : "true") + ">";
     }
     return std::string("rf::user_node_kernel<") + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", rfuser::" + u.ident + "::Stage>";
 }
@@ -356,13 +363,13 @@ bool jit_compile(int fmt, int pf, int texels, const StageList& sl, int waves_per
 }
 
 // ---- user nodes (rf_user_dev.h): user_node_kernel<Px, rfuser::<ident>::Stage>, 256 threads per workgroup ----------------
-bool jit_compile_user_node(int fmt, int user_id, std::string& err)
+bool jit_compile_user_node(int fmt, int user_id, std::string& err, bool wide)
 {
     std::lock_guard<std::mutex> lock(g_mu);
     const UserStage* u = user_stage_by_id(user_id);
     if (!u || !u->multi) { err = "not a user node"; return false; }
     if (!u->glsl && !u->buf_out.empty() && !load_expr(fill_expression(*u), {user_id}, 1, 4, err)) return false;      // RF_BUFFER_OUT: its fill kernel
-    return load_expr(node_expression(fmt, *u), {user_id}, 1, 4, err);
+    return load_expr(node_expression(fmt, *u, wide), {user_id}, 1, 4, err);
 }
 
 const JitKernel* jit_lookup_user_fill(int user_id)
@@ -374,12 +381,12 @@ const JitKernel* jit_lookup_user_fill(int user_id)
     return it == g_loaded.end() ? nullptr : &it->second;
 }
 
-const JitKernel* jit_lookup_user_node(int fmt, int user_id)
+const JitKernel* jit_lookup_user_node(int fmt, int user_id, bool wide)
 {
     std::lock_guard<std::mutex> lock(g_mu);
     const UserStage* u = user_stage_by_id(user_id);
     if (!u) return nullptr;
-    auto it = g_loaded.find(loaded_key(node_expression(fmt, *u)));
+    auto it = g_loaded.find(loaded_key(node_expression(fmt, *u, wide)));
     return it == g_loaded.end() ? nullptr : &it->second;
 }
 

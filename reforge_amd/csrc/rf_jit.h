@@ -39,8 +39,9 @@ int jit_compile_count();
 size_t jit_compile_only(int fmt, int pf, int texels, const StageList& sl, int waves_per_block, std::string& err);
 // user NODES (a stage file that declares its images, rf_user.h): user_node_kernel<Px, Stage> of rf_user_dev.h, launched with
 // 256 threads per workgroup and a UserNodeArgs block
-bool jit_compile_user_node(int fmt, int user_id, std::string& err);
-const JitKernel* jit_lookup_user_node(int fmt, int user_id);
+// wide: the node's images are 4 GiB or larger (a .comp node then addresses its texels with 64-bit pointers instead of buffer loads with a 32-bit offset)
+bool jit_compile_user_node(int fmt, int user_id, std::string& err, bool wide = false);
+const JitKernel* jit_lookup_user_node(int fmt, int user_id, bool wide = false);
 const JitKernel* jit_lookup_user_fill(int user_id);      // user_fill_kernel<Stage> of a node that declares RF_BUFFER_OUT
 size_t jit_compile_only_user_node(int fmt, int user_id, std::string& err);
 

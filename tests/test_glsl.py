@@ -482,7 +482,7 @@ def test_glsl_kernels_have_no_scratch_and_batch_their_loads(tmp_path, compiler):
         for name, ins in isa_obj.functions(f).items():
             if "glsl_node_kernel" not in name:
                 continue
-            loads = [i for i in ins if i.op.startswith("global_load")]
+            loads = [i for i in ins if i.op.startswith(("global_load", "buffer_load"))]
             waits = [i for i in ins if i.op == "s_waitcnt" and "vmcnt(0)" in i.text]      # full drains (a counted wait leaves younger loads in flight)
             assert not any(i.op.startswith(("scratch_", "s_barrier")) for i in ins), name
             if len(loads) >= 20:      # gaussian5 (25 loads) and local_contrast (26): a handful of waits, not one per load
