@@ -338,6 +338,34 @@ def test_equality_of_vectors_and_the_integer_built_ins_on_the_gpu(ctx, glsl_dir)
     util.assert_same(got, equality(img), "equality.comp")
 
 
+def test_a_shader_on_a_frame_of_four_gibibytes(ctx, glsl_dir):
+    """16384 x 16384 rgba32f: an image is exactly 4 GiB, beyond a 32-bit byte offset -- the kernel variant with 64-bit addresses; rows
+    at both ends of the frame against the input generator"""
+    from oracle import pixel
+    (glsl_dir / "shift.comp").write_text("""#version 450
+#pragma rf radius 0
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform readonly image2D input_image;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); imageStore(output_image, p, imageLoad(input_image, p + ivec2(1, 0)) + vec4(0.5)); }
+""")
+    assert not rf.glsl_reflect("shift", (glsl_dir / "shift.comp").read_text())["point"]
+    W = H = 16384
+    g = rf.Graph(ctx, rf.Config("input -> sf -> output\nsf: shift {}"), W, H, util.F32)
+    try:
+        g.fill_synthetic(0x5EED0042)
+        g.execute()
+        g.wait()
+        for y0, y1 in ((0, 2), (8191, 8193), (H - 2, H)):
+            src = pixel.fill_synthetic(W, y1 - y0, util.F32, 0x5EED0042, y0=y0)
+            want = np.zeros_like(src)
+            want[:, :-1] = src[:, 1:]      # the texel to the right; beyond the frame's last column: zero
+            want += np.float32(0.5)
+            util.assert_same(g.download_rows(y0, y1), want, "rows %d..%d" % (y0, y1))
+    finally:
+        g.close()
+
+
 # ---- combined image samplers ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("fmt", [util.F32, util.U8], ids=["rgba32f", "rgba8"])
 def test_a_sampler2D_is_filtered_by_the_graphs_sampler(ctx, glsl_dir, fmt):
