@@ -78,6 +78,8 @@ typedef struct rf_graph  rf_graph;   /* PipelineGraph + its frames  pipeline_gra
                                            exchange (how the multi-rank split is tested on one GPU) */
 #define RF_EXEC_NO_ALTERNATE      0x8u  /* every chunk walks top-down (default: chosen per launch)      */
 #define RF_EXEC_ALTERNATE         0x20u /* odd chunks walk bottom-up (halo rows shared through L2)      */
+#define RF_EXEC_GLSL_NO_WINDOW    0x40u /* a {type}.comp stencil runs on its generic kernel only (the
+                                          * LDS-tiled window kernel is what rf_graph_create checks it against) */
 
 typedef struct rf_graph_options {
     int       width;        /* RenderInfo.width   src/render.rs:40 */

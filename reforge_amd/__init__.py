@@ -12,7 +12,7 @@ PipelineGraph (src/vulkan/pipeline_graph.rs), Render / RenderInfo
 """
 from ._lib import (RF_FORMAT_RGBA8, RF_FORMAT_RGBA32F, RF_GRAPH_TIMERS, RF_GRAPH_NO_FUSION,
                    RF_GRAPH_HIPGRAPH, RF_GRAPH_NO_HALO_XCHG, RF_GRAPH_NO_JIT, RF_EXEC_SYNC_LAUNCHES, RF_EXEC_CONCURRENT_LAYERS,
-                   RF_EXEC_FORCE_SPLIT, RF_EXEC_NO_ALTERNATE, RF_EXEC_ALTERNATE, RF_CONV_AUTO, RF_CONV_TILE,
+                   RF_EXEC_FORCE_SPLIT, RF_EXEC_NO_ALTERNATE, RF_EXEC_ALTERNATE, RF_EXEC_GLSL_NO_WINDOW, RF_CONV_AUTO, RF_CONV_TILE,
                    RF_CONV_MFMA, RF_CONV_VALU, SO_PATH, lib)
 from .host import (RfError, Config, Plan, Context, Graph, Render, RenderInfo, get_dim, comm_selftest,
                    registry_types, registry_binding, strip_rows, set_shader_path, shader_path, config_syntax, FILE_INPUT, FINAL_OUTPUT,
@@ -21,7 +21,7 @@ from .host import (RfError, Config, Plan, Context, Graph, Render, RenderInfo, ge
 __all__ = [
     "RF_FORMAT_RGBA8", "RF_FORMAT_RGBA32F", "RF_GRAPH_TIMERS", "RF_GRAPH_NO_FUSION",
     "RF_GRAPH_HIPGRAPH", "RF_GRAPH_NO_HALO_XCHG", "RF_GRAPH_NO_JIT", "RF_EXEC_SYNC_LAUNCHES", "RF_EXEC_CONCURRENT_LAYERS",
-    "RF_EXEC_FORCE_SPLIT", "RF_EXEC_NO_ALTERNATE", "RF_EXEC_ALTERNATE", "RF_CONV_AUTO", "RF_CONV_TILE", "RF_CONV_MFMA",
+    "RF_EXEC_FORCE_SPLIT", "RF_EXEC_NO_ALTERNATE", "RF_EXEC_ALTERNATE", "RF_EXEC_GLSL_NO_WINDOW", "RF_CONV_AUTO", "RF_CONV_TILE", "RF_CONV_MFMA",
     "RF_CONV_VALU", "SO_PATH", "lib",
     "RfError", "Config", "Plan", "Context", "Graph", "Render", "RenderInfo", "get_dim",
     "registry_types", "registry_binding", "strip_rows", "set_shader_path", "shader_path", "config_syntax", "FILE_INPUT", "FINAL_OUTPUT",

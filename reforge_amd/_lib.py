@@ -35,6 +35,7 @@ RF_EXEC_CONCURRENT_LAYERS = 0x2
 RF_EXEC_FORCE_SPLIT = 0x4
 RF_EXEC_NO_ALTERNATE = 0x8
 RF_EXEC_ALTERNATE = 0x20
+RF_EXEC_GLSL_NO_WINDOW = 0x40
 
 RF_CONV_AUTO, RF_CONV_TILE, RF_CONV_MFMA, RF_CONV_VALU = 0, 1, 2, 3
 

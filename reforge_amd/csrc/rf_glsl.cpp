@@ -961,6 +961,248 @@ bool point_shader(const std::string& text, const GlslShader& sh, std::string& in
     return true;
 }
 
+// Is the shader a TRANSLATION-INVARIANT STENCIL -- what an invocation writes depends on the texels around its own position and on nothing
+// else about that position or the frame?  Then (with `#pragma rf radius R`) it can run on the LDS-tiled window kernel the stage files use
+// (user_node_kernel, rf_user_dev.h): in a virtual frame of (2R+1)^2 texels around the invocation every coordinate the shader computes is a
+// constant of the unrolled code, so a tap is a register or an LDS read at a fixed offset.  Decided on the file's tokens, conservatively:
+// position and frame size (gl_GlobalInvocationID, imageSize and every integer variable or helper parameter computed from them) may be
+// used ONLY to compute further integer coordinates, as the coordinate of an imageLoad, in the frame guard, and as the coordinate of an
+// imageStore (the invocation's own).  A use anywhere else -- a float, a condition, a loop bound -- makes the shader position-dependent
+// as far as this analysis can tell, and it keeps its generic kernel.  (The radius itself and the border behaviour are not proven here: the
+// frame's border texels are computed by the generic kernel, and rf_graph_create runs both kernels on a small random frame and keeps the
+// window kernel only if the two agree bit for bit.)
+bool stencil_shader(const std::string& text, const GlslShader& sh)
+{
+    if (sh.grouped || !sh.ssbos.empty() || sh.radius < 1 || sh.radius > 15 || sh.lx < 16 || sh.ly < 16 || sh.ubo_bytes > 56) return false;
+    std::set<std::string> in_names, out_names;
+    for (const auto& im : sh.images) {
+        if (im.sampled || im.readonly == im.writeonly) return false;      // every image is read or written, never both
+        (im.readonly ? in_names : out_names).insert(im.name);
+    }
+    if (in_names.empty() || out_names.empty() || in_names.size() > 4 || out_names.size() > 4) return false;
+    const std::vector<Tok> t = lex(text);
+    auto is_image = [&](const std::string& s) { return in_names.count(s) || out_names.count(s); };
+    static const std::set<std::string> int_types = {"int", "uint", "ivec2", "ivec3", "ivec4", "uvec2", "uvec3", "uvec4"};
+    static const char* forbidden[] = {"gl_WorkGroupID", "gl_LocalInvocationID", "gl_LocalInvocationIndex", "gl_NumWorkGroups", "gl_WorkGroupSize"};
+    // functions: name -> (parameter names, parameter types, by-reference flags, body range, return type)
+    struct Fn { std::vector<std::string> pname, ptype; std::vector<bool> byref; size_t b = 0, e = 0; std::string ret; };
+    std::map<std::string, Fn> fns;
+    {
+        int depth = 0;
+        for (size_t i = 0; i + 3 < t.size(); ++i) {
+            if (t[i].k == T_PUNCT && (t[i].s == "{" )) ++depth;
+            if (t[i].k == T_PUNCT && (t[i].s == "}" )) --depth;
+            if (depth != 0 || t[i].k != T_ID || t[i + 1].k != T_ID || !is(t[i + 2], "(")) continue;
+            const size_t close = match(t, i + 2, t.size());
+            if (!is(t[close + 1], "{")) continue;
+            Fn f;
+            f.ret = t[i].s;
+            f.b = close + 2;
+            f.e = match(t, close + 1, t.size());
+            size_t pb = i + 3;
+            while (pb < close) {
+                size_t pe = pb;
+                int d = 0;
+                while (pe < close && !(d == 0 && is(t[pe], ","))) { if (is(t[pe], "(") || is(t[pe], "[")) ++d; if (is(t[pe], ")") || is(t[pe], "]")) --d; ++pe; }
+                std::string ty, nm;
+                bool ref = false;
+                int bd = 0;
+                for (size_t k = pb; k < pe; ++k) {
+                    if (is(t[k], "[")) ++bd;
+                    if (is(t[k], "]")) --bd;
+                    if (bd || t[k].k != T_ID) continue;
+                    if (t[k].s == "out" || t[k].s == "inout") ref = true;
+                    else if (t[k].s == "in" || t[k].s == "const" || dropped_qualifiers().count(t[k].s)) {}
+                    else if (ty.empty()) ty = t[k].s;
+                    else nm = t[k].s;
+                }
+                if (!ty.empty() && ty != "void") { f.ptype.push_back(ty); f.pname.push_back(nm); f.byref.push_back(ref); }
+                pb = pe + 1;
+            }
+            fns[t[i + 1].s] = f;
+            i = close;      // the body is scanned by the passes below
+        }
+    }
+    if (!fns.count("main")) return false;
+    // names the position or the frame size has reached
+    std::set<std::string> tainted = {"gl_GlobalInvocationID", "imageSize"};
+    std::set<std::string> int_returning;      // helpers that return an integer computed with tainted arguments: their calls are tainted values
+    std::vector<char> ok;
+    auto has_taint = [&](size_t a, size_t b) {
+        for (size_t k = a; k < b; ++k)
+            if (t[k].k == T_ID && (tainted.count(t[k].s) || int_returning.count(t[k].s)) && !(k > 0 && is(t[k - 1], "."))) return true;
+        return false;
+    };
+    auto arg_end = [&](size_t a, size_t limit) {      // end of the argument (or declarator) starting at a: the next `,` `;` or closing bracket at depth 0
+        int d = 0;
+        size_t k = a;
+        for (; k < limit; ++k) {
+            if (t[k].k != T_PUNCT) continue;
+            const char c = t[k].s[0];
+            if (c == '(' || c == '[' || c == '{') ++d;
+            else if (c == ')' || c == ']' || c == '}') { if (d == 0) break; --d; }
+            else if (d == 0 && (c == ',' || c == ';')) break;
+        }
+        return k;
+    };
+    for (const auto& q : t) {
+        if (q.k == T_PP) {
+            const std::vector<Tok> d = lex(q.s.substr(1));
+            for (const auto& w : d)
+                if (w.k == T_ID && (w.s == "gl_GlobalInvocationID" || w.s == "imageSize" || w.s == "imageLoad" || w.s == "imageStore" || is_image(w.s))) return false;
+        } else if (q.k == T_ID) {
+            for (const char* f : forbidden)
+                if (q.s == f) return false;
+        }
+    }
+    // pure coordinate / size variables of main (the frame guard and the store coordinate are written with these)
+    const Fn& mainf = fns["main"];
+    std::set<std::string> pure_coord, pure_size;
+    auto seq = [&](size_t i, std::initializer_list<const char*> pat) {
+        size_t k = i;
+        for (const char* p : pat) {
+            if (k >= t.size()) return false;
+            if (std::string(p) == "$ID") { if (t[k].k != T_ID) return false; }
+            else if (!is(t[k], p)) return false;
+            ++k;
+        }
+        return true;
+    };
+    auto inline_coord = [&](size_t i) -> size_t {
+        if (seq(i, {"ivec2", "(", "gl_GlobalInvocationID", ".", "xy", ")"})) return 6;
+        if (seq(i, {"ivec2", "(", "gl_GlobalInvocationID", ")"})) return 4;
+        return 0;
+    };
+    for (size_t i = mainf.b; i < mainf.e; ++i) {
+        if (!is(t[i], "ivec2") || t[i + 1].k != T_ID || !is(t[i + 2], "=")) continue;
+        const size_t n = inline_coord(i + 3);
+        if (n && is(t[i + 3 + n], ";")) pure_coord.insert(t[i + 1].s);
+        else if (seq(i + 3, {"imageSize", "(", "$ID", ")", ";"}) && is_image(t[i + 5].s)) pure_size.insert(t[i + 1].s);
+    }
+    auto coord_at = [&](size_t i) -> size_t { return (t[i].k == T_ID && pure_coord.count(t[i].s)) ? 1 : inline_coord(i); };
+    auto size_at = [&](size_t i) -> size_t {
+        if (t[i].k == T_ID && pure_size.count(t[i].s)) return 1;
+        return (seq(i, {"imageSize", "(", "$ID", ")"}) && is_image(t[i + 2].s)) ? 4 : 0;
+    };
+    for (int round = 0; round < 16; ++round) {
+        const size_t before = tainted.size() + int_returning.size();
+        ok.assign(t.size(), 0);
+        auto mark = [&](size_t a, size_t b) { for (size_t k = a; k < b; ++k) ok[k] = 1; };
+        for (const auto& kv : fns) {
+            const Fn& f = kv.second;
+            for (size_t i = f.b; i < f.e; ++i) {
+                if (t[i].k != T_ID) continue;
+                const std::string& w = t[i].s;
+                if (int_types.count(w) && t[i + 1].k == T_ID && !is(t[i + 1], "(")) {
+                    // INTTYPE a = e, b = e2, c;  : every initialiser may use position; what it uses it taints
+                    size_t k = i + 1;
+                    for (;;) {
+                        if (t[k].k != T_ID) break;
+                        const std::string name = t[k].s;
+                        size_t q = k + 1;
+                        while (is(t[q], "[")) q = match(t, q, f.e) + 1;
+                        if (is(t[q], "=")) {
+                            const size_t e = arg_end(q + 1, f.e);
+                            if (has_taint(q + 1, e)) tainted.insert(name);
+                            mark(i, e);
+                            q = e;
+                        }
+                        if (is(t[q], ",")) { k = q + 1; continue; }
+                        break;
+                    }
+                } else if ((tainted.count(w)) && !(i > 0 && is(t[i - 1], ".")) && (is(t[i - 1], ";") || is(t[i - 1], "{") || is(t[i - 1], "}") || is(t[i - 1], ")"))) {
+                    // NAME = e;  NAME += e;  NAME.x = e;  at the start of a statement: an assignment to an integer the position has reached
+                    size_t q = i + 1;
+                    while (is(t[q], ".") || (t[q].k == T_ID && is(t[q - 1], "."))) ++q;
+                    if (t[q].k == T_PUNCT && std::string("+-*/%&|^").find(t[q].s[0]) != std::string::npos && is(t[q + 1], "=")) ++q;
+                    if (is(t[q], "=") && !is(t[q + 1], "=")) mark(i, arg_end(q + 1, f.e));
+                } else if ((w == "imageLoad" || w == "imageStore") && is(t[i + 1], "(") && t[i + 2].k == T_ID && is(t[i + 3], ",")) {
+                    const bool load = w == "imageLoad";
+                    if (!(load ? in_names.count(t[i + 2].s) : out_names.count(t[i + 2].s))) return false;
+                    const size_t e = arg_end(i + 4, f.e);
+                    if (!load) {
+                        // a store: in main(), at the invocation's own coordinate
+                        const size_t n = coord_at(i + 4);
+                        if (kv.first != "main" || !n || i + 4 + n != e) return false;
+                    }
+                    mark(i, e);
+                } else if (w == "imageSize" && is(t[i + 1], "(") && t[i + 2].k == T_ID && is_image(t[i + 2].s) && is(t[i + 3], ")")) {
+                    ok[i + 2] = 1;      // (the call itself is a tainted value: allowed only where such values are)
+                } else if (w == "if" && is(t[i + 1], "(") && kv.first == "main") {
+                    const size_t close = match(t, i + 1, f.e);
+                    size_t k = close + 1;
+                    const bool braces = is(t[k], "{");
+                    if (braces) ++k;
+                    if (!(is(t[k], "return") && is(t[k + 1], ";") && (!braces || is(t[k + 2], "}")))) continue;
+                    const size_t q = i + 2;
+                    bool guard = false;
+                    if (seq(q, {"any", "(", "greaterThanEqual", "("})) {
+                        const size_t a = q + 4, n1 = coord_at(a);
+                        if (n1 && is(t[a + n1], ",")) {
+                            const size_t n2 = size_at(a + n1 + 1);
+                            guard = n2 && seq(a + n1 + 1 + n2, {")", ")", ")"}) && a + n1 + 1 + n2 + 2 == close;
+                        }
+                    } else {
+                        auto half = [&](size_t a, char want, size_t& end) {
+                            const size_t n1 = coord_at(a);
+                            if (!n1 || !is(t[a + n1], ".") || t[a + n1 + 1].s != std::string(1, want)) return false;
+                            const size_t b = a + n1 + 2;
+                            if (!(is(t[b], ">") && is(t[b + 1], "=") && t[b + 1].ws.empty())) return false;
+                            const size_t n2 = size_at(b + 2);
+                            if (!n2 || !is(t[b + 2 + n2], ".") || t[b + 2 + n2 + 1].s != std::string(1, want)) return false;
+                            end = b + 2 + n2 + 2;
+                            return true;
+                        };
+                        for (int order = 0; order < 2 && !guard; ++order) {
+                            size_t e1 = 0, e2 = 0;
+                            if (half(q, order ? 'y' : 'x', e1) && is(t[e1], "|") && is(t[e1 + 1], "|") && half(e1 + 2, order ? 'x' : 'y', e2) && e2 == close) guard = true;
+                        }
+                    }
+                    if (guard) mark(i, close + 1);
+                } else if (fns.count(w) && is(t[i + 1], "(") && w != kv.first) {
+                    // a helper call: a tainted argument taints the parameter it lands in (an integer, passed by value)
+                    const Fn& h = fns.at(w);
+                    const size_t close = match(t, i + 1, f.e);
+                    size_t a = i + 2;
+                    bool any = false;
+                    for (size_t p = 0; a < close; ++p) {
+                        const size_t e = arg_end(a, close);
+                        if (has_taint(a, e)) {
+                            if (p >= h.pname.size() || !int_types.count(h.ptype[p]) || h.byref[p]) return false;
+                            tainted.insert(h.pname[p]);
+                            mark(a, e);
+                            any = true;
+                        }
+                        a = e + 1;
+                    }
+                    if (any && int_types.count(h.ret)) int_returning.insert(w);
+                }
+            }
+        }
+        if (tainted.size() + int_returning.size() == before && round > 0) break;
+    }
+    // the verdict: a tainted name outside every allowed place?  an image variable that is not the first argument of an image function?
+    for (const auto& kv : fns)
+        for (size_t i = kv.second.b; i < kv.second.e; ++i) {
+            if (t[i].k != T_ID || (i > 0 && is(t[i - 1], "."))) continue;
+            if (is_image(t[i].s) && !(i >= 2 && is(t[i - 1], "(") && (t[i - 2].s == "imageLoad" || t[i - 2].s == "imageStore" || t[i - 2].s == "imageSize"))) return false;
+            if ((tainted.count(t[i].s) || int_returning.count(t[i].s)) && !ok[i]) {
+                // the declaration of a tainted parameter is not a use
+                if (i + 1 < t.size() && (is(t[i + 1], ",") || is(t[i + 1], ")")) && i < kv.second.b) continue;
+                return false;
+            }
+        }
+    // outside function bodies: no image function, no position
+    {
+        std::vector<char> inside(t.size(), 0);
+        for (const auto& kv : fns)
+            for (size_t i = kv.second.b; i < kv.second.e; ++i) inside[i] = 1;
+        for (size_t i = 0; i < t.size(); ++i)
+            if (!inside[i] && t[i].k == T_ID && (t[i].s == "gl_GlobalInvocationID" || t[i].s == "imageSize" || t[i].s == "imageLoad" || t[i].s == "imageStore")) return false;
+    }
+    return true;
+}
+
 }  // namespace
 
 bool glsl_translate(const std::string& type, const std::string& text, const std::string& ident, GlslShader& out, std::string& err)
@@ -992,10 +1234,26 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
     } catch (const Fail&) {      // (a bracket the analysis could not pair: not recognised, that is all)
         out.point = false;
     }
+    try {
+        out.stencil = !out.point && stencil_shader(text, out);
+    } catch (const Fail&) {
+        out.stencil = false;
+    }
     if (out.point) {
         // the shader as a row stage: its image variables hold one texel (image2D<PointPx>, rf_glsl_dev.h)
         s += "    RFG void rfg_bind_point(const unsigned char* rfg_ubo, vec4 rfg_c)\n    {\n        (void)rfg_ubo;\n" + tr.bind_ubo + "        " + pout + ".value = vec4{0.0f, 0.0f, 0.0f, 0.0f};\n        " + pin +
              ".value = rfg_c;\n    }\n    RFG vec4 rfg_result() const { return " + pout + ".value; }\n";
+    }
+    std::vector<std::string> win_in, win_out;
+    if (out.stencil) {
+        // the shader on the window kernel: its readable images are windows around the invocation, its written images one texel each
+        std::string b = "    template <class RfgW> RFG void rfg_bind_win(const unsigned char* rfg_ubo, const RfgW* rfg_in)\n    {\n        (void)rfg_ubo; (void)rfg_in;\n" + tr.bind_ubo;
+        std::string o = "    RFG vec4 rfg_out(int rfg_o) const\n    {\n";
+        for (const auto& im : out.images) {
+            if (im.readonly) { b += "        " + im.name + ".w = &rfg_in[" + std::to_string(win_in.size()) + "];\n"; win_in.push_back(im.name); }
+            else { b += "        " + im.name + ".value = vec4{0.0f, 0.0f, 0.0f, 0.0f};\n"; o += "        if (rfg_o == " + std::to_string(win_out.size()) + ") return " + im.name + ".value;\n"; win_out.push_back(im.name); }
+        }
+        s += b + "    }\n" + o + "        return vec4{0.0f, 0.0f, 0.0f, 0.0f};\n    }\n";
     }
     s += "#line 1 \"" + type + ".comp\"\n";
     s += emit(tr.v, 0, tr.v.size());
@@ -1012,6 +1270,15 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
              "    template <class Q> static RFG rf::f4 box(const Q&, const rf::f4 (&n)[3][3]) { return n[1][1]; }\n};\n} }\n"
              "namespace rfuser { namespace " + ident + " { typedef rfglsl::" + ident + "::RfgStage Stage; } }\n#endif\n";
     }
+    if (out.stencil) {
+        const std::string n = std::to_string(out.ubo_bytes > 0 ? out.ubo_bytes : 1), R = std::to_string(out.radius);
+        s += "#ifdef RFGLSL_KERNEL\nnamespace rfglsl { namespace " + ident + " {\nstruct RfgWParams { unsigned char b[" + n + "]; };\nstruct RfgWStage {\n    typedef RfgWParams P;\n    static constexpr int R = " + R +
+             ", NI = " + std::to_string(win_in.size()) + ", NO = " + std::to_string(win_out.size()) + ", FILL = 0;\n"
+             "    template <class Q, class In> static RFG void node(const Q& p, const In (&in)[NI], rf::f4 (&out)[NO], const float*)\n    {\n        RfgShader<WinPx<In, R>> s;\n"
+             "        s.gl_NumWorkGroups = uvec3{1u, 1u, 1u};\n        s.gl_WorkGroupID = uvec3{0u, 0u, 0u};\n        s.gl_LocalInvocationID = s.gl_GlobalInvocationID = uvec3{" + R + "u, " + R + "u, 0u};\n"
+             "        s.gl_LocalInvocationIndex = 0u;\n        s.rfg_bind_win(p.b, in);\n        s.main();\n#pragma unroll\n        for (int o = 0; o < NO; ++o) { const vec4 r = s.rfg_out(o); out[o] = make_float4(r.x, r.y, r.z, r.w); }\n    }\n};\n} }\n"
+             "namespace rfuser { namespace " + ident + " { typedef rfglsl::" + ident + "::RfgWStage Stage; } }\n#endif\n";
+    }
     out.source = s;
     return true;
 }
@@ -1019,7 +1286,7 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
 std::string glsl_reflection_json(const GlslShader& s)
 {
     auto q = [](const std::string& x) { return "\"" + x + "\""; };
-    std::string j = std::string("{\"point\": ") + (s.point ? "true" : "false") + ", \"local_size\": [" + std::to_string(s.lx) + ", " + std::to_string(s.ly) + ", " + std::to_string(s.lz) + "], \"grouped\": " + (s.grouped ? "true" : "false") +
+    std::string j = std::string("{\"point\": ") + (s.point ? "true" : "false") + ", \"stencil\": " + (s.stencil ? "true" : "false") + ", \"local_size\": [" + std::to_string(s.lx) + ", " + std::to_string(s.ly) + ", " + std::to_string(s.lz) + "], \"grouped\": " + (s.grouped ? "true" : "false") +
                     ", \"radius\": " + std::to_string(s.radius) + ", \"uniform_bytes\": " + std::to_string(s.ubo_bytes) + ", \"images\": [";
     for (size_t i = 0; i < s.images.size(); ++i)
         j += std::string(i ? ", " : "") + "{\"name\": " + q(s.images[i].name) + ", \"binding\": " + std::to_string(s.images[i].binding) + ", \"readonly\": " + (s.images[i].readonly ? "true" : "false") +

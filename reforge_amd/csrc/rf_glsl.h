@@ -63,6 +63,7 @@ struct GlslShader {
     bool grouped = false;                  // uses workgroup built-ins, shared variables or barrier(): dispatched in the file's own workgroups
     int radius = -1;                       // #pragma rf radius N; -1 = not stated
     bool point = false;                    // recognised as a point operation on one image: also a row stage of the stream kernel (fuses)
+    bool stencil = false;                  // recognised as a translation-invariant stencil of the stated radius: also runs on the LDS-tiled window kernel
     int ubo_bytes = 0;
     std::string source;                    // namespace rfglsl { namespace <ident> { ... RfgShader<Px> ... RfgInfo ... } }
 };

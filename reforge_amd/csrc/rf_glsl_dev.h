@@ -451,7 +451,9 @@ struct GlslFrame {
                               // may write storage blocks
     int groups_x, groups_y;   // the dispatch: ceil(W/16) x ceil(H/16) workgroups (command.rs:167-168) whatever local_size says
     const char* zero;         // 16 zero bytes in device memory (what imageLoad outside an image reads)
-    int pad[2];
+    int ring;                 // > 0: the launch runs only the invocations within `ring` texels of the frame's edges (rows y0 .. y1): the border
+                              // of a node whose interior the window kernel computes (WinPx below)
+    int pad;
 };
 
 }  // namespace rfglsl
@@ -466,6 +468,28 @@ template <class P, bool BUF> struct GPx : P {      // the texel formats of rf_de
     static constexpr bool BUFFER = BUF;            // imageLoad through buffer resources (images below 4 GiB)
     RFG static rf::f4 texel(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
 };
+
+// A shader the translator recognises as a TRANSLATION-INVARIANT STENCIL (rf_glsl.cpp, stencil_shader) also runs on the LDS-tiled window
+// kernel of the stage files (rf::user_node_kernel, rf_user_dev.h): there an invocation lives in a virtual frame of (2R+1)^2 texels around
+// itself -- gl_GlobalInvocationID = (R, R), imageSize = (2R+1, 2R+1) -- so every coordinate it computes is a constant of the unrolled code
+// and imageLoad is Window::at at a constant offset: a register of the window the thread slides down its outputs (R <= 2), or an LDS
+// read at an immediate offset.  (Offsets are clamped into the window: a shader that reads further than it states stays inside memory;
+// rf_graph_create compares this kernel with the generic one on a random frame and keeps it only if they agree.)
+template <class W, int R> struct WinPx {};
+template <class W, int R> struct image2D<WinPx<W, R>> {
+    const W* w;
+    mutable vec4 value;
+};
+template <class W, int R> RFG ivec2 imageSize(const image2D<WinPx<W, R>>&) { return ivec2{2 * R + 1, 2 * R + 1}; }
+template <class W, int R> RFG vec4 imageLoad(const image2D<WinPx<W, R>>& im, ivec2 q)
+{
+    int dx = q.x - R, dy = q.y - R;
+    dx = dx < -R ? -R : (dx > R ? R : dx);
+    dy = dy < -R ? -R : (dy > R ? R : dy);
+    const rf::f4 t = im.w->at(dx, dy);
+    return vec4{t.x, t.y, t.z, t.w};
+}
+template <class W, int R> RFG void imageStore(const image2D<WinPx<W, R>>& im, ivec2, vec4 v) { im.value = v; }
 
 RFG void barrier() { __syncthreads(); }
 RFG void memoryBarrier() { __threadfence(); }
@@ -513,8 +537,23 @@ __global__ __launch_bounds__(I::GROUPED ? I::LX * I::LY * I::LZ : 256) void glsl
         const unsigned tiles_y = ((unsigned)A.f.y1 - y_first + 3u) / 4u;
         const unsigned per_xcd = gridDim.x >> 3;
         const unsigned q = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+        unsigned gx, gy;
+        if (A.f.ring > 0) {
+            // the border ring of rows y0 .. y1: top rows, bottom rows (whole rows), then the `ring` first and last columns of the rows between
+            const int R = A.f.ring, W = A.f.W, H = A.f.H;
+            const int t0 = A.f.y0 > 0 ? A.f.y0 : 0, t1 = A.f.y1 < R ? A.f.y1 : R, nt = t1 > t0 ? t1 - t0 : 0;
+            const int b0 = A.f.y0 > H - R ? A.f.y0 : H - R, b1 = A.f.y1 < H ? A.f.y1 : H, nb = b1 > b0 ? b1 - b0 : 0;
+            const int m0 = A.f.y0 > R ? A.f.y0 : R, m1 = A.f.y1 < H - R ? A.f.y1 : H - R, nm = m1 > m0 ? m1 - m0 : 0;
+            long idx = (long)q * 256 + (long)threadIdx.x;
+            if (idx < (long)nt * W) { gy = (unsigned)(t0 + (int)(idx / W)); gx = (unsigned)(idx % W); }
+            else if ((idx -= (long)nt * W) < (long)nb * W) { gy = (unsigned)(b0 + (int)(idx / W)); gx = (unsigned)(idx % W); }
+            else if ((idx -= (long)nb * W) < (long)nm * 2 * R) { gy = (unsigned)(m0 + (int)(idx / (2 * R))); const int c = (int)(idx % (2 * R)); gx = (unsigned)(c < R ? c : W - 2 * R + c); }
+            else return;
+        } else {
         if (q >= tiles_x * tiles_y) return;
-        const unsigned gx = (q % tiles_x) * 64u + (threadIdx.x & 63u), gy = y_first + (q / tiles_x) * 4u + (threadIdx.x >> 6);
+        gx = (q % tiles_x) * 64u + (threadIdx.x & 63u);
+        gy = y_first + (q / tiles_x) * 4u + (threadIdx.x >> 6);
+        }
         if (gx >= (unsigned)(A.f.groups_x * I::LX) || gy >= (unsigned)(A.f.groups_y * I::LY)) return;
         wg = uvec3{gx / (unsigned)I::LX, gy / (unsigned)I::LY, 0u};
         lid = uvec3{gx % (unsigned)I::LX, gy % (unsigned)I::LY, 0u};

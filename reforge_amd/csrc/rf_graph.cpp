@@ -197,11 +197,11 @@ static std::string unwired_buffer_name(const std::string& label, const std::stri
 // a node whose type is {shader_path}/{type}.comp (rf_glsl.h): rfglsl::glsl_node_kernel, one invocation of the translated
 // main() per thread.  The dispatch is the reference's: ceil(W/16) x ceil(H/16) workgroups of the file's local_size
 // (command.rs:167-168), in FRAME coordinates; a row strip runs the invocations of its own rows.
-static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, const Geom& geo, hipStream_t stream, const UserStage* u, const JitKernel* k)
+static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, const Geom& geo, hipStream_t stream, const UserStage* u, const JitKernel* k, int ring = 0)
 {
     const Op& op = L.ops[0];
     const int y_org = g->strip_y0;
-    struct Frame { int W, H, row_lo, row_hi, y0, y1, groups_x, groups_y; const char* zero; int pad[2]; } fr;
+    struct Frame { int W, H, row_lo, row_hi, y0, y1, groups_x, groups_y; const char* zero; int ring, pad; } fr;
     static_assert(sizeof(Frame) == 48, "GlslFrame of rf_glsl_dev.h");
     fr.W = geo.W;
     fr.H = g->opt.height;
@@ -211,7 +211,8 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     fr.y1 = geo.y1 + y_org;
     fr.groups_x = (fr.W + 15) / 16;
     fr.groups_y = (fr.H + 15) / 16;
-    fr.pad[0] = fr.pad[1] = 0;
+    fr.ring = ring;
+    fr.pad = 0;
     {
         auto z = g->dev_buffers.find(kGlslZeroTexel);
         if (z == g->dev_buffers.end()) return hipErrorInvalidValue;
@@ -219,7 +220,7 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     }
     // the launch that runs the frame's last row also runs the invocations below it that the dispatch covers (they exist in the
     // reference; their image accesses fall outside the frame and are dropped, their storage-block writes are not)
-    if (fr.y1 == fr.H) fr.y1 = std::max(fr.H, fr.groups_y * u->glsl_groups[1]);
+    if (fr.y1 == fr.H && ring == 0) fr.y1 = std::max(fr.H, fr.groups_y * u->glsl_groups[1]);
     // the kernel's argument block (GlslArgs): 48 + 16 x 32 + 8 x 32 + 256 bytes at most, built on the stack every frame
     struct ArgBlock {
         alignas(8) unsigned char b[sizeof(Frame) + 16 * kGlslMaxImages + 8 * kGlslMaxBuffers + kGlslMaxUniformBytes + 8];
@@ -282,6 +283,16 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
         const unsigned threads = (unsigned)(u->glsl_groups[0] * u->glsl_groups[1] * u->glsl_groups[2]);
         return jit_launch(*k, (unsigned)fr.groups_x * (unsigned)fr.groups_y, threads, args.data(), args.size(), stream);
     }
+    if (ring > 0) {
+        // the border ring of these rows (the kernel enumerates it the same way): whole rows within `ring` of the frame's top and bottom,
+        // 2 x ring columns of the rows between
+        const int R = ring, W = fr.W, H = fr.H;
+        const long nt = std::max(0, std::min(fr.y1, R) - std::max(fr.y0, 0)), nb = std::max(0, std::min(fr.y1, H) - std::max(fr.y0, H - R));
+        const long nm = std::max(0, std::min(fr.y1, H - R) - std::max(fr.y0, R));
+        const long total = (nt + nb) * W + nm * 2 * R;
+        if (total <= 0) return hipSuccess;
+        return jit_launch(*k, (unsigned)(((total + 255) / 256 + 7) / 8 * 8), 256, args.data(), args.size(), stream);
+    }
     // 64 x 4 invocations per workgroup over x < groups_x * LX, the rows of this launch (the kernel aligns the first to 4)
     const unsigned tiles_x = ((unsigned)(fr.groups_x * u->glsl_groups[0]) + 63u) / 64u;
     const unsigned y_first = (unsigned)fr.y0 & ~3u;
@@ -305,7 +316,20 @@ static hipError_t launch_user_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     const UserStage* u = user_stage_by_id(op.user_id);
     const JitKernel* k = jit_lookup_user_node(fmt, op.user_id, wide_images(g));
     if (!u || !k || L.src.size() != u->inputs.size()) return hipErrorInvalidDeviceFunction;      // graph_build compiled it: cannot happen
-    if (u->glsl) return launch_glsl_node(g, L, f, geo, stream, u, k);
+    // a .comp file: its generic kernel -- unless it is a recognised stencil whose window kernel rf_graph_create has checked against the
+    // generic one (glsl_window_ok): then the LDS-tiled kernel computes the frame and the generic kernel only the border ring, where the
+    // shader's own treatment of the frame's edges decides (interior texels cannot tell the two apart)
+    bool ring_after = false;
+    if (u->glsl) {
+        const bool window = u->glsl_window && g->glsl_window_ok.count(L.label) && geo.W > 2 * u->radius && g->opt.height > 2 * u->radius;
+        if (!window) return launch_glsl_node(g, L, f, geo, stream, u, k);
+        ring_after = true;
+    }
+    const JitKernel* generic = k;
+    if (ring_after) {
+        k = jit_lookup_glsl_window(fmt, op.user_id);
+        if (!k) return hipErrorInvalidDeviceFunction;
+    }
     UserNodeArgs A;
     std::memset(&A, 0, sizeof(A));
     for (size_t i = 0; i < L.src.size(); ++i) {
@@ -349,13 +373,17 @@ static hipError_t launch_user_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     // a node that reads through windows: one workgroup per 64 x TH tile of the output, its inputs staged in LDS (rf_user_dev.h,
     // UserTile); the grid a multiple of the 8 XCDs (the kernel gives each a contiguous range of tiles)
     const UserTile tile = user_tile((int)bytes_per_pixel(fmt), u->radius, (int)u->inputs.size());
+    hipError_t e;
     if (u->radius > 0 && tile.lds) {
         A.grid_x = (geo.W + 63) / 64;
         const long tiles = (long)A.grid_x * ((rows + tile.th - 1) / tile.th);
-        return jit_launch(*k, (unsigned)((tiles + 7) / 8 * 8), 256, &A, sizeof(A), stream);
+        e = jit_launch(*k, (unsigned)((tiles + 7) / 8 * 8), 256, &A, sizeof(A), stream);
+    } else {
+        const unsigned gy = (unsigned)(rows > 1024 ? 1024 : rows);
+        e = jit_launch(*k, (unsigned)A.grid_x * gy, 256, &A, sizeof(A), stream);
     }
-    const unsigned gy = (unsigned)(rows > 1024 ? 1024 : rows);
-    return jit_launch(*k, (unsigned)A.grid_x * gy, 256, &A, sizeof(A), stream);
+    if (e != hipSuccess || !ring_after) return e;
+    return launch_glsl_node(g, L, f, geo, stream, u, generic, u->radius);      // behind it on the same stream: the border ring, exactly as the file treats it
 }
 
 // the kernel(s) of one launch over output rows [y0, y1) of `geo`
@@ -660,6 +688,7 @@ static void read_tuning(rf_graph* g)
     g->sync_launches = (opt.exec_flags & RF_EXEC_SYNC_LAUNCHES) != 0;
     g->concurrent_layers = (opt.exec_flags & RF_EXEC_CONCURRENT_LAYERS) != 0;
     g->force_split = (opt.exec_flags & RF_EXEC_FORCE_SPLIT) != 0;
+    g->glsl_no_window = (opt.exec_flags & RF_EXEC_GLSL_NO_WINDOW) != 0;
     if (const char* e = std::getenv("RF_ROWS_PER_CHUNK")) g->tune.rows_per_chunk = std::atoi(e);
     if (const char* e = std::getenv("RF_CONV_PATH")) g->tune.conv_path = std::atoi(e);
     if (g->tune.conv_path < 0 || g->tune.conv_path > 3) g->tune.conv_path = -1;      // refused by rf_graph_create (RF_ERR_INVALID): there is no such kernel
@@ -892,6 +921,72 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
     return RF_OK;
 }
 
+// A .comp stencil (UserStage::glsl_window) has two kernels: the generic one, which IS the file as the reference would run it, and the
+// LDS-tiled window kernel, which rests on what rf_glsl.cpp read off the file's text (translation invariance) and on the radius the file
+// states.  Before a graph uses the window kernel it is held against the generic one: the node alone on a small random frame with the
+// node's own parameters, both ways, every wired output, bit for bit.  A difference (a shader that reads further than it states, an
+// analysis that was wrong) keeps the generic kernel and says so in rf_graph_note.  Graph creation is where the reference compiles
+// its shaders (pipeline_graph.rs:509-545): a few milliseconds here are in the right place.
+static thread_local bool t_in_selftest = false;
+static void glsl_window_selftests(rf_graph* g)
+{
+    if (g->glsl_no_window) return;
+    for (const auto& L : g->launches) {
+        if (L.ops.size() != 1 || L.ops[0].kind != OP_USERN) continue;
+        const UserStage* u = user_stage_by_id(L.ops[0].user_id);
+        if (!u || !u->glsl || !u->glsl_window) continue;
+        if (t_in_selftest) { g->glsl_window_ok.insert(L.label); continue; }      // the inner graph of a self-test: this IS the kernel under test
+        t_in_selftest = true;
+        std::string why;
+        bool same = true;
+        const int W = 96, H = 64;
+        const size_t bpp = bytes_per_pixel(g->opt.format);
+        const NodeParams& np = g->plan.plan.nodes.at(L.members[0]);
+        rf_ctx* ctx = nullptr;
+        if (rf_ctx_create(g->ctx->device, &ctx) != RF_OK) { same = false; why = last_error(); }
+        for (size_t o = 0; same && o < u->outputs.size(); ++o) {
+            if (std::find(L.dst_bindings.begin(), L.dst_bindings.end(), u->out_binding[o]) == L.dst_bindings.end()) continue;      // not wired in this graph
+            std::string text;
+            for (size_t k = 0; k < u->inputs.size(); ++k) {
+                if (k == 0) text += "input -> nn:" + u->inputs[k] + "\n";
+                else text += "input -> t" + std::to_string(k) + "x -> nn:" + u->inputs[k] + "\nt" + std::to_string(k) + "x: grade { slope: 0." + std::to_string(5 + k) + ", offset: 0.0" + std::to_string(k) + ", saturation: 1.0 }\n";
+            }
+            text += "nn:" + u->outputs[o] + " -> output\nnn: " + u->type_name + " {}\n";
+            rf_config* cfg = nullptr;
+            if (rf_config_parse(text.c_str(), 1, &cfg) != RF_OK) { same = false; why = last_error(); break; }
+            std::vector<unsigned char> got[2];
+            for (int variant = 0; same && variant < 2; ++variant) {
+                rf_graph_options opt{};
+                opt.width = W;
+                opt.height = H;
+                opt.format = g->opt.format;
+                opt.num_frames = 1;
+                opt.exec_flags = variant ? RF_EXEC_GLSL_NO_WINDOW : 0u;
+                rf_graph* t = nullptr;
+                if (rf_graph_create(ctx, cfg, &opt, &t) != RF_OK) { same = false; why = last_error(); break; }
+                for (const auto& p : u->params) {
+                    auto it = np.values.find(p.name);
+                    ParamValue v;
+                    v.i = 0;
+                    if (it != np.values.end()) v = it->second;
+                    (void)rf_graph_set_param(t, "nn", p.name.c_str(), p.type == PARAM_F32 ? RF_PARAM_F32 : (p.type == PARAM_I32 ? RF_PARAM_I32 : RF_PARAM_BOOL), &v);
+                }
+                got[variant].resize((size_t)W * H * bpp);
+                if (rf_graph_fill_synthetic(t, 0x5E1F7E57u + (uint32_t)o) != RF_OK || rf_graph_execute(t, 0) != RF_OK || rf_graph_wait(t, 0) != RF_OK ||
+                    rf_graph_download_raw(t, 0, got[variant].data(), (size_t)W * bpp) != RF_OK) { same = false; why = last_error(); }
+                rf_graph_destroy(t);
+            }
+            rf_config_destroy(cfg);
+            if (same && got[0] != got[1]) { same = false; why = "its window kernel and its generic kernel differ on a random 96 x 64 frame (output " + u->outputs[o] + ")"; }
+        }
+        if (ctx) rf_ctx_destroy(ctx);
+        t_in_selftest = false;
+        (void)hipSetDevice(g->ctx->device);
+        if (same) g->glsl_window_ok.insert(L.label);
+        else g->jit_note += (g->jit_note.empty() ? "" : "; ") + std::string("node '") + L.label + "' (" + u->file_name() + ", #pragma rf radius " + std::to_string(u->radius) + ") keeps its generic kernel: " + why;
+    }
+}
+
 extern "C" rf_status rf_graph_create(rf_ctx* ctx, const rf_config* cfg, const rf_graph_options* opt, rf_graph** out)
 {
     if (!ctx || !cfg || !opt || !out) return fail(RF_ERR_INVALID, "rf_graph_create: null argument");
@@ -909,6 +1004,7 @@ extern "C" rf_status rf_graph_create(rf_ctx* ctx, const rf_config* cfg, const rf
         set_error(keep);
         return st;
     }
+    glsl_window_selftests(g);
     *out = g;
     return RF_OK;
 }

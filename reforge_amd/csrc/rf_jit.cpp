@@ -199,6 +199,12 @@ std::string node_expression(int fmt, const UserStage& u, bool wide = false)
     return std::string("rf::user_node_kernel<") + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", rfuser::" + u.ident + "::Stage>";
 }
 
+// the window kernel of a .comp stencil: user_node_kernel over the stage rf_glsl.cpp generates (rfuser::<ident>::Stage)
+std::string window_expression(int fmt, const UserStage& u)
+{
+    return std::string("rf::user_node_kernel<") + (fmt == kFmtRGBA8 ? "rf::PxU8" : "rf::PxF32") + ", rfuser::" + u.ident + "::Stage>";
+}
+
 std::string fill_expression(const UserStage& u) { return "rf::user_fill_kernel<rfuser::" + u.ident + "::Stage>"; }
 
 // expr: the kernel instantiation to build; users: the user stages (rf_user.h ids) whose wrappers the translation unit needs
@@ -369,7 +375,17 @@ bool jit_compile_user_node(int fmt, int user_id, std::string& err, bool wide)
     const UserStage* u = user_stage_by_id(user_id);
     if (!u || !u->multi) { err = "not a user node"; return false; }
     if (!u->glsl && !u->buf_out.empty() && !load_expr(fill_expression(*u), {user_id}, 1, 4, err)) return false;      // RF_BUFFER_OUT: its fill kernel
+    if (u->glsl && u->glsl_window && !load_expr(window_expression(fmt, *u), {user_id}, 1, 4, err)) return false;
     return load_expr(node_expression(fmt, *u, wide), {user_id}, 1, 4, err);
+}
+
+const JitKernel* jit_lookup_glsl_window(int fmt, int user_id)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    const UserStage* u = user_stage_by_id(user_id);
+    if (!u || !u->glsl_window) return nullptr;
+    auto it = g_loaded.find(loaded_key(window_expression(fmt, *u)));
+    return it == g_loaded.end() ? nullptr : &it->second;
 }
 
 const JitKernel* jit_lookup_user_fill(int user_id)
@@ -400,6 +416,11 @@ size_t jit_compile_only_user_node(int fmt, int user_id, std::string& err)
         const Compiled* f = compile_expr(fill_expression(*u), {user_id}, 4, err);
         if (!f) return 0;
         total += f->code.size();
+    }
+    if (u->glsl && u->glsl_window) {
+        const Compiled* w = compile_expr(window_expression(fmt, *u), {user_id}, 4, err);
+        if (!w) return 0;
+        total += w->code.size();
     }
     const Compiled* c = compile_expr(node_expression(fmt, *u), {user_id}, 4, err);
     return c ? total + c->code.size() : 0;

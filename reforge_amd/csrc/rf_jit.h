@@ -42,7 +42,9 @@ size_t jit_compile_only(int fmt, int pf, int texels, const StageList& sl, int wa
 // wide: the node's images are 4 GiB or larger (a .comp node then addresses its texels with 64-bit pointers instead of buffer loads with a 32-bit offset)
 bool jit_compile_user_node(int fmt, int user_id, std::string& err, bool wide = false);
 const JitKernel* jit_lookup_user_node(int fmt, int user_id, bool wide = false);
-const JitKernel* jit_lookup_user_fill(int user_id);      // user_fill_kernel<Stage> of a node that declares RF_BUFFER_OUT
+const JitKernel* jit_lookup_user_fill(int user_id);
+// a .comp stencil (UserStage::glsl_window): its window kernel, rf::user_node_kernel<Px, the generated stage> (compiled by jit_compile_user_node with the generic one)
+const JitKernel* jit_lookup_glsl_window(int fmt, int user_id);      // user_fill_kernel<Stage> of a node that declares RF_BUFFER_OUT
 size_t jit_compile_only_user_node(int fmt, int user_id, std::string& err);
 
 }  // namespace rf

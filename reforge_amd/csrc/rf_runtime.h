@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -112,6 +113,8 @@ struct rf_graph {
     bool exchanged_once = false;           // the first halo exchange of THIS graph is waited for with a deadline
     // A storage buffer a user node FILLS on the device (RF_BUFFER_OUT) is one per graph, where the reference has one per frame
     // slot: frames of such a graph on different slots are ordered one behind the other (submit_frame) instead of overlapping
+    bool glsl_no_window = false;           // RF_EXEC_GLSL_NO_WINDOW: .comp stencils run on their generic kernel only
+    std::set<std::string> glsl_window_ok;  // launches (labels) of .comp stencils whose window kernel agreed with the generic one at graph creation
     bool fills_buffers = false;
     hipEvent_t buffers_idle = nullptr;
     bool buffers_idle_set = false;

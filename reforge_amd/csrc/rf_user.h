@@ -56,6 +56,7 @@ struct UserStage {
     std::vector<bool> glsl_image_written;          // the variable is not readonly
     int glsl_buffers = 0, glsl_groups[3] = {1, 1, 1};
     bool glsl_grouped = false;
+    bool glsl_window = false;     // recognised as a translation-invariant stencil: its interior runs on user_node_kernel (LDS tiles), its border ring on the generic kernel
     std::string glsl_source;      // the translation
     std::string file_name() const { return type_name + (glsl ? ".comp" : ".stage.hip"); }
     std::vector<UserParam> params;

@@ -267,6 +267,59 @@ def test_a_point_shader_fuses_with_its_neighbours(glsl_dir):
     assert rf.Plan(rf.Config(text), rf.RF_GRAPH_NO_FUSION).launches() == ["gg", "gn", "iv", "sh"]
 
 
+# ---- translation-invariant stencils run on the LDS-tiled window kernel -----------------------------------------------------------------------
+BOX5 = """#version 450
+#pragma rf radius 2
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform readonly image2D input_image;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+layout (binding = 2) uniform Params { float gain; };
+vec4 tap(ivec2 q, ivec2 size) { return imageLoad(input_image, clamp(q, ivec2(0), size - 1)); }
+void main()
+{
+    ivec2 size = imageSize(output_image);
+    ivec2 p = ivec2(gl_GlobalInvocationID.xy);
+    if (p.x >= size.x || p.y >= size.y) return;
+    vec4 acc = vec4(0.0);
+    for (int dy = -2; dy <= 2; ++dy) {
+        int yy = p.y + dy;
+        for (int dx = -2; dx <= 2; ++dx) acc += tap(ivec2(p.x + dx, yy), size);
+    }
+    imageStore(output_image, p, acc * gain);
+}
+"""
+NOT_STENCIL = {
+    "the position in a float": BOX5.replace("acc * gain", "acc * gain * float(p.x & 1)"),
+    "the frame size in a float": BOX5.replace("acc * gain", "acc * gain / float(size.x)"),
+    "a loop bound by the position": BOX5.replace("dx <= 2;", "dx <= p.x;"),
+    "a branch on the position": BOX5.replace("    vec4 acc", "    if (p.x == 100) { imageStore(output_image, p, vec4(1.0)); return; }\n    vec4 acc"),
+    "the position through an integer into a float": BOX5.replace("    vec4 acc", "    int parity = (p.x + p.y) & 1;\n    vec4 acc").replace("acc * gain", "acc * gain * float(parity)"),
+    "the position through a helper into a float": BOX5.replace("void main()", "float fade(int x) { return float(x) * 0.001; }\nvoid main()").replace("acc * gain", "acc * gain * fade(p.x)"),
+    "a store somewhere else": BOX5.replace("imageStore(output_image, p,", "imageStore(output_image, ivec2(size.x - 1 - p.x, p.y),"),
+    "no stated radius": BOX5.replace("#pragma rf radius 2\n", ""),
+    "an image read and written": BOX5.replace("uniform readonly image2D input_image", "uniform image2D input_image"),
+}
+
+
+def test_translation_invariant_stencils_are_recognised_conservatively():
+    r = rf.glsl_reflect("box5", BOX5)
+    assert r["stencil"] and not r["point"] and r["radius"] == 2
+    for why, text in NOT_STENCIL.items():
+        assert not rf.glsl_reflect("box5", text)["stencil"], why
+    stencil = {t for t in COMP if rf.glsl_reflect(t, text_of(t))["stencil"]}
+    assert stencil == {"gaussian5", "gaussian9", "sharpen", "edge_detect", "local_contrast"}, stencil      # (gaussian: 80 bytes of uniforms; conv2d: a storage block)
+
+
+def test_a_recognised_stencil_compiles_its_window_kernel_too(glsl_dir):
+    (glsl_dir / "box5.comp").write_text(BOX5)
+    p = rf.Plan(rf.Config("input -> bb -> output\nbb: box5 { gain: 0.04 }"))
+    two = p.jit_compile(rf.RF_FORMAT_RGBA32F)
+    (glsl_dir / "box5.comp").write_text(NOT_STENCIL["the position in a float"])
+    os.utime(glsl_dir / "box5.comp", ns=(10 ** 18, 10 ** 18))
+    one = rf.Plan(rf.Config("input -> bb -> output\nbb: box5 { gain: 0.04 }")).jit_compile(rf.RF_FORMAT_RGBA32F)
+    assert two > one + 8192, (two, one)      # the generic kernel and rf::user_node_kernel over the generated window stage
+
+
 # ---- == / != on vectors, specialisation constants, integer and packing built-ins --------------------------------------------------------------
 EQUALITY = """#version 450
 layout (local_size_x = 16, local_size_y = 16) in;
@@ -474,12 +527,15 @@ def test_glsl_kernels_have_no_scratch_and_batch_their_loads(tmp_path, compiler):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "compiled with" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
     files = sorted(glob.glob(str(tmp_path / "*.hsaco")))
-    assert len(files) == 10, files      # five graphs x two formats, one GLSL kernel each (passthrough is in the catalogue)
-    many = 0
+    assert len(files) >= 10, files      # five graphs x two formats: a generic kernel each (colour_grade: a fused row stage), and the window kernels of gaussian5 / local_contrast
+    many = windows = 0
     for f in files:
         notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f], capture_output=True, text=True, check=True).stdout
         assert ".private_segment_fixed_size: 0" in notes, "a GLSL kernel uses scratch: " + f
         for name, ins in isa_obj.functions(f).items():
+            if "user_node_kernel" in name:      # a window kernel: its taps are LDS reads at constant offsets -- no address arithmetic per tap survives
+                windows += 1
+                assert sum(1 for i in ins if i.op.startswith("ds_read")) >= 20 and not any(i.op.startswith(("global_load_dwordx4", "buffer_load")) for i in ins[len(ins) // 3:]), name
             if "glsl_node_kernel" not in name:
                 continue
             loads = [i for i in ins if i.op.startswith(("global_load", "buffer_load"))]
@@ -488,4 +544,4 @@ def test_glsl_kernels_have_no_scratch_and_batch_their_loads(tmp_path, compiler):
             if len(loads) >= 20:      # gaussian5 (25 loads) and local_contrast (26): a handful of waits, not one per load
                 many += 1
                 assert len(waits) <= len(loads) // 3, (name, len(loads), len(waits))
-    assert many == 4, many
+    assert many == 4 and windows == 4, (many, windows)

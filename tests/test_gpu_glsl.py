@@ -328,6 +328,58 @@ def test_point_shaders_fused_between_hand_written_stages(ctx, glsl_dir, fmt):
         util.assert_same(util.run_hip(ctx, text, img, flags=rf.RF_GRAPH_NO_FUSION), want, "node by node %dx%d" % (W, H))
 
 
+def box5(img, gain):
+    H, W, _ = img.shape
+    ys = np.clip(np.arange(-2, H + 2), 0, H - 1)
+    xs = np.clip(np.arange(-2, W + 2), 0, W - 1)
+    pad = img[ys][:, xs]
+    acc = np.zeros_like(img)
+    for dy in range(5):
+        for dx in range(5):
+            acc = acc + pad[dy:dy + H, dx:dx + W]
+    return acc * np.float32(gain)
+
+
+def test_a_stencil_shader_on_the_window_kernel_and_on_its_generic_kernel(ctx, glsl_dir):
+    """BOX5 (tests/test_glsl.py): a 5 x 5 box through a helper function, recognised as a translation-invariant stencil -- the LDS-tiled window
+    kernel computes the frame, the generic kernel its border ring; both ways (RF_EXEC_GLSL_NO_WINDOW) against numpy, bit for bit"""
+    from tests.test_glsl import BOX5
+    (glsl_dir / "box5.comp").write_text(BOX5)
+    text = "input -> bb -> output\nbb: box5 { gain: 0.04 }"
+    for W, H in ((250, 131), (64, 5), (5, 64), (4, 4), (96, 64)):
+        img = util.synthetic(W, H, util.F32, seed=W)
+        want = box5(img, 0.04)
+        g = rf.Graph(ctx, rf.Config(text), W, H, util.F32)
+        try:
+            assert g.note == "", g.note      # the self-test of rf_graph_create accepted the window kernel
+            g.upload_raw(img)
+            g.execute()
+            g.wait()
+            util.assert_same(g.download_raw(), want, "window kernel %dx%d" % (W, H))
+        finally:
+            g.close()
+        util.assert_same(util.run_hip(ctx, text, img, exec_flags=rf.RF_EXEC_GLSL_NO_WINDOW), want, "generic kernel %dx%d" % (W, H))
+
+
+def test_a_shader_that_reads_further_than_it_states_keeps_its_generic_kernel(ctx, glsl_dir):
+    """gaussian9.comp reads 4 texels out; with `#pragma rf radius 2` its window kernel cannot agree with the generic one: rf_graph_create
+    finds out on a random frame, says so, and the graph gives the right frame on the generic kernel"""
+    src = open(os.path.join(SHADERS, "gaussian9.comp")).read()
+    assert "#pragma rf radius 4" in src
+    (glsl_dir / "gaussian9.comp").write_text(src.replace("#pragma rf radius 4", "#pragma rf radius 2"))
+    text = TWINS["gaussian9"][1]
+    img = util.synthetic(200, 90, util.F32)
+    g = rf.Graph(ctx, rf.Config(text), 200, 90, util.F32)
+    try:
+        assert "keeps its generic kernel" in g.note and "gaussian9.comp" in g.note, g.note
+        g.upload_raw(img)
+        g.execute()
+        g.wait()
+        util.assert_same(g.download_raw(), util.run_oracle(text, img), "understated radius")
+    finally:
+        g.close()
+
+
 def test_equality_of_vectors_and_the_integer_built_ins_on_the_gpu(ctx, glsl_dir):
     from tests.test_glsl import EQUALITY, equality
     (glsl_dir / "equality.comp").write_text(EQUALITY)
