@@ -234,6 +234,8 @@ long long   rf_user_stage_mtime(const char* type_name);
  * "T.comp:LINE: why", like a file that does not compile (Option::None + warning, shader.rs:92; the caller keeps its graph).
  * A file that is provably a POINT operation on one image (every load and store at the invocation's own texel, position used only in
  * the frame guard) also becomes a row stage of the stream kernel and fuses with its neighbours (rf_plan_launch_label shows it).
+ * A stencil file (radius >= 2) that is provably translation-invariant also runs on the LDS-tiled window kernel of the stage files;
+ * rf_graph_create compares that kernel with the file's generic kernel on a random frame and keeps it only if they agree (rf_graph_note).
  * [host] the translation of `text` (HIP device source; its first line is a comment naming the namespace it lives in) */
 rf_status   rf_glsl_translate(const char* type_name, const char* text, char* buf, size_t cap, size_t* len);
 /* [host] the reflection of `text` as JSON: {"local_size": [x, y, z], "grouped", "radius" (-1: not stated), "uniform_bytes",
