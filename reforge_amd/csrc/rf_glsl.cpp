@@ -981,30 +981,42 @@ bool stencil_shader(const std::string& text, const GlslShader& sh)
     }
     if (in_names.empty() || out_names.empty() || in_names.size() > 4 || out_names.size() > 4) return false;
     const std::vector<Tok> t = lex(text);
+    const size_t N = t.size();
     auto is_image = [&](const std::string& s) { return in_names.count(s) || out_names.count(s); };
     static const std::set<std::string> int_types = {"int", "uint", "ivec2", "ivec3", "ivec4", "uvec2", "uvec3", "uvec4"};
     static const char* forbidden[] = {"gl_WorkGroupID", "gl_LocalInvocationID", "gl_LocalInvocationIndex", "gl_NumWorkGroups", "gl_WorkGroupSize"};
-    // functions: name -> (parameter names, parameter types, by-reference flags, body range, return type)
-    struct Fn { std::vector<std::string> pname, ptype; std::vector<bool> byref; size_t b = 0, e = 0; std::string ret; };
+    for (const auto& q : t) {
+        if (q.k == T_PP) {
+            const std::vector<Tok> d = lex(q.s.substr(1));
+            for (const auto& w : d)
+                if (w.k == T_ID && (w.s == "gl_GlobalInvocationID" || w.s == "imageSize" || w.s == "imageLoad" || w.s == "imageStore" || is_image(w.s))) return false;
+        } else if (q.k == T_ID) {
+            for (const char* f : forbidden)
+                if (q.s == f) return false;
+        }
+    }
+    // ---- functions -----------------------------------------------------------------------------------------------------------------
+    struct Fn { std::vector<std::string> pname, ptype; std::vector<bool> byref; std::vector<size_t> pat; size_t b = 0, e = 0; std::string ret; };
     std::map<std::string, Fn> fns;
     {
         int depth = 0;
-        for (size_t i = 0; i + 3 < t.size(); ++i) {
-            if (t[i].k == T_PUNCT && (t[i].s == "{" )) ++depth;
-            if (t[i].k == T_PUNCT && (t[i].s == "}" )) --depth;
+        for (size_t i = 0; i + 3 < N; ++i) {
+            if (is(t[i], "{")) ++depth;
+            if (is(t[i], "}")) --depth;
             if (depth != 0 || t[i].k != T_ID || t[i + 1].k != T_ID || !is(t[i + 2], "(")) continue;
-            const size_t close = match(t, i + 2, t.size());
+            const size_t close = match(t, i + 2, N);
             if (!is(t[close + 1], "{")) continue;
             Fn f;
             f.ret = t[i].s;
             f.b = close + 2;
-            f.e = match(t, close + 1, t.size());
+            f.e = match(t, close + 1, N);
             size_t pb = i + 3;
             while (pb < close) {
                 size_t pe = pb;
                 int d = 0;
                 while (pe < close && !(d == 0 && is(t[pe], ","))) { if (is(t[pe], "(") || is(t[pe], "[")) ++d; if (is(t[pe], ")") || is(t[pe], "]")) --d; ++pe; }
                 std::string ty, nm;
+                size_t at = 0;
                 bool ref = false;
                 int bd = 0;
                 for (size_t k = pb; k < pe; ++k) {
@@ -1014,26 +1026,93 @@ bool stencil_shader(const std::string& text, const GlslShader& sh)
                     if (t[k].s == "out" || t[k].s == "inout") ref = true;
                     else if (t[k].s == "in" || t[k].s == "const" || dropped_qualifiers().count(t[k].s)) {}
                     else if (ty.empty()) ty = t[k].s;
-                    else nm = t[k].s;
+                    else { nm = t[k].s; at = k; }
                 }
-                if (!ty.empty() && ty != "void") { f.ptype.push_back(ty); f.pname.push_back(nm); f.byref.push_back(ref); }
+                if (!ty.empty() && ty != "void") { f.ptype.push_back(ty); f.pname.push_back(nm); f.byref.push_back(ref); f.pat.push_back(at); }
                 pb = pe + 1;
             }
             fns[t[i + 1].s] = f;
-            i = close;      // the body is scanned by the passes below
+            i = close;
         }
     }
     if (!fns.count("main")) return false;
-    // names the position or the frame size has reached
-    std::set<std::string> tainted = {"gl_GlobalInvocationID", "imageSize"};
-    std::set<std::string> int_returning;      // helpers that return an integer computed with tainted arguments: their calls are tainted values
-    std::vector<char> ok;
-    auto has_taint = [&](size_t a, size_t b) {
-        for (size_t k = a; k < b; ++k)
-            if (t[k].k == T_ID && (tainted.count(t[k].s) || int_returning.count(t[k].s)) && !(k > 0 && is(t[k - 1], "."))) return true;
-        return false;
+    // ---- integer variables, each with the range of tokens it is visible in -------------------------------------------------------
+    // position reaches a variable (`pos`) / a uniform reaches it (`var`): flags of the DECLARATION, so that the `i` of one loop is not the
+    // `i` of another
+    struct Decl { std::string name; size_t at, b, e; bool pos = false, var = false; };
+    std::vector<Decl> decls;
+    for (const auto& kv : fns) {
+        const Fn& f = kv.second;
+        for (size_t p = 0; p < f.pname.size(); ++p)
+            if (int_types.count(f.ptype[p]) && !f.pname[p].empty()) decls.push_back(Decl{f.pname[p], f.pat[p], f.b, f.e});
+        std::vector<size_t> block_end;      // innermost last: where the enclosing { } ends
+        block_end.push_back(f.e);
+        std::vector<std::pair<size_t, size_t>> for_scope;      // (init range end, statement end) of the `for` statements we are inside the header of
+        for (size_t i = f.b; i < f.e; ++i) {
+            if (is(t[i], "{")) block_end.push_back(match(t, i, f.e));
+            else if (is(t[i], "}") && block_end.size() > 1) block_end.pop_back();
+            if (t[i].k != T_ID || !int_types.count(t[i].s) || t[i + 1].k != T_ID || is(t[i + 1], "(")) continue;
+            // the scope: the enclosing block -- or, in the header of a `for`, that statement
+            size_t scope_end = block_end.back();
+            {
+                size_t k = i;      // are we inside `for ( ... ;` ?  walk back over the init expression to the opening parenthesis
+                int d = 0;
+                while (k > f.b) {
+                    --k;
+                    if (is(t[k], ")") || is(t[k], "]")) ++d;
+                    else if (is(t[k], "(") || is(t[k], "[")) { if (d == 0) break; --d; }
+                    else if (d == 0 && (is(t[k], ";") || is(t[k], "{") || is(t[k], "}"))) { k = 0; break; }
+                }
+                if (k > f.b && is(t[k], "(") && t[k - 1].k == T_ID && t[k - 1].s == "for") {
+                    const size_t close = match(t, k, f.e);
+                    size_t b1 = close + 1;
+                    if (is(t[b1], "{")) scope_end = match(t, b1, f.e) + 1;
+                    else { int d2 = 0; while (b1 < f.e && !(d2 == 0 && is(t[b1], ";"))) { if (is(t[b1], "(") || is(t[b1], "{")) ++d2; if (is(t[b1], ")") || is(t[b1], "}")) --d2; ++b1; } scope_end = b1 + 1; }
+                }
+            }
+            size_t k = i + 1;
+            for (;;) {      // INTTYPE a = e, b[3], c = e2;
+                if (t[k].k != T_ID) break;
+                decls.push_back(Decl{t[k].s, k, k, scope_end});
+                size_t q = k + 1;
+                while (is(t[q], "[")) q = match(t, q, f.e) + 1;
+                if (is(t[q], "=")) {
+                    int d = 0;
+                    ++q;
+                    while (q < f.e && !(d == 0 && (is(t[q], ",") || is(t[q], ";") || is(t[q], ")")))) { if (is(t[q], "(") || is(t[q], "[") || is(t[q], "{")) ++d; if (is(t[q], ")") || is(t[q], "]") || is(t[q], "}")) --d; ++q; }
+                }
+                if (is(t[q], ",")) { k = q + 1; continue; }
+                break;
+            }
+        }
+    }
+    auto resolve = [&](size_t i) -> Decl* {      // the declaration an identifier at i names: the innermost one in scope
+        Decl* best = nullptr;
+        for (auto& d : decls)
+            if (d.name == t[i].s && d.b <= i && i < d.e && (!best || d.b >= best->b)) best = &d;
+        return best;
     };
-    auto arg_end = [&](size_t a, size_t limit) {      // end of the argument (or declarator) starting at a: the next `,` `;` or closing bracket at depth 0
+    std::set<std::string> uniforms;
+    for (const auto& blk : sh.ubos) {
+        if (!blk.instance.empty()) uniforms.insert(blk.instance);
+        for (const auto& m : blk.members) uniforms.insert(m.name.substr(m.name.rfind('.') == std::string::npos ? 0 : m.name.rfind('.') + 1));
+    }
+    std::set<std::string> int_returning;      // helpers that return an integer computed from the position: their calls are such values
+    auto names = [&](size_t i) { return t[i].k == T_ID && !(i > 0 && is(t[i - 1], ".")); };
+    auto pos_at = [&](size_t i) {
+        if (!names(i)) return false;
+        if (t[i].s == "gl_GlobalInvocationID" || t[i].s == "imageSize" || int_returning.count(t[i].s)) return true;
+        const Decl* d = resolve(i);
+        return d && d->pos;
+    };
+    auto var_at = [&](size_t i) {
+        if (!names(i)) return false;
+        const Decl* d = resolve(i);
+        return d ? d->var : uniforms.count(t[i].s) > 0;
+    };
+    auto has_pos = [&](size_t a, size_t b) { for (size_t k = a; k < b; ++k) if (pos_at(k)) return true; return false; };
+    auto has_var = [&](size_t a, size_t b) { for (size_t k = a; k < b; ++k) if (var_at(k)) return true; return false; };
+    auto arg_end = [&](size_t a, size_t limit) {
         int d = 0;
         size_t k = a;
         for (; k < limit; ++k) {
@@ -1045,23 +1124,13 @@ bool stencil_shader(const std::string& text, const GlslShader& sh)
         }
         return k;
     };
-    for (const auto& q : t) {
-        if (q.k == T_PP) {
-            const std::vector<Tok> d = lex(q.s.substr(1));
-            for (const auto& w : d)
-                if (w.k == T_ID && (w.s == "gl_GlobalInvocationID" || w.s == "imageSize" || w.s == "imageLoad" || w.s == "imageStore" || is_image(w.s))) return false;
-        } else if (q.k == T_ID) {
-            for (const char* f : forbidden)
-                if (q.s == f) return false;
-        }
-    }
     // pure coordinate / size variables of main (the frame guard and the store coordinate are written with these)
     const Fn& mainf = fns["main"];
     std::set<std::string> pure_coord, pure_size;
     auto seq = [&](size_t i, std::initializer_list<const char*> pat) {
         size_t k = i;
         for (const char* p : pat) {
-            if (k >= t.size()) return false;
+            if (k >= N) return false;
             if (std::string(p) == "$ID") { if (t[k].k != T_ID) return false; }
             else if (!is(t[k], p)) return false;
             ++k;
@@ -1084,50 +1153,92 @@ bool stencil_shader(const std::string& text, const GlslShader& sh)
         if (t[i].k == T_ID && pure_size.count(t[i].s)) return 1;
         return (seq(i, {"imageSize", "(", "$ID", ")"}) && is_image(t[i + 2].s)) ? 4 : 0;
     };
-    for (int round = 0; round < 16; ++round) {
-        const size_t before = tainted.size() + int_returning.size();
-        ok.assign(t.size(), 0);
+    std::vector<char> ok, controlled;
+    auto flags = [&]() { size_t n = int_returning.size(); for (const auto& d : decls) n += (d.pos ? 1 : 0) + (d.var ? 2 : 0); return n; };
+    for (int round = 0; round < 24; ++round) {
+        const size_t before = flags();
+        ok.assign(N, 0);
+        controlled.assign(N, 0);
         auto mark = [&](size_t a, size_t b) { for (size_t k = a; k < b; ++k) ok[k] = 1; };
+        // statements whose execution depends on a uniform: what they assign follows the uniform too
+        for (const auto& kv : fns) {
+            const Fn& f = kv.second;
+            for (size_t i = f.b; i < f.e; ++i) {
+                if (t[i].k != T_ID || !(t[i].s == "if" || t[i].s == "for" || t[i].s == "while") || !is(t[i + 1], "(")) continue;
+                const size_t close = match(t, i + 1, f.e);
+                size_t c0 = i + 2, c1 = close;
+                if (t[i].s == "for") {
+                    int d = 0;
+                    std::vector<size_t> semi;
+                    for (size_t k = i + 2; k < close; ++k) {
+                        if (is(t[k], "(") || is(t[k], "[")) ++d;
+                        if (is(t[k], ")") || is(t[k], "]")) --d;
+                        if (d == 0 && is(t[k], ";")) semi.push_back(k);
+                    }
+                    if (semi.size() == 2) { c0 = semi[0] + 1; c1 = semi[1]; }
+                }
+                if (!has_var(c0, c1)) continue;
+                for (size_t k = c0; k < c1; ++k)
+                    if (names(k)) if (Decl* d = resolve(k)) d->var = true;
+                size_t b0 = close + 1, b1;
+                for (;;) {
+                    if (is(t[b0], "{")) b1 = match(t, b0, f.e) + 1;
+                    else { b1 = b0; int d = 0; while (b1 < f.e && !(d == 0 && is(t[b1], ";"))) { if (is(t[b1], "(") || is(t[b1], "{")) ++d; if (is(t[b1], ")") || is(t[b1], "}")) --d; ++b1; } ++b1; }
+                    for (size_t k = (t[i].s == "for" ? i : b0); k < b1 && k < f.e; ++k) controlled[k] = 1;
+                    if (b1 < f.e && t[b1].k == T_ID && t[b1].s == "else") { b0 = b1 + 1; continue; }
+                    break;
+                }
+            }
+        }
         for (const auto& kv : fns) {
             const Fn& f = kv.second;
             for (size_t i = f.b; i < f.e; ++i) {
                 if (t[i].k != T_ID) continue;
                 const std::string& w = t[i].s;
                 if (int_types.count(w) && t[i + 1].k == T_ID && !is(t[i + 1], "(")) {
-                    // INTTYPE a = e, b = e2, c;  : every initialiser may use position; what it uses it taints
                     size_t k = i + 1;
                     for (;;) {
                         if (t[k].k != T_ID) break;
-                        const std::string name = t[k].s;
+                        Decl* d = nullptr;
+                        for (auto& q : decls) if (q.at == k) d = &q;
+                        if (!d) return false;
+                        if (controlled[k]) d->var = true;
                         size_t q = k + 1;
                         while (is(t[q], "[")) q = match(t, q, f.e) + 1;
                         if (is(t[q], "=")) {
                             const size_t e = arg_end(q + 1, f.e);
-                            if (has_taint(q + 1, e)) tainted.insert(name);
+                            if (has_var(q + 1, e)) d->var = true;
+                            if (has_pos(q + 1, e)) d->pos = true;
                             mark(i, e);
                             q = e;
                         }
                         if (is(t[q], ",")) { k = q + 1; continue; }
                         break;
                     }
-                } else if ((tainted.count(w)) && !(i > 0 && is(t[i - 1], ".")) && (is(t[i - 1], ";") || is(t[i - 1], "{") || is(t[i - 1], "}") || is(t[i - 1], ")"))) {
-                    // NAME = e;  NAME += e;  NAME.x = e;  at the start of a statement: an assignment to an integer the position has reached
+                } else if (names(i) && resolve(i) && (is(t[i - 1], ";") || is(t[i - 1], "{") || is(t[i - 1], "}") || is(t[i - 1], ")"))) {
+                    // NAME = e;  NAME += e;  NAME.x = e;  ++ / -- are left alone  -- an assignment to an integer variable
+                    Decl* d = resolve(i);
                     size_t q = i + 1;
                     while (is(t[q], ".") || (t[q].k == T_ID && is(t[q - 1], "."))) ++q;
                     if (t[q].k == T_PUNCT && std::string("+-*/%&|^").find(t[q].s[0]) != std::string::npos && is(t[q + 1], "=")) ++q;
-                    if (is(t[q], "=") && !is(t[q + 1], "=")) mark(i, arg_end(q + 1, f.e));
+                    if (is(t[q], "=") && !is(t[q + 1], "=")) {
+                        const size_t e = arg_end(q + 1, f.e);
+                        if (has_var(q + 1, e) || controlled[i]) d->var = true;
+                        if (has_pos(q + 1, e)) d->pos = true;
+                        if (d->pos) mark(i, e);
+                    }
                 } else if ((w == "imageLoad" || w == "imageStore") && is(t[i + 1], "(") && t[i + 2].k == T_ID && is(t[i + 3], ",")) {
                     const bool load = w == "imageLoad";
                     if (!(load ? in_names.count(t[i + 2].s) : out_names.count(t[i + 2].s))) return false;
                     const size_t e = arg_end(i + 4, f.e);
+                    if (has_var(i + 4, e)) return false;      // a coordinate that follows a parameter: rf_graph_create could not vouch for later frames
                     if (!load) {
-                        // a store: in main(), at the invocation's own coordinate
-                        const size_t n = coord_at(i + 4);
+                        const size_t n = coord_at(i + 4);      // a store: in main(), at the invocation's own coordinate
                         if (kv.first != "main" || !n || i + 4 + n != e) return false;
                     }
                     mark(i, e);
                 } else if (w == "imageSize" && is(t[i + 1], "(") && t[i + 2].k == T_ID && is_image(t[i + 2].s) && is(t[i + 3], ")")) {
-                    ok[i + 2] = 1;      // (the call itself is a tainted value: allowed only where such values are)
+                    ok[i + 2] = 1;
                 } else if (w == "if" && is(t[i + 1], "(") && kv.first == "main") {
                     const size_t close = match(t, i + 1, f.e);
                     size_t k = close + 1;
@@ -1160,16 +1271,20 @@ bool stencil_shader(const std::string& text, const GlslShader& sh)
                     }
                     if (guard) mark(i, close + 1);
                 } else if (fns.count(w) && is(t[i + 1], "(") && w != kv.first) {
-                    // a helper call: a tainted argument taints the parameter it lands in (an integer, passed by value)
+                    // a helper call: what an argument carries lands in the parameter (an integer, passed by value)
                     const Fn& h = fns.at(w);
                     const size_t close = match(t, i + 1, f.e);
                     size_t a = i + 2;
                     bool any = false;
                     for (size_t p = 0; a < close; ++p) {
                         const size_t e = arg_end(a, close);
-                        if (has_taint(a, e)) {
-                            if (p >= h.pname.size() || !int_types.count(h.ptype[p]) || h.byref[p]) return false;
-                            tainted.insert(h.pname[p]);
+                        Decl* pd = nullptr;
+                        if (p < h.pname.size())
+                            for (auto& q : decls) if (q.at == h.pat[p] && q.b == h.b) pd = &q;
+                        if (has_var(a, e) && pd) pd->var = true;
+                        if (has_pos(a, e)) {
+                            if (!pd || h.byref[p]) return false;
+                            pd->pos = true;
                             mark(a, e);
                             any = true;
                         }
@@ -1179,25 +1294,23 @@ bool stencil_shader(const std::string& text, const GlslShader& sh)
                 }
             }
         }
-        if (tainted.size() + int_returning.size() == before && round > 0) break;
+        if (flags() == before && round > 0) break;
     }
-    // the verdict: a tainted name outside every allowed place?  an image variable that is not the first argument of an image function?
+    // a variable the position AND a uniform reach cannot be vouched for
+    for (const auto& d : decls)
+        if (d.pos && d.var) return false;
+    // the verdict: the position outside every allowed place?  an image variable that is not the first argument of an image function?
     for (const auto& kv : fns)
         for (size_t i = kv.second.b; i < kv.second.e; ++i) {
-            if (t[i].k != T_ID || (i > 0 && is(t[i - 1], "."))) continue;
+            if (!names(i)) continue;
             if (is_image(t[i].s) && !(i >= 2 && is(t[i - 1], "(") && (t[i - 2].s == "imageLoad" || t[i - 2].s == "imageStore" || t[i - 2].s == "imageSize"))) return false;
-            if ((tainted.count(t[i].s) || int_returning.count(t[i].s)) && !ok[i]) {
-                // the declaration of a tainted parameter is not a use
-                if (i + 1 < t.size() && (is(t[i + 1], ",") || is(t[i + 1], ")")) && i < kv.second.b) continue;
-                return false;
-            }
+            if (pos_at(i) && !ok[i]) return false;
         }
-    // outside function bodies: no image function, no position
     {
-        std::vector<char> inside(t.size(), 0);
+        std::vector<char> inside(N, 0);
         for (const auto& kv : fns)
             for (size_t i = kv.second.b; i < kv.second.e; ++i) inside[i] = 1;
-        for (size_t i = 0; i < t.size(); ++i)
+        for (size_t i = 0; i < N; ++i)
             if (!inside[i] && t[i].k == T_ID && (t[i].s == "gl_GlobalInvocationID" || t[i].s == "imageSize" || t[i].s == "imageLoad" || t[i].s == "imageStore")) return false;
     }
     return true;

@@ -296,6 +296,8 @@ NOT_STENCIL = {
     "the position through an integer into a float": BOX5.replace("    vec4 acc", "    int parity = (p.x + p.y) & 1;\n    vec4 acc").replace("acc * gain", "acc * gain * float(parity)"),
     "the position through a helper into a float": BOX5.replace("void main()", "float fade(int x) { return float(x) * 0.001; }\nvoid main()").replace("acc * gain", "acc * gain * fade(p.x)"),
     "a store somewhere else": BOX5.replace("imageStore(output_image, p,", "imageStore(output_image, ivec2(size.x - 1 - p.x, p.y),"),
+    "an offset that follows a parameter": BOX5.replace("uniform Params { float gain; }", "uniform Params { float gain; int reach; }").replace("p.x + dx, yy", "p.x + dx * reach, yy"),
+    "a loop bound by a parameter feeding the coordinate": BOX5.replace("uniform Params { float gain; }", "uniform Params { float gain; int reach; }").replace("dx <= 2;", "dx <= reach;"),
     "no stated radius": BOX5.replace("#pragma rf radius 2\n", ""),
     "an image read and written": BOX5.replace("uniform readonly image2D input_image", "uniform image2D input_image"),
 }
