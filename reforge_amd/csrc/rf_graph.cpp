@@ -301,6 +301,17 @@ static hipError_t launch_glsl_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     return jit_launch(*k, (unsigned)((tiles + 7) / 8 * 8), 256, args.data(), args.size(), stream);
 }
 
+// Does a recognised .comp stencil run on its window kernel in this graph?  Radius >= 2: yes.  Radius 1: on rgba8 only -- measured at 4K
+// (profiles/r04_glsl_radius1_ab.txt): rgba32f sharpen.comp 39.3 us generic against 47.5 window + border ring, edge_detect.comp 51.0 / 50.2;
+// rgba8 35.4 / 29.8 and 51.3 / 36.9 (there the generic kernel's per-load conversions are what the window's registers save).
+static bool glsl_wants_window(const rf_graph* g, const UserStage* u)
+{
+    static const int min_radius = [] { const char* e = std::getenv("RF_GLSL_WINDOW_MIN_RADIUS"); return e && std::atoi(e) > 0 ? std::atoi(e) : 0; }();      // (A/B)
+    if (!u->glsl || !u->glsl_window || g->glsl_no_window) return false;
+    if (min_radius > 0) return u->radius >= min_radius;
+    return u->radius >= 2 || g->opt.format == RF_FORMAT_RGBA8;
+}
+
 // an image of this graph spans 4 GiB or more (16384^2 rgba32f): beyond a 32-bit byte offset
 static bool wide_images(const rf_graph* g)
 {
@@ -321,7 +332,7 @@ static hipError_t launch_user_node(rf_graph* g, const Launch& L, FrameSlot& f, c
     // shader's own treatment of the frame's edges decides (interior texels cannot tell the two apart)
     bool ring_after = false;
     if (u->glsl) {
-        const bool window = u->glsl_window && g->glsl_window_ok.count(L.label) && geo.W > 2 * u->radius && g->opt.height > 2 * u->radius;
+        const bool window = glsl_wants_window(g, u) && g->glsl_window_ok.count(L.label) && geo.W > 2 * u->radius && g->opt.height > 2 * u->radius;
         if (!window) return launch_glsl_node(g, L, f, geo, stream, u, k);
         ring_after = true;
     }
@@ -934,7 +945,7 @@ static void glsl_window_selftests(rf_graph* g)
     for (const auto& L : g->launches) {
         if (L.ops.size() != 1 || L.ops[0].kind != OP_USERN) continue;
         const UserStage* u = user_stage_by_id(L.ops[0].user_id);
-        if (!u || !u->glsl || !u->glsl_window) continue;
+        if (!u || !glsl_wants_window(g, u)) continue;
         if (t_in_selftest) { g->glsl_window_ok.insert(L.label); continue; }      // the inner graph of a self-test: this IS the kernel under test
         t_in_selftest = true;
         std::string why;

@@ -218,8 +218,7 @@ bool parse_glsl_stage(const std::string& type, const std::string& text, UserStag
     static const bool no_fuse = [] { const char* e = std::getenv("RF_GLSL_NO_FUSE"); return e && std::atoi(e) != 0; }();
     if (sh.point && !no_fuse) out.multi = false;
     static const bool no_window = [] { const char* e = std::getenv("RF_GLSL_NO_WINDOW"); return e && std::atoi(e) != 0; }();
-    // (radius 1: the generic kernel's nine loads through L1 beat a window launch plus a border launch -- sharpen.comp 39 vs 47 us at 4K)
-    out.glsl_window = sh.stencil && sh.radius >= 2 && !no_window;
+    out.glsl_window = sh.stencil && !no_window;      // (which graphs use it: glsl_wants_window, rf_graph.cpp)
     out.radius = sh.radius < 0 ? 0 : sh.radius;
     out.radius_stated = sh.radius >= 0;
     out.glsl_grouped = sh.grouped;

@@ -20,6 +20,7 @@ CASES = [   # (name, types as files, config, images moved per texel)
     ("colour_grade", ["colour_grade"], "input -> cg -> output\ncg: colour_grade { slope: 1.1, offset: -0.02, saturation: 1.2 }", 2),
     ("unsharp_mask", ["unsharp_mask"], "input -> bl -> um:blurred_image\ninput -> um:input_image\num -> output\nbl: passthrough {}\num: unsharp_mask { amount: 1.5, threshold: 0.02 }", 3),
     ("sharpen", ["sharpen"], "input -> sh -> output\nsh: sharpen { amount: 0.5 }", 2),
+    ("edge_detect", ["edge_detect"], "input -> ed -> output\ned: edge_detect { scale: 1.5 }", 2),
     ("gaussian5", ["gaussian5"], "input -> gg -> output\ngg: gaussian5 { sigma: 1.0, %s }" % glsl_weights.as_params(1.0, 2), 2),
     ("local_contrast", ["local_contrast"], "input -> lc -> output\nlc: local_contrast { amount: 0.8 }", 2),
 ]
