@@ -53,7 +53,7 @@ void usage()
 {
     std::fputs(
         "Usage: reforge [OPTIONS] [shader]\n\n"
-        "Arguments:\n  [shader]  A single filter type to execute instead of a config\n\n"
+        "Arguments:\n  [shader]  A single filter to execute instead of a config: a type name, or the path of a .comp (GLSL) / .stage.hip file\n\n"
         "Options:\n"
         "  -i, --input-file <INPUT_FILE>      File to read from (.png, .ppm P6 or .rgba raw)\n"
         "  -o, --output-file <OUTPUT_FILE>    File to write to (.png, .ppm or .rgba)\n"
@@ -276,6 +276,19 @@ static int run(int argc, char** argv)
     // create_config, render.rs:100-119 (nullptr + warning on a user error)
     (void)rf_set_shader_path(args.shader_path.c_str());       // Config::new(path, shader_path), config.rs:59-75
     (void)rf_set_type_lookup(args.files_first ? 1 : 0);
+    {
+        // `reforge [shader]` names a FILE (single_shader_parse, config.rs:77-90: the pipeline is that file, whatever the shader path):
+        // an existing .comp / .stage.hip given by path is looked up where it lies, and it wins over a built-in type of its name
+        struct stat st;
+        const std::string& sp = args.shader_file_path;
+        const bool is_file = sp.size() > 5 && (sp.compare(sp.size() - 5, 5, ".comp") == 0 || (sp.size() > 10 && sp.compare(sp.size() - 10, 10, ".stage.hip") == 0));
+        if (is_file && ::stat(sp.c_str(), &st) == 0) {
+            const size_t slash = sp.find_last_of('/');
+            args.shader_path = slash == std::string::npos ? "." : sp.substr(0, slash);
+            (void)rf_set_shader_path(args.shader_path.c_str());
+            (void)rf_set_type_lookup(1);
+        }
+    }
     auto create_config = [&]() -> rf_config* {
         rf_config* c = nullptr;
         if (!args.config.empty()) {
@@ -289,7 +302,7 @@ static int run(int argc, char** argv)
             std::string stem = args.shader_file_path;   // config.rs:79: file stem
             size_t slash = stem.find_last_of('/');
             if (slash != std::string::npos) stem = stem.substr(slash + 1);
-            size_t dot = stem.find_last_of('.');
+            size_t dot = stem.find('.');      // (the type of `x.stage.hip` is x)
             if (dot != std::string::npos) stem = stem.substr(0, dot);
             if (rf_config_single(stem.c_str(), has_input, &c) != RF_OK) { warnln(rf_last_error()); return nullptr; }
         } else if (rf_config_parse("input -> passthrough -> output", has_input, &c) != RF_OK) {

@@ -263,6 +263,14 @@ def test_cli_runs_a_directory_of_glsl_shaders_as_it_is(tmp_path):
     r = run_cli("-i", src, "--config", str(cfg), "-o", dst, "--shader-path", str(shaders))      # default lookup: sharpen is the built-in kernel, invert the file
     assert r.returncode == 0, r.stderr
     assert np.fromfile(dst, np.uint8).reshape(64, 96, 4).tobytes() == got.tobytes()            # the same bits either way
+    # `reforge [shader]`: the path of a shader FILE is the whole pipeline (single_shader_parse, config.rs:77-90), wherever it lies
+    one = str(tmp_path / "one.rgba")
+    r = run_cli("-i", src, "-o", one, str(shaders / "sharpen.comp"))
+    assert r.returncode == 0 and "GPU: {sharpen: " in r.stderr, r.stderr
+    (tmp_path / "only.cfg").write_text("input -> sharpen -> output")      # amount = 0 either way (absent parameters are zero, render.rs:200-203)
+    r = run_cli("-i", src, "--config", str(tmp_path / "only.cfg"), "-o", dst)
+    assert r.returncode == 0, r.stderr
+    assert np.fromfile(one, np.uint8).tobytes() == np.fromfile(dst, np.uint8).tobytes()
     with open(log, "wb") as err:
         p = subprocess.Popen([CLI, "-i", src, "--config", str(cfg), "-o", dst, "--shader-path", str(shaders), "--shader-files-first", "--frames", "300", "--watch",
                               "--frame-interval-ms", "25"], stderr=err)
