@@ -361,6 +361,35 @@ def test_a_stencil_shader_on_the_window_kernel_and_on_its_generic_kernel(ctx, gl
         util.assert_same(util.run_hip(ctx, text, img, exec_flags=rf.RF_EXEC_GLSL_NO_WINDOW), want, "generic kernel %dx%d" % (W, H))
 
 
+def test_a_stencil_that_relies_on_zeros_outside_the_image(ctx, glsl_dir):
+    """the same box WITHOUT clamps: imageLoad outside the image returns zero, so the frame's edges darken.  The window kernel's tiles hold
+    clamp-to-edge copies there -- which is why the border ring is the generic kernel's: against numpy (zero padding), both ways"""
+    from tests.test_glsl import BOX5
+    src = BOX5.replace("clamp(q, ivec2(0), size - 1)", "q")
+    assert src != BOX5 and rf.glsl_reflect("box5z", src)["stencil"]
+    (glsl_dir / "box5z.comp").write_text(src)
+    text = "input -> bb -> output\nbb: box5z { gain: 0.04 }"
+    for W, H in ((250, 131), (3, 70), (70, 3), (1, 1)):
+        img = util.synthetic(W, H, util.F32, seed=W + 5)
+        pad = np.zeros((H + 4, W + 4, 4), np.float32)
+        pad[2:-2, 2:-2] = img
+        acc = np.zeros_like(img)
+        for dy in range(5):
+            for dx in range(5):
+                acc = acc + pad[dy:dy + H, dx:dx + W]
+        want = acc * np.float32(0.04)
+        g = rf.Graph(ctx, rf.Config(text), W, H, util.F32)
+        try:
+            assert g.note == "", g.note
+            g.upload_raw(img)
+            g.execute()
+            g.wait()
+            util.assert_same(g.download_raw(), want, "window kernel %dx%d" % (W, H))
+        finally:
+            g.close()
+        util.assert_same(util.run_hip(ctx, text, img, exec_flags=rf.RF_EXEC_GLSL_NO_WINDOW), want, "generic kernel %dx%d" % (W, H))
+
+
 def test_a_shader_that_reads_further_than_it_states_keeps_its_generic_kernel(ctx, glsl_dir):
     """gaussian9.comp reads 4 texels out; with `#pragma rf radius 2` its window kernel cannot agree with the generic one: rf_graph_create
     finds out on a random frame, says so, and the graph gives the right frame on the generic kernel"""
