@@ -248,6 +248,17 @@ void rewrite(std::vector<Tok>& v, size_t b, size_t e, const Ctx& cx)
         const size_t n = next_live(v, i + 1, e);
         const bool call = n < e && is(v[n], "(");
         const bool after_dot = i > b && is(v[i - 1], ".");
+        if (after_dot && t.s == "length" && call && i >= b + 2 && v[i - 2].k == T_ID && !(i >= b + 3 && is(v[i - 3], "."))) {
+            // name.length(): the number of elements of an array (of components of a vector) -- a constant either way
+            const size_t close = next_live(v, n + 1, e);
+            if (close < e && is(v[close], ")")) {
+                v[i - 2].pre += "rfg_length(";
+                v[i - 1].drop = true;      // the dot
+                t.drop = true;
+                v[n].drop = true;
+                continue;                  // the closing parenthesis stays: rfg_length(name)
+            }
+        }
         if (after_dot) {
             // a swizzle spelled with texture coordinates: clang's vectors know xyzw and rgba
             bool stpq = !t.s.empty() && t.s.size() <= 4 && !cx.struct_members.count(t.s);
@@ -267,6 +278,18 @@ void rewrite(std::vector<Tok>& v, size_t b, size_t e, const Ctx& cx)
                 for (size_t k = i; k <= rb; ++k) v[k].drop = true;
                 v[p].s = "{";
                 v[q].s = "}";
+                continue;
+            }
+        }
+        if ((basic || cx.structs.count(t.s)) && n < e && is(v[n], "[")) {
+            // float[3] w  (GLSL's other spelling of  float w[3]):  the dimensions move behind the name
+            size_t rb = match(v, n, e), q = next_live(v, rb + 1, e);
+            while (q < e && is(v[q], "[")) { rb = match(v, q, e); q = next_live(v, rb + 1, e); }
+            const size_t after = q < e ? next_live(v, q + 1, e) : e;
+            if (q < e && v[q].k == T_ID && !(after < e && is(v[after], "("))) {
+                std::string dims;
+                for (size_t k = n; k <= rb; ++k) { if (!v[k].drop) dims += v[k].s; v[k].drop = true; }
+                v[q].post = dims + v[q].post;
                 continue;
             }
         }

@@ -300,6 +300,18 @@ RFG_EQ(vec2, 2) RFG_EQ(vec3, 3) RFG_EQ(vec4, 4) RFG_EQ(ivec2, 2) RFG_EQ(ivec3, 3
 template <class V, int N> RFG bool rfg_eq(const matN<V, N>& a, const matN<V, N>& b) { bool r = true; for (int i = 0; i < N; ++i) r = r && rfg_eq(a.c[i], b.c[i]); return r; }
 template <class A, class B> RFG bool rfg_ne(A a, B b) { return !rfg_eq(a, b); }
 
+// name.length() (the translator writes rfg_length(name)): elements of an array, components of a vector
+template <class T, int N> RFG constexpr int rfg_length(const T (&)[N]) { return N; }
+RFG constexpr int rfg_length(vec2) { return 2; }
+RFG constexpr int rfg_length(vec3) { return 3; }
+RFG constexpr int rfg_length(vec4) { return 4; }
+RFG constexpr int rfg_length(ivec2) { return 2; }
+RFG constexpr int rfg_length(ivec3) { return 3; }
+RFG constexpr int rfg_length(ivec4) { return 4; }
+RFG constexpr int rfg_length(uvec2) { return 2; }
+RFG constexpr int rfg_length(uvec3) { return 3; }
+RFG constexpr int rfg_length(uvec4) { return 4; }
+
 // ---- integer and packing built-ins --------------------------------------------------------------------------------------------------------
 RFG int bitCount(uint x) { return __builtin_popcount(x); }
 RFG int bitCount(int x) { return __builtin_popcount((unsigned)x); }

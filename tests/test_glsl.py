@@ -337,7 +337,8 @@ void main()
     bool e = c.rgb != vec3(0.0) && MODE == 2 ? c.a <= 0.5 == false : SAME(c.r, c.g);
     int k = (p.x & 1) == 0 ? 1 : 2;
     if (corner != e) c.a = float(k);
-    for (int i = 0; i != 3; ++i) c[i] += 0.25;
+    float[3] lift = float[3](0.25, 0.25, 0.25);
+    for (int i = 0; i != lift.length(); ++i) c[i] += lift[i];
     if (mat2(1.0) == mat2(1.0, 0.0, 0.0, 1.0)) c.b = 1.0;
     uint packed = packUnorm4x8(vec4(c.r - 0.25, 0.5, 2.0, -1.0));
     c.g = unpackUnorm4x8(packed).x + float(bitCount(packed & 0xFFu)) + float(findMSB(uint(p.x + 1))) + float(bitfieldExtract(uint(p.y), 1, 3));
@@ -368,7 +369,7 @@ def test_equality_of_vectors_is_one_bool_and_the_integer_built_ins_work():
     src = rf.glsl_translate("equality", EQUALITY)
     assert "rfg_eq(p , mk_ivec2(0)) || rfg_eq(p + 1 , imageSize(image))" in src
     assert "rfg_ne(c.rgb , mk_vec3(0.0f)) && rfg_eq(MODE , 2) ? rfg_eq(c.a <= 0.5f , false) : SAME(c.r, c.g)" in src
-    assert "#define SAME(a, b) (rfg_eq((a) , (b)))" in src and "static constexpr int MODE = 2 ;" in src and "rfg_ne(i , 3)" in src
+    assert "#define SAME(a, b) (rfg_eq((a) , (b)))" in src and "static constexpr int MODE = 2 ;" in src and "rfg_ne(i , rfg_length(lift))" in src and "float lift[3] = {0.25f, 0.25f, 0.25f};" in src
     img = util.synthetic(37, 21, util.F32)
     img[3, 5, :3] = 0.0
     img[4, 6, 0] = img[4, 6, 1]
