@@ -484,6 +484,21 @@ def test_glsl_nodes_split_into_row_strips(fake_rccl_dir, glsl_dir, tmp_path, mon
         util.assert_same(got, util.run_oracle(text, pixel.fill_synthetic(W, H, fmt, seed)), "GLSL chain on 3 ranks, flags=%d fmt=%d" % (flags, fmt))
 
 
+def test_a_shader_with_shared_memory_split_into_row_strips(fake_rccl_dir, glsl_dir, tmp_path, monkeypatch):
+    """TILE_BLUR (16 x 16 workgroups, an 18 x 18 tile in shared memory, barrier()) on three ranks: a rank runs the workgroups that hold rows
+    of its strip, loads reach one row into the neighbours' (#pragma rf radius 1), stores outside the strip are dropped"""
+    (glsl_dir / "tile_blur.comp").write_text(TILE_BLUR)
+    monkeypatch.setenv("RF_TEST_SHADER_PATH", str(glsl_dir))
+    monkeypatch.setenv("RF_TEST_FILES_FIRST", "1")
+    from oracle import pixel
+    W, H, seed = 333, 257, 0x5EED0012
+    for flags in (0, rf.RF_GRAPH_NO_HALO_XCHG):
+        sub = tmp_path / ("flags%d" % flags)
+        sub.mkdir()
+        got = run_ranks(fake_rccl_dir, sub, "input -> tb -> output\ntb: tile_blur {}", 3, W, H, util.F32, flags, seed)
+        util.assert_same(got, box3(pixel.fill_synthetic(W, H, util.F32, seed)), "tile_blur on 3 ranks, flags=%d" % flags)
+
+
 def test_a_shader_that_does_not_state_its_radius_is_not_split(glsl_dir):
     """one GPU: any shader runs; more than one rank: the node must say how far it reads -- and may not fill a storage block"""
     (glsl_dir / "mystery.comp").write_text(open(os.path.join(SHADERS, "sharpen.comp")).read().replace("#pragma rf radius 1", ""))
