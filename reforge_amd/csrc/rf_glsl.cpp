@@ -396,7 +396,12 @@ struct ConstEval {
         if (is(t, "(")) { ++i; const long r = sum(); if (i >= e || !is(v[i], ")")) throw Fail{t.line, "unbalanced ( in an array size"}; ++i; return r; }
         if (is(t, "-")) { ++i; return -primary(); }
         if (is(t, "+")) { ++i; return primary(); }
-        if (t.k == T_NUM) { ++i; return std::strtol(t.s.c_str(), nullptr, 0); }
+        if (t.k == T_NUM) {
+            const bool hex = t.s.size() > 1 && (t.s[1] == 'x' || t.s[1] == 'X');
+            if (!hex && t.s.find_first_of(".eEfF") != std::string::npos) throw Fail{t.line, "an array size is an integer (`" + t.s + "` is not)"};
+            ++i;
+            return std::strtol(t.s.c_str(), nullptr, 0);
+        }
         if (t.k == T_ID) {
             auto it = names.find(t.s);
             if (it == names.end()) throw Fail{t.line, "the array size `" + t.s + "` of a block member is not a constant this translator can evaluate (a literal, an object-like #define or a const int of literals)"};
