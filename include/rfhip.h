@@ -62,6 +62,8 @@ typedef enum rf_param_type { RF_PARAM_F32 = 0, RF_PARAM_I32 = 1, RF_PARAM_BOOL =
 #define RF_GRAPH_NO_JIT      0x10u /* fuse only chains whose kernel is in the ahead-of-time catalogue: nothing is
                                       compiled at graph creation (the reference compiles every node's shader
                                       there, shader.rs:29-93; here only chains the catalogue lacks need it)      */
+#define RF_GRAPH_GLSL_NODES  0x20u /* every {type}.comp file is a node with a kernel of its own: none becomes a row stage of the
+                                      stream kernel (what rf_graph_create checks such a stage against; A/B measurements) */
 
 typedef struct rf_ctx    rf_ctx;     /* VkCore            src/vulkan/core.rs:47-64   */
 typedef struct rf_config rf_config;  /* config::Config    src/config/config.rs:35-38 */

@@ -11,7 +11,7 @@ PipelineGraph (src/vulkan/pipeline_graph.rs), Render / RenderInfo
 (src/render.rs:37-58,:537-588).
 """
 from ._lib import (RF_FORMAT_RGBA8, RF_FORMAT_RGBA32F, RF_GRAPH_TIMERS, RF_GRAPH_NO_FUSION,
-                   RF_GRAPH_HIPGRAPH, RF_GRAPH_NO_HALO_XCHG, RF_GRAPH_NO_JIT, RF_EXEC_SYNC_LAUNCHES, RF_EXEC_CONCURRENT_LAYERS,
+                   RF_GRAPH_HIPGRAPH, RF_GRAPH_NO_HALO_XCHG, RF_GRAPH_NO_JIT, RF_GRAPH_GLSL_NODES, RF_EXEC_SYNC_LAUNCHES, RF_EXEC_CONCURRENT_LAYERS,
                    RF_EXEC_FORCE_SPLIT, RF_EXEC_NO_ALTERNATE, RF_EXEC_ALTERNATE, RF_EXEC_GLSL_NO_WINDOW, RF_CONV_AUTO, RF_CONV_TILE,
                    RF_CONV_MFMA, RF_CONV_VALU, SO_PATH, lib)
 from .host import (RfError, Config, Plan, Context, Graph, Render, RenderInfo, get_dim, comm_selftest,
@@ -20,7 +20,7 @@ from .host import (RfError, Config, Plan, Context, Graph, Render, RenderInfo, ge
 
 __all__ = [
     "RF_FORMAT_RGBA8", "RF_FORMAT_RGBA32F", "RF_GRAPH_TIMERS", "RF_GRAPH_NO_FUSION",
-    "RF_GRAPH_HIPGRAPH", "RF_GRAPH_NO_HALO_XCHG", "RF_GRAPH_NO_JIT", "RF_EXEC_SYNC_LAUNCHES", "RF_EXEC_CONCURRENT_LAYERS",
+    "RF_GRAPH_HIPGRAPH", "RF_GRAPH_NO_HALO_XCHG", "RF_GRAPH_NO_JIT", "RF_GRAPH_GLSL_NODES", "RF_EXEC_SYNC_LAUNCHES", "RF_EXEC_CONCURRENT_LAYERS",
     "RF_EXEC_FORCE_SPLIT", "RF_EXEC_NO_ALTERNATE", "RF_EXEC_ALTERNATE", "RF_EXEC_GLSL_NO_WINDOW", "RF_CONV_AUTO", "RF_CONV_TILE", "RF_CONV_MFMA",
     "RF_CONV_VALU", "SO_PATH", "lib",
     "RfError", "Config", "Plan", "Context", "Graph", "Render", "RenderInfo", "get_dim",

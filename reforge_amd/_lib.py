@@ -29,6 +29,7 @@ RF_GRAPH_NO_FUSION = 0x2
 RF_GRAPH_HIPGRAPH = 0x4
 RF_GRAPH_NO_HALO_XCHG = 0x8
 RF_GRAPH_NO_JIT = 0x10
+RF_GRAPH_GLSL_NODES = 0x20
 
 RF_EXEC_SYNC_LAUNCHES = 0x1
 RF_EXEC_CONCURRENT_LAYERS = 0x2

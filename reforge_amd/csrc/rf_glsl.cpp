@@ -1380,6 +1380,12 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
     } catch (const Fail&) {
         out.stencil = false;
     }
+    out.box = out.stencil && out.radius == 1 && out.images.size() == 2;      // (a stencil has read-only and write-only images only: one of each)
+    if (out.box) {
+        const std::string& bi = out.images[out.images[0].readonly ? 0 : 1].name, & bo = out.images[out.images[0].readonly ? 1 : 0].name;
+        s += "    template <class RfgN> RFG void rfg_bind_box(const unsigned char* rfg_ubo, const RfgN& rfg_n)\n    {\n        (void)rfg_ubo;\n" + tr.bind_ubo + "        " + bi + ".n = rfg_n;\n        " + bo +
+             ".n = rfg_n;\n        " + bo + ".value = vec4{0.0f, 0.0f, 0.0f, 0.0f};\n    }\n    RFG vec4 rfg_box_result() const { return " + bo + ".value; }\n";
+    }
     if (out.point) {
         // the shader as a row stage: its image variables hold one texel (image2D<PointPx>, rf_glsl_dev.h)
         s += "    RFG void rfg_bind_point(const unsigned char* rfg_ubo, vec4 rfg_c)\n    {\n        (void)rfg_ubo;\n" + tr.bind_ubo + "        " + pout + ".value = vec4{0.0f, 0.0f, 0.0f, 0.0f};\n        " + pin +
@@ -1411,6 +1417,15 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
              "    template <class Q> static RFG rf::f4 box(const Q&, const rf::f4 (&n)[3][3]) { return n[1][1]; }\n};\n} }\n"
              "namespace rfuser { namespace " + ident + " { typedef rfglsl::" + ident + "::RfgStage Stage; } }\n#endif\n";
     }
+    if (out.box) {
+        const std::string n = std::to_string(out.ubo_bytes > 0 ? out.ubo_bytes : 1);
+        s += "#ifdef RFGLSL_KERNEL\nnamespace rfglsl { namespace " + ident + " {\nstruct RfgBParams { unsigned char b[" + n + "]; };\nstruct RfgBStage {\n    typedef RfgBParams P;\n    static constexpr int R = 1;\n"
+             "    template <class Q> static RFG rf::f4 point(const Q&, rf::f4 c) { return c; }\n"
+             "    template <class Q> static RFG rf::f4 box(const Q& p, const rf::f4 (&n)[3][3])\n    {\n        RfgShader<BoxPx> s;\n        s.gl_NumWorkGroups = uvec3{1u, 1u, 1u};\n        s.gl_WorkGroupID = uvec3{0u, 0u, 0u};\n"
+             "        s.gl_LocalInvocationID = s.gl_GlobalInvocationID = uvec3{1u, 1u, 0u};\n        s.gl_LocalInvocationIndex = 0u;\n        s.rfg_bind_box(p.b, n);\n        s.main();\n"
+             "        const vec4 r = s.rfg_box_result();\n        return make_float4(r.x, r.y, r.z, r.w);\n    }\n};\n} }\n"
+             "namespace rfuser { namespace " + ident + " { typedef rfglsl::" + ident + "::RfgBStage BStage; } }\n#endif\n";
+    }
     if (out.stencil) {
         const std::string n = std::to_string(out.ubo_bytes > 0 ? out.ubo_bytes : 1), R = std::to_string(out.radius);
         s += "#ifdef RFGLSL_KERNEL\nnamespace rfglsl { namespace " + ident + " {\nstruct RfgWParams { unsigned char b[" + n + "]; };\nstruct RfgWStage {\n    typedef RfgWParams P;\n    static constexpr int R = " + R +
@@ -1427,7 +1442,7 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
 std::string glsl_reflection_json(const GlslShader& s)
 {
     auto q = [](const std::string& x) { return "\"" + x + "\""; };
-    std::string j = std::string("{\"point\": ") + (s.point ? "true" : "false") + ", \"stencil\": " + (s.stencil ? "true" : "false") + ", \"local_size\": [" + std::to_string(s.lx) + ", " + std::to_string(s.ly) + ", " + std::to_string(s.lz) + "], \"grouped\": " + (s.grouped ? "true" : "false") +
+    std::string j = std::string("{\"point\": ") + (s.point ? "true" : "false") + ", \"stencil\": " + (s.stencil ? "true" : "false") + ", \"box\": " + (s.box ? "true" : "false") + ", \"local_size\": [" + std::to_string(s.lx) + ", " + std::to_string(s.ly) + ", " + std::to_string(s.lz) + "], \"grouped\": " + (s.grouped ? "true" : "false") +
                     ", \"radius\": " + std::to_string(s.radius) + ", \"uniform_bytes\": " + std::to_string(s.ubo_bytes) + ", \"images\": [";
     for (size_t i = 0; i < s.images.size(); ++i)
         j += std::string(i ? ", " : "") + "{\"name\": " + q(s.images[i].name) + ", \"binding\": " + std::to_string(s.images[i].binding) + ", \"readonly\": " + (s.images[i].readonly ? "true" : "false") +

@@ -487,6 +487,24 @@ template <class P, bool BUF> struct GPx : P {      // the texel formats of rf_de
 // and imageLoad is Window::at at a constant offset: a register of the window the thread slides down its outputs (R <= 2), or an LDS
 // read at an immediate offset.  (Offsets are clamped into the window: a shader that reads further than it states stays inside memory;
 // rf_graph_create compares this kernel with the generic one on a random frame and keeps it only if they agree.)
+// ... and a recognised stencil of RADIUS 1 with one image in and one out is also a 3 x 3 ROW STAGE of the stream kernel (StUser, R = 1): the
+// same virtual frame, 3 x 3, backed by the neighbourhood the stage is handed (clamp-to-edge at the frame's edges, as every stencil of the
+// stream kernel sees it -- a file that treats the edges otherwise is found out by rf_graph_create and keeps a kernel of its own).
+struct BoxPx {};
+template <> struct image2D<BoxPx> {
+    const rf::f4 (*n)[3];
+    mutable vec4 value;
+};
+RFG ivec2 imageSize(const image2D<BoxPx>&) { return ivec2{3, 3}; }
+RFG vec4 imageLoad(const image2D<BoxPx>& im, ivec2 q)
+{
+    const bool in = (unsigned)q.x < 3u && (unsigned)q.y < 3u;
+    const int x = q.x < 0 ? 0 : (q.x > 2 ? 2 : q.x), y = q.y < 0 ? 0 : (q.y > 2 ? 2 : q.y);
+    const rf::f4 t = im.n[y][x];
+    return in ? vec4{t.x, t.y, t.z, t.w} : vec4{0.0f, 0.0f, 0.0f, 0.0f};
+}
+RFG void imageStore(const image2D<BoxPx>& im, ivec2, vec4 v) { im.value = v; }
+
 template <class W, int R> struct WinPx {};
 template <class W, int R> struct image2D<WinPx<W, R>> {
     const W* w;

@@ -715,6 +715,98 @@ static void read_tuning(rf_graph* g)
     if (exchange_mode(g)) g->concurrent_layers = false;
 }
 
+// ---- .comp files: the fast forms of a shader are held against its generic kernel before a graph uses them ------------------------------
+// The generic kernel IS the file as the reference would run it.  The LDS-tiled window kernel and the 3 x 3 row stage rest on what
+// rf_glsl.cpp read off the file's text (translation invariance), on the radius the file states and -- the row stage -- on the file
+// treating the frame's edges as clamp-to-edge.  So the node is run alone on a small random frame with the node's own parameters, both
+// ways, every wired output, and compared bit for bit.  Graph creation is where the reference compiles its shaders
+// (pipeline_graph.rs:509-545): a few milliseconds here are in the right place.
+static thread_local bool t_in_selftest = false;
+static bool glsl_same_both_ways(rf_graph* g, const UserStage* u, const NodeParams& np, const std::vector<int>* wired, uint32_t flags_a, uint32_t exec_a,
+                                uint32_t flags_b, uint32_t exec_b, std::string& why)
+{
+    t_in_selftest = true;
+    bool same = true;
+    const int W = 96, H = 64;
+    const size_t bpp = bytes_per_pixel(g->opt.format);
+    rf_ctx* ctx = nullptr;
+    if (rf_ctx_create(g->ctx->device, &ctx) != RF_OK) { same = false; why = last_error(); }
+    for (size_t o = 0; same && o < u->outputs.size(); ++o) {
+        if (wired && std::find(wired->begin(), wired->end(), u->out_binding[o]) == wired->end()) continue;      // not wired in this graph
+        std::string text;
+        for (size_t k = 0; k < u->inputs.size(); ++k) {
+            if (k == 0) text += "input -> nn:" + u->inputs[k] + "\n";
+            else text += "input -> t" + std::to_string(k) + "x -> nn:" + u->inputs[k] + "\nt" + std::to_string(k) + "x: grade { slope: 0." + std::to_string(5 + k) + ", offset: 0.0" + std::to_string(k) + ", saturation: 1.0 }\n";
+        }
+        text += "nn:" + u->outputs[o] + " -> output\nnn: " + u->type_name + " {}\n";
+        rf_config* cfg = nullptr;
+        if (rf_config_parse(text.c_str(), 1, &cfg) != RF_OK) { same = false; why = last_error(); break; }
+        std::vector<unsigned char> got[2];
+        for (int variant = 0; same && variant < 2; ++variant) {
+            rf_graph_options opt{};
+            opt.width = W;
+            opt.height = H;
+            opt.format = g->opt.format;
+            opt.num_frames = 1;
+            opt.flags = variant ? flags_b : flags_a;
+            opt.exec_flags = variant ? exec_b : exec_a;
+            rf_graph* t = nullptr;
+            if (rf_graph_create(ctx, cfg, &opt, &t) != RF_OK) { same = false; why = last_error(); break; }
+            for (const auto& p : u->params) {
+                auto it = np.values.find(p.name);
+                ParamValue v;
+                v.i = 0;
+                if (it != np.values.end()) v = it->second;
+                (void)rf_graph_set_param(t, "nn", p.name.c_str(), p.type == PARAM_F32 ? RF_PARAM_F32 : (p.type == PARAM_I32 ? RF_PARAM_I32 : RF_PARAM_BOOL), &v);
+            }
+            got[variant].resize((size_t)W * H * bpp);
+            if (rf_graph_fill_synthetic(t, 0x5E1F7E57u + (uint32_t)o) != RF_OK || rf_graph_execute(t, 0) != RF_OK || rf_graph_wait(t, 0) != RF_OK ||
+                rf_graph_download_raw(t, 0, got[variant].data(), (size_t)W * bpp) != RF_OK) { same = false; why = last_error(); }
+            rf_graph_destroy(t);
+        }
+        rf_config_destroy(cfg);
+        if (same && got[0] != got[1]) { same = false; why = "it differs from the file's generic kernel on a random 96 x 64 frame (output " + u->outputs[o] + ")"; }
+    }
+    if (ctx) rf_ctx_destroy(ctx);
+    t_in_selftest = false;
+    (void)hipSetDevice(g->ctx->device);
+    return same;
+}
+
+// the window kernels of the graph's launches
+static void glsl_window_selftests(rf_graph* g)
+{
+    if (g->glsl_no_window) return;
+    for (const auto& L : g->launches) {
+        if (L.ops.size() != 1 || L.ops[0].kind != OP_USERN) continue;
+        const UserStage* u = user_stage_by_id(L.ops[0].user_id);
+        if (!u || !glsl_wants_window(g, u)) continue;
+        if (t_in_selftest) { g->glsl_window_ok.insert(L.label); continue; }      // the inner graph of a check: this IS the kernel under test
+        std::string why;
+        if (glsl_same_both_ways(g, u, g->plan.plan.nodes.at(L.members[0]), &L.dst_bindings, 0u, 0u, 0u, RF_EXEC_GLSL_NO_WINDOW, why)) g->glsl_window_ok.insert(L.label);
+        else g->jit_note += (g->jit_note.empty() ? "" : "; ") + std::string("node '") + L.label + "' (" + u->file_name() + ", #pragma rf radius " + std::to_string(u->radius) + ") keeps its generic kernel: its window kernel: " + why;
+    }
+}
+
+// the 3 x 3 row stages the plan holds: true if one was given up (the caller plans again: the type is a node from now on)
+static bool glsl_row_stage_selftests(rf_graph* g)
+{
+    if (t_in_selftest) return false;
+    bool gave_up = false;
+    std::set<int> seen;
+    for (const auto& kv : g->plan.plan.nodes) {
+        if (kv.second.type->kind != OP_USER) continue;
+        const UserStage* u = user_stage_of(kv.second.type);
+        if (!u || !u->glsl || u->radius != 1 || !seen.insert(u->id).second) continue;      // (a point shader is a row stage by a proof of its own)
+        std::string why;
+        if (glsl_same_both_ways(g, u, kv.second, nullptr, RF_GRAPH_NO_FUSION, 0u, RF_GRAPH_GLSL_NODES, RF_EXEC_GLSL_NO_WINDOW, why)) continue;
+        user_stage_give_up_row_stage(u->id);
+        gave_up = true;
+        g->jit_note += (g->jit_note.empty() ? "" : "; ") + std::string("type '") + u->type_name + "' (" + u->file_name() + ") is not fused: as a 3 x 3 row stage " + why;
+    }
+    return gave_up;
+}
+
 static rf_status graph_build(rf_graph* g, const rf_config* cfg)
 {
     rf_ctx* ctx = g->ctx;
@@ -722,8 +814,12 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
     std::string err;
     uint32_t plan_flags = opt.flags;
     if (!build_plan(cfg->cfg, plan_flags, g->plan.plan, err)) return fail(RF_ERR_GRAPH, err);
-    g->plan.index();
     HIP_TRY(hipSetDevice(ctx->device));
+    if (!(plan_flags & kPlanGlslNodes) && glsl_row_stage_selftests(g)) {
+        g->plan = rf_plan();
+        if (!build_plan(cfg->cfg, plan_flags, g->plan.plan, err)) return fail(RF_ERR_GRAPH, err);
+    }
+    g->plan.index();
     read_tuning(g);
     if (g->tune.conv_path < 0) return fail(RF_ERR_INVALID, "rf_graph_create: conv_path must be 0 (auto), 1 (LDS tile), 2 (MFMA band) or 3 (VALU)");
     // Kernels of fused chains the ahead-of-time catalogue lacks are compiled HERE, where the reference compiles its
@@ -930,72 +1026,6 @@ static rf_status graph_build(rf_graph* g, const rf_config* cfg)
     // the fills above (storage buffers) ran on the null stream; the frames run on non-blocking streams of their own
     HIP_TRY(hipDeviceSynchronize());
     return RF_OK;
-}
-
-// A .comp stencil (UserStage::glsl_window) has two kernels: the generic one, which IS the file as the reference would run it, and the
-// LDS-tiled window kernel, which rests on what rf_glsl.cpp read off the file's text (translation invariance) and on the radius the file
-// states.  Before a graph uses the window kernel it is held against the generic one: the node alone on a small random frame with the
-// node's own parameters, both ways, every wired output, bit for bit.  A difference (a shader that reads further than it states, an
-// analysis that was wrong) keeps the generic kernel and says so in rf_graph_note.  Graph creation is where the reference compiles
-// its shaders (pipeline_graph.rs:509-545): a few milliseconds here are in the right place.
-static thread_local bool t_in_selftest = false;
-static void glsl_window_selftests(rf_graph* g)
-{
-    if (g->glsl_no_window) return;
-    for (const auto& L : g->launches) {
-        if (L.ops.size() != 1 || L.ops[0].kind != OP_USERN) continue;
-        const UserStage* u = user_stage_by_id(L.ops[0].user_id);
-        if (!u || !glsl_wants_window(g, u)) continue;
-        if (t_in_selftest) { g->glsl_window_ok.insert(L.label); continue; }      // the inner graph of a self-test: this IS the kernel under test
-        t_in_selftest = true;
-        std::string why;
-        bool same = true;
-        const int W = 96, H = 64;
-        const size_t bpp = bytes_per_pixel(g->opt.format);
-        const NodeParams& np = g->plan.plan.nodes.at(L.members[0]);
-        rf_ctx* ctx = nullptr;
-        if (rf_ctx_create(g->ctx->device, &ctx) != RF_OK) { same = false; why = last_error(); }
-        for (size_t o = 0; same && o < u->outputs.size(); ++o) {
-            if (std::find(L.dst_bindings.begin(), L.dst_bindings.end(), u->out_binding[o]) == L.dst_bindings.end()) continue;      // not wired in this graph
-            std::string text;
-            for (size_t k = 0; k < u->inputs.size(); ++k) {
-                if (k == 0) text += "input -> nn:" + u->inputs[k] + "\n";
-                else text += "input -> t" + std::to_string(k) + "x -> nn:" + u->inputs[k] + "\nt" + std::to_string(k) + "x: grade { slope: 0." + std::to_string(5 + k) + ", offset: 0.0" + std::to_string(k) + ", saturation: 1.0 }\n";
-            }
-            text += "nn:" + u->outputs[o] + " -> output\nnn: " + u->type_name + " {}\n";
-            rf_config* cfg = nullptr;
-            if (rf_config_parse(text.c_str(), 1, &cfg) != RF_OK) { same = false; why = last_error(); break; }
-            std::vector<unsigned char> got[2];
-            for (int variant = 0; same && variant < 2; ++variant) {
-                rf_graph_options opt{};
-                opt.width = W;
-                opt.height = H;
-                opt.format = g->opt.format;
-                opt.num_frames = 1;
-                opt.exec_flags = variant ? RF_EXEC_GLSL_NO_WINDOW : 0u;
-                rf_graph* t = nullptr;
-                if (rf_graph_create(ctx, cfg, &opt, &t) != RF_OK) { same = false; why = last_error(); break; }
-                for (const auto& p : u->params) {
-                    auto it = np.values.find(p.name);
-                    ParamValue v;
-                    v.i = 0;
-                    if (it != np.values.end()) v = it->second;
-                    (void)rf_graph_set_param(t, "nn", p.name.c_str(), p.type == PARAM_F32 ? RF_PARAM_F32 : (p.type == PARAM_I32 ? RF_PARAM_I32 : RF_PARAM_BOOL), &v);
-                }
-                got[variant].resize((size_t)W * H * bpp);
-                if (rf_graph_fill_synthetic(t, 0x5E1F7E57u + (uint32_t)o) != RF_OK || rf_graph_execute(t, 0) != RF_OK || rf_graph_wait(t, 0) != RF_OK ||
-                    rf_graph_download_raw(t, 0, got[variant].data(), (size_t)W * bpp) != RF_OK) { same = false; why = last_error(); }
-                rf_graph_destroy(t);
-            }
-            rf_config_destroy(cfg);
-            if (same && got[0] != got[1]) { same = false; why = "its window kernel and its generic kernel differ on a random 96 x 64 frame (output " + u->outputs[o] + ")"; }
-        }
-        if (ctx) rf_ctx_destroy(ctx);
-        t_in_selftest = false;
-        (void)hipSetDevice(g->ctx->device);
-        if (same) g->glsl_window_ok.insert(L.label);
-        else g->jit_note += (g->jit_note.empty() ? "" : "; ") + std::string("node '") + L.label + "' (" + u->file_name() + ", #pragma rf radius " + std::to_string(u->radius) + ") keeps its generic kernel: " + why;
-    }
 }
 
 extern "C" rf_status rf_graph_create(rf_ctx* ctx, const rf_config* cfg, const rf_graph_options* opt, rf_graph** out)

@@ -373,7 +373,7 @@ bool jit_compile_user_node(int fmt, int user_id, std::string& err, bool wide)
 {
     std::lock_guard<std::mutex> lock(g_mu);
     const UserStage* u = user_stage_by_id(user_id);
-    if (!u || !u->multi) { err = "not a user node"; return false; }
+    if (!u || !(u->multi || u->has_alt)) { err = "not a user node"; return false; }
     if (!u->glsl && !u->buf_out.empty() && !load_expr(fill_expression(*u), {user_id}, 1, 4, err)) return false;      // RF_BUFFER_OUT: its fill kernel
     if (u->glsl && u->glsl_window && !load_expr(window_expression(fmt, *u), {user_id}, 1, 4, err)) return false;
     return load_expr(node_expression(fmt, *u, wide), {user_id}, 1, 4, err);
@@ -410,7 +410,7 @@ size_t jit_compile_only_user_node(int fmt, int user_id, std::string& err)
 {
     std::lock_guard<std::mutex> lock(g_mu);
     const UserStage* u = user_stage_by_id(user_id);
-    if (!u || !u->multi) { err = "not a user node"; return 0; }
+    if (!u || !(u->multi || u->has_alt)) { err = "not a user node"; return 0; }
     size_t total = 0;
     if (!u->glsl && !u->buf_out.empty()) {
         const Compiled* f = compile_expr(fill_expression(*u), {user_id}, 4, err);

@@ -78,12 +78,12 @@ const std::vector<NodeType>& registry()
     return types;
 }
 
-const NodeType* find_type(const std::string& name, std::string* why)
+const NodeType* find_type(const std::string& name, std::string* why, bool glsl_nodes)
 {
     std::string err;
     if (files_first()) {      // the reference's rule: the file IS the type (config.rs:59-75) -- a file that does not translate is an error, not a fallback
         const UserStage* u = user_stage_for_type(name, err);
-        if (u) return &u->node_type;
+        if (u) return user_stage_node_type(u, glsl_nodes);
         if (!err.empty()) { if (why) *why = err; return nullptr; }
     }
     for (const auto& t : registry())
@@ -91,7 +91,7 @@ const NodeType* find_type(const std::string& name, std::string* why)
     // not built in: a type that is a file, {shader_path}/{name}.stage.hip or {name}.comp (config.rs:59-75; rf_user.h, rf_glsl.h)
     const UserStage* u = user_stage_for_type(name, err);
     if (why) *why = err;
-    return u ? &u->node_type : nullptr;
+    return u ? user_stage_node_type(u, glsl_nodes) : nullptr;
 }
 
 // ---------------------------------------------------------------------------------
@@ -645,7 +645,7 @@ bool build_plan(const Config& cfg, uint32_t flags, Plan& plan, std::string& err)
         const std::string& name = kv.first;
         const std::string& tname = cfg.type_of(name);
         std::string why;
-        const NodeType* type = find_type(tname, &why);
+        const NodeType* type = find_type(tname, &why, (flags & kPlanGlslNodes) != 0);
         if (!type) {   // Shader::from_path -> None (utils.rs:23)
             err = "Error reading node type '" + tname + "' for node '" + name + "': " + (why.empty() ? std::string("no such filter") : why);
             return false;

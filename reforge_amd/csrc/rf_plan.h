@@ -43,7 +43,8 @@ struct NodeType {
 
 const std::vector<NodeType>& registry();
 // built-in types first, then {shader_path}/{name}.stage.hip (rf_user.h); *why = what is wrong with such a file, if it exists
-const NodeType* find_type(const std::string& name, std::string* why = nullptr);
+// glsl_nodes: a {type}.comp file that could be a row stage of the stream kernel is wanted as a node with a kernel of its own (kPlanGlslNodes)
+const NodeType* find_type(const std::string& name, std::string* why = nullptr, bool glsl_nodes = false);
 
 // one uniform member's value (the UBO bytes of render.rs:167-210)
 union ParamValue {
@@ -132,6 +133,7 @@ void halo_schedule(std::vector<LaunchDesc>& launches, bool multi_rank, bool exch
 
 constexpr uint32_t kPlanNoFusion = 0x2u;   // == RF_GRAPH_NO_FUSION
 constexpr uint32_t kPlanNoJit = 0x10u;     // == RF_GRAPH_NO_JIT: fuse only what the ahead-of-time kernel catalogue holds
+constexpr uint32_t kPlanGlslNodes = 0x20u; // == RF_GRAPH_GLSL_NODES: every {type}.comp file is a node with a kernel of its own, never a row stage
 
 bool build_plan(const Config& cfg, uint32_t flags, Plan& out, std::string& err);
 

@@ -147,7 +147,7 @@ static std::string stage_letter(int kind, int r, int user = -1)
 }
 static std::string stage_type(int kind, int r, int user = -1)
 {
-    if (kind == ST_USER) { const UserStage* u = user_stage_by_id(user); return "rf::StUser<rfuser::" + (u ? u->ident : std::string("missing")) + "::Stage>"; }
+    if (kind == ST_USER) { const UserStage* u = user_stage_by_id(user); return "rf::StUser<rfuser::" + (u ? u->ident + "::" + u->row_stage : std::string("missing::Stage")) + ">"; }
     switch (kind) {
         case ST_HTAP: return "rf::StHTap<" + std::to_string(r) + ">";
         case ST_VTAP: return "rf::StVTap<" + std::to_string(r) + ">";

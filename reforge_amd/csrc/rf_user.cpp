@@ -12,6 +12,7 @@
 #include <fstream>
 #include <map>
 #include <mutex>
+#include <set>
 #include <sstream>
 
 namespace rf {
@@ -216,7 +217,8 @@ bool parse_glsl_stage(const std::string& type, const std::string& text, UserStag
     // a point operation on one image: a ROW STAGE of the stream kernel like a {type}.stage.hip of RADIUS 0 -- it fuses with its neighbours
     // (RF_GLSL_NO_FUSE=1: every .comp file stays a node with a kernel of its own, for A/B measurements and tests of that path)
     static const bool no_fuse = [] { const char* e = std::getenv("RF_GLSL_NO_FUSE"); return e && std::atoi(e) != 0; }();
-    if (sh.point && !no_fuse) out.multi = false;
+    if ((sh.point || sh.box) && !no_fuse) out.multi = false;
+    if (sh.box && !sh.point) out.row_stage = "BStage";      // (Stage is the window stage of the same file)
     static const bool no_window = [] { const char* e = std::getenv("RF_GLSL_NO_WINDOW"); return e && std::atoi(e) != 0; }();
     out.glsl_window = sh.stencil && !no_window;      // (which graphs use it: glsl_wants_window, rf_graph.cpp)
     out.radius = sh.radius < 0 ? 0 : sh.radius;
@@ -336,9 +338,28 @@ const UserStage* user_stage_for_type(const std::string& type, std::string& err)
         if (!listed) s.node_type.buffers.push_back(NodeType::BufferDef{b.name.c_str(), b.binding, b.bytes});
     }
     for (const auto& p : s.params) s.node_type.params.push_back(ParamDef{p.name.c_str(), p.type});
+    if (s.glsl && !s.multi) {      // a row stage: the same type as a node with a kernel of its own
+        s.node_type_alt = s.node_type;
+        s.node_type_alt.kind = OP_USERN;
+        s.has_alt = true;
+        g_by_type[&s.node_type_alt] = s.id;
+    }
     g_latest[type] = s.id;
     g_by_type[&s.node_type] = s.id;
     return &s;
+}
+
+namespace { std::set<int> g_no_row_stage; }
+const NodeType* user_stage_node_type(const UserStage* u, bool want_node)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    return u->has_alt && (want_node || g_no_row_stage.count(u->id)) ? &u->node_type_alt : &u->node_type;
+}
+
+void user_stage_give_up_row_stage(int id)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_no_row_stage.insert(id);
 }
 
 const UserStage* user_stage_by_id(int id)

@@ -63,6 +63,11 @@ struct UserStage {
     int params_size = 1;          // sizeof(Params) as the device compiler lays it out (checked there by static_assert)
     long long mtime_ns = 0;
     NodeType node_type;           // the registry entry (names point into `params` / `type_name`)
+    // a .comp file that is a ROW STAGE (a point shader, a 3 x 3 stencil) is also a node with a kernel of its own: the same entry with kind
+    // OP_USERN, handed out when a plan asks for it (kPlanGlslNodes) or after rf_graph_create found the stage and the generic kernel to differ
+    NodeType node_type_alt;
+    bool has_alt = false;
+    std::string row_stage = "Stage";      // rfuser::<ident>::<row_stage>: the struct StUser is instantiated with
     std::string wrapper() const;  // device source appended to the run-time compiler's translation unit
 };
 
@@ -72,6 +77,10 @@ const std::string& shader_path();
 // the stage of a type the built-in registry lacks: loads / reloads {shader_path}/{type}.stage.hip, or, when there is no such
 // file, {shader_path}/{type}.comp.  nullptr: no such file (err empty) or a file that does not parse (err set)
 const UserStage* user_stage_for_type(const std::string& type, std::string& err);
+// the registry entry of a stage: node_type, or node_type_alt when the caller wants a node (or the row stage has been given up)
+const NodeType* user_stage_node_type(const UserStage* u, bool want_node);
+// rf_graph_create found the row stage of this file to differ from its generic kernel: from now on the type is a node (process-wide)
+void user_stage_give_up_row_stage(int id);
 const UserStage* user_stage_by_id(int id);
 const UserStage* user_stage_of(const NodeType* t);
 // parse one stage file's text (exposed for the tests of the parser)

@@ -24,9 +24,10 @@ def compile_all(rf, root):
     rf.set_type_lookup(True)
     try:
         for text in GRAPHS.values():
-            p = rf.Plan(rf.Config(text))
-            p.jit_compile(rf.RF_FORMAT_RGBA32F)
-            p.jit_compile(rf.RF_FORMAT_RGBA8)
+            for flags in (0, rf.RF_GRAPH_GLSL_NODES):      # as planned (row stages where a file is one), and every file as a node with a kernel of its own
+                p = rf.Plan(rf.Config(text), flags)
+                p.jit_compile(rf.RF_FORMAT_RGBA32F)
+                p.jit_compile(rf.RF_FORMAT_RGBA8)
     finally:
         rf.set_type_lookup(False)
         rf.set_shader_path(old)

@@ -258,7 +258,7 @@ def test_cli_runs_a_directory_of_glsl_shaders_as_it_is(tmp_path):
     write_png(src, rgba, lambda y: 0)
     cfg.write_text("input -> neg -> sh -> output\nneg: invert { enabled: true, strength: 1.0 }\nsh: sharpen { amount: 0.5 }")
     r = run_cli("-i", src, "--config", str(cfg), "-o", dst, "--shader-path", str(shaders), "--shader-files-first")
-    assert r.returncode == 0 and "GPU: {neg: " in r.stderr and "sh: " in r.stderr, r.stderr      # two launches: both types are files
+    assert r.returncode == 0 and "GPU: {neg+sh: " in r.stderr, r.stderr      # both types are files -- a point shader and a 3 x 3 stencil: row stages, ONE launch
     got = np.fromfile(dst, np.uint8).reshape(64, 96, 4).copy()
     r = run_cli("-i", src, "--config", str(cfg), "-o", dst, "--shader-path", str(shaders))      # default lookup: sharpen is the built-in kernel, invert the file
     assert r.returncode == 0, r.stderr
@@ -276,7 +276,7 @@ def test_cli_runs_a_directory_of_glsl_shaders_as_it_is(tmp_path):
                               "--frame-interval-ms", "25"], stderr=err)
         try:
             end = time.time() + 90
-            while time.time() < end and "GPU: {neg: " not in log.read_text(errors="replace"):
+            while time.time() < end and "GPU: {neg+sh: " not in log.read_text(errors="replace"):
                 time.sleep(0.01)
             good = (shaders / "invert.comp").read_text()
             (shaders / "invert.comp").write_text(good.replace("uniform Params", "uniform samplerCube nope; uniform Params"))

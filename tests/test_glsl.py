@@ -312,6 +312,23 @@ def test_translation_invariant_stencils_are_recognised_conservatively():
     assert stencil == {"gaussian5", "gaussian9", "sharpen", "edge_detect", "local_contrast"}, stencil      # (gaussian: 80 bytes of uniforms; conv2d: a storage block)
 
 
+def test_a_three_by_three_stencil_is_a_row_stage_and_fuses(glsl_dir):
+    rf.set_type_lookup(False)
+    shutil.copy(os.path.join(SHADERS, "sharpen.comp"), glsl_dir / "sharp3.comp")
+    shutil.copy(os.path.join(SHADERS, "edge_detect.comp"), glsl_dir / "edges3.comp")
+    shutil.copy(os.path.join(SHADERS, "invert.comp"), glsl_dir / "invert.comp")
+    for t in ("sharp3", "edges3"):
+        r = rf.glsl_reflect(t, (glsl_dir / (t + ".comp")).read_text())
+        assert r["stencil"] and r["box"] and not r["point"], t
+    assert not rf.glsl_reflect("gaussian5", text_of("gaussian5"))["box"]      # radius 2
+    text = ("input -> gg -> s3 -> iv -> e3 -> cg -> output\ngg: gaussian5 { sigma: 1.0 }\ns3: sharp3 { amount: 0.5 }\niv: invert { enabled: true, strength: 0.5 }\n"
+            "e3: edges3 { scale: 1.5 }\ncg: colour_grade { slope: 1.1, offset: 0.0, saturation: 1.0 }")
+    p = rf.Plan(rf.Config(text))
+    assert p.launches() == ["gg+s3+iv+e3+cg"] and [l["radius"] for l in p.launch_info()] == [4]      # three GLSL files inside one launch
+    assert p.jit_compile(rf.RF_FORMAT_RGBA32F) > 8192 and p.jit_compile(rf.RF_FORMAT_RGBA8) > 8192
+    assert rf.Plan(rf.Config(text), rf.RF_GRAPH_GLSL_NODES).launches() == ["gg", "s3", "iv", "e3", "cg"]
+
+
 def test_a_recognised_stencil_compiles_its_window_kernel_too(glsl_dir):
     (glsl_dir / "box5.comp").write_text(BOX5)
     p = rf.Plan(rf.Config("input -> bb -> output\nbb: box5 { gain: 0.04 }"))
@@ -473,7 +490,8 @@ def test_conv2d_weights_fills_its_block_from_invocations_beyond_a_small_frame():
 def test_a_type_that_is_a_comp_file_plans_as_a_node_of_its_own(glsl_dir):
     for t in ("gaussian5", "colour_grade", "sharpen"):
         shutil.copy(os.path.join(SHADERS, t + ".comp"), glsl_dir / (t + ".comp"))
-    assert rf.Plan(rf.Config(util.CHAIN3)).launches() == ["blur", "grade", "sharp"]      # the FILES are the types (the reference's rule)
+    assert rf.Plan(rf.Config(util.CHAIN3)).launches() == ["blur", "grade+sharp"]         # the FILES are the types (the reference's rule): gaussian5.comp a node
+    assert rf.Plan(rf.Config(util.CHAIN3), rf.RF_GRAPH_GLSL_NODES).launches() == ["blur", "grade", "sharp"]      # (colour_grade.comp and sharpen.comp: row stages, fused)
     rf.set_type_lookup(False)
     assert rf.Plan(rf.Config(util.CHAIN3)).launches() == ["blur+grade+sharp"]             # default: the hand-written kernels, fused
     (glsl_dir / "wobble.comp").write_text(text_of("invert").replace("strength", "depth"))

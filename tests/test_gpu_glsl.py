@@ -77,13 +77,13 @@ def test_a_graph_run_through_the_glsl_files_matches_the_oracle(ctx, glsl_dir, na
 
 
 def test_the_files_are_what_ran(ctx, glsl_dir):
-    """with the file-first lookup a type that is a file is a node with a kernel of its own: the 3-stage chain is three launches, not one fused"""
+    """with the file-first lookup the files are what runs: the 3-stage chain is gaussian5.comp as a node and the other two files as fused row stages"""
     use(glsl_dir, "gaussian5", "colour_grade", "sharpen")
-    assert glsl_launches(util.CHAIN3) == ["blur", "grade", "sharp"]
+    assert glsl_launches(util.CHAIN3) == ["blur", "grade+sharp"]      # gaussian5.comp: a node (window kernel); colour_grade.comp + sharpen.comp: row stages, fused
     rf.set_type_lookup(False)
     assert glsl_launches(util.CHAIN3) == ["blur+grade+sharp"]
     rf.set_type_lookup(True)
-    assert rf.Plan(rf.Config(util.CHAIN3)).needs_jit() == [True, True, True]
+    assert rf.Plan(rf.Config(util.CHAIN3)).needs_jit() == [True, True]
 
 
 def test_the_reference_passthrough_shader_text(ctx, glsl_dir):
@@ -359,6 +359,78 @@ def test_a_stencil_shader_on_the_window_kernel_and_on_its_generic_kernel(ctx, gl
         finally:
             g.close()
         util.assert_same(util.run_hip(ctx, text, img, exec_flags=rf.RF_EXEC_GLSL_NO_WINDOW), want, "generic kernel %dx%d" % (W, H))
+
+
+@pytest.mark.parametrize("fmt", [util.F32, util.U8], ids=["rgba32f", "rgba8"])
+def test_three_by_three_stencil_shaders_fused_as_row_stages(ctx, glsl_dir, fmt):
+    """gaussian5 -> sharpen.comp -> invert.comp -> edge_detect.comp -> colour_grade: ONE launch (the 3 x 3 files are StUser row stages of radius 1 in
+    a virtual 3 x 3 frame, checked against their generic kernels when the graph is created), against the oracle's restatement of every node"""
+    rf.set_type_lookup(False)
+    for src, dst in (("sharpen", "sharp3"), ("edge_detect", "edges3"), ("invert", "invert")):
+        shutil.copy(os.path.join(SHADERS, src + ".comp"), glsl_dir / (dst + ".comp"))
+    for t in ("invert", "edge_detect"):
+        if "user" not in ograph.NODE_TYPES.get(t, {}):
+            ograph.register_user_type(t, os.path.join(SHADERS, t + ".stage.hip"))
+    text = ("input -> gg -> s3 -> iv -> e3 -> cg -> output\ngg: gaussian5 { sigma: 1.0 }\ns3: sharp3 { amount: 0.5 }\niv: invert { enabled: true, strength: 0.5 }\n"
+            "e3: edges3 { scale: 1.5 }\ncg: colour_grade { slope: 1.1, offset: 0.0, saturation: 1.0 }")
+    oracle_text = text.replace("sharp3", "sharpen").replace("edges3", "edge_detect")
+    for W, H in ((250, 131), (64, 4), (17, 13), (1, 1)):
+        img = util.synthetic(W, H, fmt, seed=0x81 + W)
+        want = util.run_oracle(oracle_text, img)
+        g = rf.Graph(ctx, rf.Config(text), W, H, fmt)
+        try:
+            assert g.note == "" and g.plan.launches() == ["gg+s3+iv+e3+cg"], (g.note, g.plan.launches())
+            g.upload_raw(img)
+            g.execute()
+            g.wait()
+            util.assert_same(g.download_raw(), want, "fused %dx%d" % (W, H))
+        finally:
+            g.close()
+        util.assert_same(util.run_hip(ctx, text, img, flags=rf.RF_GRAPH_GLSL_NODES), want, "files as nodes %dx%d" % (W, H))
+
+
+def test_a_three_by_three_shader_with_its_own_idea_of_the_edges_is_not_fused(ctx, glsl_dir):
+    """a 3 x 3 box WITHOUT clamps darkens the frame's edges (zeros outside the image); a row stage of the stream kernel sees clamp-to-edge
+    neighbours there.  rf_graph_create finds the two to differ, says so, and the type is a node with a kernel of its own from then on"""
+    rf.set_type_lookup(False)
+    src = """#version 450
+#pragma rf radius 1
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform readonly image2D input_image;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+void main()
+{
+    ivec2 p = ivec2(gl_GlobalInvocationID.xy);
+    if (any(greaterThanEqual(p, imageSize(output_image)))) return;
+    vec4 acc = vec4(0.0);
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) acc += imageLoad(input_image, p + ivec2(dx, dy));
+    imageStore(output_image, p, acc * 0.125);
+}
+"""
+    assert rf.glsl_reflect("box3z", src)["box"]
+    (glsl_dir / "box3z.comp").write_text(src)
+    text = "input -> gg -> bz -> output\ngg: gaussian5 { sigma: 1.0 }\nbz: box3z {}"
+    assert rf.Plan(rf.Config(text)).launches() == ["gg+bz"]      # before any graph has looked: a row stage
+    img = util.synthetic(120, 70, util.F32)
+    g = rf.Graph(ctx, rf.Config(text), 120, 70, util.F32)
+    try:
+        assert "box3z.comp) is not fused" in g.note and g.plan.launches() == ["gg", "bz"], (g.note, g.plan.launches())
+        g.upload_raw(img)
+        g.execute()
+        g.wait()
+        from oracle import pixel
+        a = pixel.gaussian(img, 2, sigma=1.0)
+        pad = np.zeros((72, 122, 4), np.float32)
+        pad[1:-1, 1:-1] = a
+        acc = np.zeros_like(a)
+        for dy in range(3):
+            for dx in range(3):
+                acc = acc + pad[dy:dy + 70, dx:dx + 120]
+        util.assert_same(g.download_raw(), acc * np.float32(0.125), "zero-padded 3x3 box")
+    finally:
+        g.close()
+    assert rf.Plan(rf.Config(text)).launches() == ["gg", "bz"]      # the process remembers
 
 
 def test_a_stencil_that_relies_on_zeros_outside_the_image(ctx, glsl_dir):
