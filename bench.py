@@ -106,7 +106,7 @@ WORKLOADS["user_window_4k"] = dict(text="input -> lc -> output\nlc: local_contra
 # shader directory costs when it is run as it is.  The gaussian's weights are given (w0..w2): GLSL exp() is not the host's.
 GLSL_CHAIN3 = CHAIN3.replace("sigma: 1.0 }", "sigma: 1.0, w0: 0.402619958, w1: 0.244201347, w2: 0.0544886850 }")
 WORKLOADS["glsl_chain3_4k"] = dict(text=GLSL_CHAIN3, W=3840, H=2160, fmt=F32, nodes=3, seed=0x5EED0009, radius=3, strong=False, files_first=True,
-                                   desc="the headline graph run from the GLSL files (shaders/gaussian5.comp, colour_grade.comp, sharpen.comp), 3840x2160 rgba32f")
+                                   desc="the headline graph run from the GLSL files (shaders/gaussian5.comp: window kernel; colour_grade.comp + sharpen.comp: fused row stages), 3840x2160 rgba32f")
 # the headline graph with ONE of its types taken from a GLSL file: colour_grade.comp is recognised as a point shader and becomes a row stage
 # of the stream kernel -- it FUSES with the hand-written gaussian5 and sharpen around it: one launch, as in the headline
 WORKLOADS["glsl_fused_chain3_4k"] = dict(text=CHAIN3, W=3840, H=2160, fmt=F32, nodes=3, seed=0x5EED000B, radius=3, strong=False, files_first=True, glsl_only=("colour_grade",),
