@@ -23,6 +23,7 @@ CASES = [   # (name, types as files, config, images moved per texel)
     ("edge_detect", ["edge_detect"], "input -> ed -> output\ned: edge_detect { scale: 1.5 }", 2),
     ("gaussian5", ["gaussian5"], "input -> gg -> output\ngg: gaussian5 { sigma: 1.0, %s }" % glsl_weights.as_params(1.0, 2), 2),
     ("local_contrast", ["local_contrast"], "input -> lc -> output\nlc: local_contrast { amount: 0.8 }", 2),
+    ("gaussian9", ["gaussian9"], "input -> g9 -> output\ng9: gaussian9 { sigma: 2.0, %s }" % glsl_weights.as_params(2.0, 4), 2),
 ]
 PASSTHROUGH = ("#version 450\nlayout (local_size_x = 16, local_size_y = 16) in;\nlayout (binding = 0, rgba8) uniform readonly image2D input_image;\n"
                "layout (binding = 1, rgba8) uniform writeonly image2D output_image;\nvoid main()\n{\n    vec4 res = imageLoad(input_image, ivec2(gl_GlobalInvocationID.xy));\n"
