@@ -999,15 +999,22 @@ bool point_shader(const std::string& text, const GlslShader& sh, std::string& in
 // as far as this analysis can tell, and it keeps its generic kernel.  (The radius itself and the border behaviour are not proven here: the
 // frame's border texels are computed by the generic kernel, and rf_graph_create runs both kernels on a small random frame and keeps the
 // window kernel only if the two agree bit for bit.)
-bool stencil_shader(const std::string& text, const GlslShader& sh)
+bool stencil_shader(const std::string& text, const GlslShader& sh, std::string& why)
 {
-    if (sh.grouped || !sh.ssbos.empty() || sh.radius < 1 || sh.radius > 15 || sh.lx < 16 || sh.ly < 16 || sh.ubo_bytes > 56) return false;
+    auto no = [&](const std::string& reason) { why = reason; return false; };
+    if (sh.radius < 1) return no(sh.radius < 0 ? "it does not state `#pragma rf radius N`" : "its stated radius is 0");
+    if (sh.radius > 15) return no("its stated radius is above 15");
+    if (sh.grouped) return no("it uses workgroup built-ins, shared variables or barrier()");
+    if (!sh.ssbos.empty()) return no("it has a storage block");
+    if (sh.lx < 16 || sh.ly < 16) return no("its local_size is below 16 x 16 (the reference's dispatch then covers part of the frame only)");
+    if (sh.ubo_bytes > 56) return no("its uniform blocks take more than 56 bytes");
     std::set<std::string> in_names, out_names;
     for (const auto& im : sh.images) {
-        if (im.sampled || im.readonly == im.writeonly) return false;      // every image is read or written, never both
+        if (im.sampled) return no("it samples `" + im.name + "`");
+        if (im.readonly == im.writeonly) return no("`" + im.name + "` is read AND written");      // every image is read or written, never both
         (im.readonly ? in_names : out_names).insert(im.name);
     }
-    if (in_names.empty() || out_names.empty() || in_names.size() > 4 || out_names.size() > 4) return false;
+    if (in_names.empty() || out_names.empty() || in_names.size() > 4 || out_names.size() > 4) return no("it needs one to four images read and one to four written");
     const std::vector<Tok> t = lex(text);
     const size_t N = t.size();
     auto is_image = [&](const std::string& s) { return in_names.count(s) || out_names.count(s); };
@@ -1017,10 +1024,10 @@ bool stencil_shader(const std::string& text, const GlslShader& sh)
         if (q.k == T_PP) {
             const std::vector<Tok> d = lex(q.s.substr(1));
             for (const auto& w : d)
-                if (w.k == T_ID && (w.s == "gl_GlobalInvocationID" || w.s == "imageSize" || w.s == "imageLoad" || w.s == "imageStore" || is_image(w.s))) return false;
+                if (w.k == T_ID && (w.s == "gl_GlobalInvocationID" || w.s == "imageSize" || w.s == "imageLoad" || w.s == "imageStore" || is_image(w.s))) return no("line " + std::to_string(q.line) + ": a #define mentions `" + w.s + "`");
         } else if (q.k == T_ID) {
             for (const char* f : forbidden)
-                if (q.s == f) return false;
+                if (q.s == f) return no("line " + std::to_string(q.line) + ": it uses `" + q.s + "`");
         }
     }
     // ---- functions -----------------------------------------------------------------------------------------------------------------
@@ -1063,7 +1070,7 @@ bool stencil_shader(const std::string& text, const GlslShader& sh)
             i = close;
         }
     }
-    if (!fns.count("main")) return false;
+    if (!fns.count("main")) return no("no main()");
     // ---- integer variables, each with the range of tokens it is visible in -------------------------------------------------------
     // position reaches a variable (`pos`) / a uniform reaches it (`var`): flags of the DECLARATION, so that the `i` of one loop is not the
     // `i` of another
@@ -1259,10 +1266,10 @@ bool stencil_shader(const std::string& text, const GlslShader& sh)
                     const bool load = w == "imageLoad";
                     if (!(load ? in_names.count(t[i + 2].s) : out_names.count(t[i + 2].s))) return false;
                     const size_t e = arg_end(i + 4, f.e);
-                    if (has_var(i + 4, e)) return false;      // a coordinate that follows a parameter: rf_graph_create could not vouch for later frames
+                    if (has_var(i + 4, e)) return no("line " + std::to_string(t[i].line) + ": a coordinate follows a uniform (parameters change after the graph is created)");
                     if (!load) {
                         const size_t n = coord_at(i + 4);      // a store: in main(), at the invocation's own coordinate
-                        if (kv.first != "main" || !n || i + 4 + n != e) return false;
+                        if (kv.first != "main" || !n || i + 4 + n != e) return no("line " + std::to_string(t[i].line) + ": a store somewhere else than the invocation's own texel (`ivec2(gl_GlobalInvocationID.xy)` or a variable declared as that), or outside main()");
                     }
                     mark(i, e);
                 } else if (w == "imageSize" && is(t[i + 1], "(") && t[i + 2].k == T_ID && is_image(t[i + 2].s) && is(t[i + 3], ")")) {
@@ -1311,7 +1318,7 @@ bool stencil_shader(const std::string& text, const GlslShader& sh)
                             for (auto& q : decls) if (q.at == h.pat[p] && q.b == h.b) pd = &q;
                         if (has_var(a, e) && pd) pd->var = true;
                         if (has_pos(a, e)) {
-                            if (!pd || h.byref[p]) return false;
+                            if (!pd || h.byref[p]) return no("line " + std::to_string(t[a].line) + ": the position is handed to `" + w + "` in a parameter that is not an integer passed by value");
                             pd->pos = true;
                             mark(a, e);
                             any = true;
@@ -1326,13 +1333,13 @@ bool stencil_shader(const std::string& text, const GlslShader& sh)
     }
     // a variable the position AND a uniform reach cannot be vouched for
     for (const auto& d : decls)
-        if (d.pos && d.var) return false;
+        if (d.pos && d.var) return no("line " + std::to_string(t[d.at].line) + ": `" + d.name + "` follows both the position and a uniform");
     // the verdict: the position outside every allowed place?  an image variable that is not the first argument of an image function?
     for (const auto& kv : fns)
         for (size_t i = kv.second.b; i < kv.second.e; ++i) {
             if (!names(i)) continue;
             if (is_image(t[i].s) && !(i >= 2 && is(t[i - 1], "(") && (t[i - 2].s == "imageLoad" || t[i - 2].s == "imageStore" || t[i - 2].s == "imageSize"))) return false;
-            if (pos_at(i) && !ok[i]) return false;
+            if (pos_at(i) && !ok[i]) return no("line " + std::to_string(t[i].line) + ": `" + t[i].s + "` carries the position or the frame size into something else than an integer coordinate, the frame guard or the coordinate of a load / of the store");
         }
     {
         std::vector<char> inside(N, 0);
@@ -1376,7 +1383,8 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
         out.point = false;
     }
     try {
-        out.stencil = !out.point && stencil_shader(text, out);
+        out.stencil = !out.point && stencil_shader(text, out, out.stencil_why);
+        if (out.stencil || out.point) out.stencil_why.clear();
     } catch (const Fail&) {
         out.stencil = false;
     }
@@ -1439,10 +1447,21 @@ bool glsl_translate(const std::string& type, const std::string& text, const std:
     return true;
 }
 
+static std::string json_escape(const std::string& x)
+{
+    std::string o;
+    for (char c : x) {
+        if (c == '"' || c == '\\') { o += '\\'; o += c; }
+        else if (c == '\n') o += "\\n";
+        else o += c;
+    }
+    return o;
+}
+
 std::string glsl_reflection_json(const GlslShader& s)
 {
     auto q = [](const std::string& x) { return "\"" + x + "\""; };
-    std::string j = std::string("{\"point\": ") + (s.point ? "true" : "false") + ", \"stencil\": " + (s.stencil ? "true" : "false") + ", \"box\": " + (s.box ? "true" : "false") + ", \"local_size\": [" + std::to_string(s.lx) + ", " + std::to_string(s.ly) + ", " + std::to_string(s.lz) + "], \"grouped\": " + (s.grouped ? "true" : "false") +
+    std::string j = std::string("{\"point\": ") + (s.point ? "true" : "false") + ", \"stencil\": " + (s.stencil ? "true" : "false") + ", \"box\": " + (s.box ? "true" : "false") + ", \"stencil_why_not\": \"" + json_escape(s.stencil_why) + "\", \"local_size\": [" + std::to_string(s.lx) + ", " + std::to_string(s.ly) + ", " + std::to_string(s.lz) + "], \"grouped\": " + (s.grouped ? "true" : "false") +
                     ", \"radius\": " + std::to_string(s.radius) + ", \"uniform_bytes\": " + std::to_string(s.ubo_bytes) + ", \"images\": [";
     for (size_t i = 0; i < s.images.size(); ++i)
         j += std::string(i ? ", " : "") + "{\"name\": " + q(s.images[i].name) + ", \"binding\": " + std::to_string(s.images[i].binding) + ", \"readonly\": " + (s.images[i].readonly ? "true" : "false") +

@@ -64,6 +64,7 @@ struct GlslShader {
     int radius = -1;                       // #pragma rf radius N; -1 = not stated
     bool point = false;                    // recognised as a point operation on one image: also a row stage of the stream kernel (fuses)
     bool stencil = false;                  // recognised as a translation-invariant stencil of the stated radius: also runs on the LDS-tiled window kernel
+    std::string stencil_why;               // why not (the first reason the analysis met; "" for a point shader or a recognised stencil)
     bool box = false;                      // ... of radius 1 with one image in and one out: also a 3 x 3 row stage of the stream kernel (fuses)
     int ubo_bytes = 0;
     std::string source;                    // namespace rfglsl { namespace <ident> { ... RfgShader<Px> ... RfgInfo ... } }

@@ -306,8 +306,14 @@ NOT_STENCIL = {
 def test_translation_invariant_stencils_are_recognised_conservatively():
     r = rf.glsl_reflect("box5", BOX5)
     assert r["stencil"] and not r["point"] and r["radius"] == 2
+    assert r["stencil_why_not"] == ""
+    says = {"the position in a float": "line 18: `p` carries", "a loop bound by the position": "line 16: `p`", "the position through a helper into a float": "line 8: `x` carries",
+            "a store somewhere else": "line 18: a store somewhere else", "an offset that follows a parameter": "a coordinate follows a uniform", "no stated radius": "does not state `#pragma rf radius N`",
+            "an image read and written": "`input_image` is read AND written"}
     for why, text in NOT_STENCIL.items():
-        assert not rf.glsl_reflect("box5", text)["stencil"], why
+        rr = rf.glsl_reflect("box5", text)
+        assert not rr["stencil"] and rr["stencil_why_not"], why      # and the reflection says what kept it off the fast forms
+        assert says.get(why, "") in rr["stencil_why_not"], (why, rr["stencil_why_not"])
     stencil = {t for t in COMP if rf.glsl_reflect(t, text_of(t))["stencil"]}
     assert stencil == {"gaussian5", "gaussian9", "sharpen", "edge_detect", "local_contrast"}, stencil      # (gaussian: 80 bytes of uniforms; conv2d: a storage block)
 
