@@ -240,7 +240,9 @@ long long   rf_user_stage_mtime(const char* type_name);
  * rf_graph_create compares that kernel with the file's generic kernel on a random frame and keeps it only if they agree (rf_graph_note).
  * [host] the translation of `text` (HIP device source; its first line is a comment naming the namespace it lives in) */
 rf_status   rf_glsl_translate(const char* type_name, const char* text, char* buf, size_t cap, size_t* len);
-/* [host] the reflection of `text` as JSON: {"local_size": [x, y, z], "grouped", "radius" (-1: not stated), "uniform_bytes",
+/* [host] the reflection of `text` as JSON: {"point", "stencil", "box" (how the file can run besides its generic kernel: a fused row stage /
+ * the LDS-tiled window kernel / a fused 3 x 3 row stage), "stencil_why_not" (the first thing that kept it from being a recognised
+ * stencil: line and name), "local_size": [x, y, z], "grouped", "radius" (-1: not stated), "uniform_bytes",
  * "images": [{"name", "binding", "readonly", "writeonly"}], "uniform_blocks" / "storage_blocks": [{"type_name", "instance",
  * "binding", "bytes", "base", "members": [{"name", "base": "f|i|u|b", "comps", "cols", "dims", "offset", "stride", "bytes"}]}]} */
 rf_status   rf_glsl_reflect(const char* type_name, const char* text, char* buf, size_t cap, size_t* len);
