@@ -120,6 +120,13 @@ std::vector<Tok> lex(const std::string& t)
         }
         out.push_back(k);
     }
+    // matNxN is another spelling of matN (GLSL 4.50 4.1.6); the non-square matrices stay outside the subset
+    for (size_t k = 0; k < out.size(); ++k)
+        if (out[k].k == T_ID && !(k > 0 && out[k - 1].k == T_PUNCT && out[k - 1].s == ".")) {
+            if (out[k].s == "mat2x2") out[k].s = "mat2";
+            else if (out[k].s == "mat3x3") out[k].s = "mat3";
+            else if (out[k].s == "mat4x4") out[k].s = "mat4";
+        }
     Tok e;
     e.k = T_END;
     e.ws = ws;
@@ -145,13 +152,18 @@ const std::set<std::string>& dropped_qualifiers()
     static const std::set<std::string> s = {"precise", "highp", "mediump", "lowp", "invariant"};
     return s;
 }
+const std::set<std::string>& atomic_functions()
+{
+    static const std::set<std::string> s = {"atomicAdd", "atomicMin", "atomicMax", "atomicAnd", "atomicOr", "atomicXor", "atomicExchange", "atomicCompSwap"};
+    return s;
+}
 const std::set<std::string>& unsupported_words()
 {
     static const std::set<std::string> s = {"double",      "dvec2",       "dvec3",       "dvec4",      "dmat2",       "dmat3",          "dmat4",        "sampler1D",
                                             "sampler3D",   "samplerCube", "sampler2DArray", "sampler2DShadow", "textureGather", "image1D",        "image3D",      "imageCube",
-                                            "image2DArray", "iimage2D",   "uimage2D",    "atomicAdd",  "atomicMin",   "atomicMax",      "atomicExchange", "atomicCompSwap",
-                                            "imageAtomicAdd", "subroutine", "mat2x2",    "mat2x3",     "mat2x4",      "mat3x2",         "mat3x3",       "mat3x4",
-                                            "mat4x2",      "mat4x3",      "mat4x4",      "push_constant"};
+                                            "image2DArray", "iimage2D",   "uimage2D",    "imageAtomicAdd", "imageAtomicMin", "imageAtomicMax", "imageAtomicExchange", "imageAtomicCompSwap",
+                                            "atomic_uint", "atomicCounter", "atomicCounterIncrement", "atomicCounterDecrement", "subroutine", "mat2x3",     "mat2x4",      "mat3x2",         "mat3x4",
+                                            "mat4x2",      "mat4x3",      "push_constant"};
     return s;
 }
 
@@ -259,6 +271,30 @@ void rewrite(std::vector<Tok>& v, size_t b, size_t e, const Ctx& cx)
                 continue;                  // the closing parenthesis stays: rfg_length(name)
             }
         }
+        if (after_dot && t.s == "length" && call && i >= b + 2 && is(v[i - 2], "]")) {
+            // name[i].length() (an array of arrays): back over the subscripts to the name
+            const size_t close = next_live(v, n + 1, e);
+            size_t a = i - 2;
+            bool ok = close < e && is(v[close], ")");
+            while (ok && is(v[a], "]")) {
+                int depth = 0;
+                size_t k = a;
+                for (;; --k) {
+                    if (is(v[k], "]")) ++depth;
+                    else if (is(v[k], "[") && --depth == 0) break;
+                    if (k == b) { ok = false; break; }
+                }
+                if (!ok || k == b) { ok = false; break; }
+                a = k - 1;
+            }
+            if (ok && v[a].k == T_ID && !(a > b && is(v[a - 1], "."))) {
+                v[a].pre += "rfg_length(";
+                v[i - 1].drop = true;
+                t.drop = true;
+                v[n].drop = true;
+                continue;
+            }
+        }
         if (after_dot) {
             // a swizzle spelled with texture coordinates: clang's vectors know xyzw and rgba
             bool stpq = !t.s.empty() && t.s.size() <= 4 && !cx.struct_members.count(t.s);
@@ -269,6 +305,11 @@ void rewrite(std::vector<Tok>& v, size_t b, size_t e, const Ctx& cx)
         }
         if (unsupported_words().count(t.s)) throw Fail{t.line, "`" + t.s + "` is outside the GLSL subset this library translates (rf_glsl.h)"};
         if (dropped_qualifiers().count(t.s)) { t.drop = true; continue; }
+        if (t.s == "precision") {      // `precision highp float;` inside a function: a statement without meaning here
+            size_t q = i;
+            while (q < e && !is(v[q], ";")) ++q;
+            if (q < e) { for (size_t k = i; k <= q; ++k) v[k].drop = true; i = q; continue; }
+        }
         const bool basic = vector_types().count(t.s) || scalar_types().count(t.s);
         if ((basic || cx.structs.count(t.s)) && n < e && is(v[n], "[")) {
             // T[](a, b, c) / T[3](a, b, c): an array constructor -> {a, b, c}
@@ -301,6 +342,7 @@ void rewrite(std::vector<Tok>& v, size_t b, size_t e, const Ctx& cx)
             continue;
         }
         if (call && t.s == "not") { t.s = "rfg_not"; continue; }
+        if (call && atomic_functions().count(t.s)) { t.s = "rfg_" + t.s; continue; }      // HIP's functions of these names take pointers
         if (cx.ssbo_scalars.count(t.s)) { t.s = "(*rfg_p_" + t.s + ")"; continue; }
         if (cx.ssbo_instances.count(t.s) && n < e && is(v[n], ".")) { v[n].s = "->"; continue; }
     }
@@ -649,10 +691,21 @@ struct Translator {
                     else if (v[k].s != "const" && !dropped_qualifiers().count(v[k].s)) pname = k;      // the last identifier outside brackets: the name
                 }
             }
+            bool array = false, is_const = false;
+            for (size_t k = pb; k < pe; ++k) {
+                array = array || is(v[k], "[");
+                is_const = is_const || (v[k].k == T_ID && v[k].s == "const");
+            }
+            // an array passed by value: C++ hands the function the caller's array, GLSL a copy -- the same thing as long as the function does
+            // not write it, which `const` makes the compiler check (a write is then an error with file and line, not a silent difference)
+            // (a reference to a const array: an array constructor -- braces here -- can be passed as the argument, a pointer could not take it)
+            if (array && !by_ref && pb < pe && pname < pe) {
+                if (!is_const) v[pb].pre += "const ";
+                by_ref = true;
+            }
             if (by_ref) {
                 if (pname >= pe) fail(v[pb].line, "an out parameter without a name");
-                const bool arr = pname + 1 < pe && is(v[pname + 1], "[");
-                v[pname].s = arr ? "(&" + v[pname].s + ")" : "&" + v[pname].s;
+                v[pname].s = array ? "(&" + v[pname].s + ")" : "&" + v[pname].s;
             }
             pb = pe + 1;
         }
@@ -792,8 +845,14 @@ struct Translator {
                 if (v[i + 1].k != T_ID || !is(v[i + 2], "{")) fail(v[i].line, "cannot read this struct");
                 cx.structs.insert(v[i + 1].s);
                 const size_t close = match(v, i + 2, v.size());
+                std::string same;      // GLSL compares structs member by member (== and != are calls here: rfg_eq finds this operator)
                 for (size_t k = i + 3; k < close; ++k)
-                    if (v[k].k == T_ID && (is(v[k + 1], ";") || is(v[k + 1], ",") || is(v[k + 1], "["))) cx.struct_members.insert(v[k].s);
+                    if (v[k].k == T_ID && (is(v[k + 1], ";") || is(v[k + 1], ",") || is(v[k + 1], "["))) {
+                        cx.struct_members.insert(v[k].s);
+                        if (!vector_types().count(v[k].s) && !scalar_types().count(v[k].s) && !cx.structs.count(v[k].s))
+                            same += (same.empty() ? "" : " && ") + std::string("rfg_eq(") + v[k].s + ", rfg_o." + v[k].s + ")";
+                    }
+                v[close].pre += "RFG bool operator==(const " + v[i + 1].s + "& rfg_o) const { return " + (same.empty() ? "true" : same) + "; } ";
                 size_t e = close + 1;
                 while (!is(v[e], ";")) { if (v[e].k == T_END) fail(v[i].line, "struct without `;`"); ++e; }
                 rewrite(v, i, e + 1, cx);

@@ -21,7 +21,8 @@
 // array constructors braces, `out` / `inout` parameters references, literals `float`, `a == b` a call (one bool also for vectors); `shared` variables move in front of
 // the struct as LDS variables; `precise`, precision qualifiers and prototypes go.  Not translated (the file is refused with
 // a message, as the reference refuses a file that does not compile: Option::None + warning, shader.rs:92): samplers other
-// than sampler2D, images other than image2D, nested structs in blocks, unsized arrays, double precision, atomics.
+// than sampler2D, images other than image2D, nested structs in blocks, unsized arrays, double precision, image atomics and atomic counters
+// (atomicAdd ... atomicCompSwap on storage-block and shared integers are translated: HIP's atomics behind reference parameters).
 #pragma once
 
 #include <string>
@@ -71,7 +72,7 @@ struct GlslShader {
 };
 
 constexpr int kGlslMaxImages = 32, kGlslMaxBuffers = 32, kGlslMaxUniformBytes = 256;
-constexpr int kGlslTranslatorVersion = 2;      // part of a shader's identity (rf_user.cpp): code objects cached on disk follow the translator
+constexpr int kGlslTranslatorVersion = 3;      // part of a shader's identity (rf_user.cpp): code objects cached on disk follow the translator
 
 // `ident`: the namespace the translation lives in (unique per file text).  false + err ("type.comp:LINE: ...") if the file
 // uses something outside the subset.

@@ -234,6 +234,31 @@ RFG bool all(bvec4 a) { return a.x != 0 && a.y != 0 && a.z != 0 && a.w != 0; }
 RFG bvec2 rfg_not(bvec2 a) { return bvec2{a.x == 0, a.y == 0}; }       // GLSL's not(): `not` is an operator spelling in C++, the translator renames the call
 RFG bvec3 rfg_not(bvec3 a) { return bvec3{a.x == 0, a.y == 0, a.z == 0}; }
 RFG bvec4 rfg_not(bvec4 a) { return bvec4{a.x == 0, a.y == 0, a.z == 0, a.w == 0}; }
+// Atomic memory functions (GLSL 4.50 8.11) on the int / uint members of storage blocks and on shared variables; the translator renames the
+// calls (HIP's functions of the same names take pointers).  Each returns the value the memory held before.  On the host (tests) the
+// invocations run one after another, so the plain operation is the atomic one.
+#if defined(__HIPCC_RTC__) || defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+#define RFG_ATOMIC(name, hipname, expr) \
+    template <class T, class V> RFG T rfg_##name(T& m, V v) { static_assert(sizeof(T) == 4 && (T)0.5 == (T)0, "atomic functions take int or uint memory"); return ::hipname(&m, (T)v); }
+#else
+#define RFG_ATOMIC(name, hipname, expr) \
+    template <class T, class V> RFG T rfg_##name(T& m, V v) { static_assert(sizeof(T) == 4 && (T)0.5 == (T)0, "atomic functions take int or uint memory"); const T o = m, d = (T)v; m = (expr); return o; }
+#endif
+RFG_ATOMIC(atomicAdd, atomicAdd, (T)(o + d)) RFG_ATOMIC(atomicMin, atomicMin, d < o ? d : o) RFG_ATOMIC(atomicMax, atomicMax, d > o ? d : o)
+RFG_ATOMIC(atomicAnd, atomicAnd, (T)(o & d)) RFG_ATOMIC(atomicOr, atomicOr, (T)(o | d)) RFG_ATOMIC(atomicXor, atomicXor, (T)(o ^ d))
+RFG_ATOMIC(atomicExchange, atomicExch, d)
+#undef RFG_ATOMIC
+template <class T, class C, class V> RFG T rfg_atomicCompSwap(T& m, C compare, V v)
+{
+    static_assert(sizeof(T) == 4 && (T)0.5 == (T)0, "atomic functions take int or uint memory");
+#if defined(__HIPCC_RTC__) || defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+    return ::atomicCAS(&m, (T)compare, (T)v);
+#else
+    const T o = m;
+    if (o == (T)compare) m = (T)v;
+    return o;
+#endif
+}
 RFG bvec2 isnan(vec2 a) { return bvec2{a.x != a.x, a.y != a.y}; }
 RFG bvec3 isnan(vec3 a) { return bvec3{a.x != a.x, a.y != a.y, a.z != a.z}; }
 RFG bvec4 isnan(vec4 a) { return bvec4{a.x != a.x, a.y != a.y, a.z != a.z, a.w != a.w}; }
@@ -298,7 +323,13 @@ template <class A, class B> RFG bool rfg_eq(A a, B b) { return a == b; }
 RFG_EQ(vec2, 2) RFG_EQ(vec3, 3) RFG_EQ(vec4, 4) RFG_EQ(ivec2, 2) RFG_EQ(ivec3, 3) RFG_EQ(ivec4, 4) RFG_EQ(uvec2, 2) RFG_EQ(uvec3, 3) RFG_EQ(uvec4, 4)
 #undef RFG_EQ
 template <class V, int N> RFG bool rfg_eq(const matN<V, N>& a, const matN<V, N>& b) { bool r = true; for (int i = 0; i < N; ++i) r = r && rfg_eq(a.c[i], b.c[i]); return r; }
-template <class A, class B> RFG bool rfg_ne(A a, B b) { return !rfg_eq(a, b); }
+template <class T, int N> RFG bool rfg_eq(const T (&a)[N], const T (&b)[N])      // arrays compare element by element (C++ would compare their addresses)
+{
+    bool r = true;
+    for (int i = 0; i < N; ++i) r = r && rfg_eq(a[i], b[i]);
+    return r;
+}
+template <class A, class B> RFG bool rfg_ne(const A& a, const B& b) { return !rfg_eq(a, b); }
 
 // name.length() (the translator writes rfg_length(name)): elements of an array, components of a vector
 template <class T, int N> RFG constexpr int rfg_length(const T (&)[N]) { return N; }

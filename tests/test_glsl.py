@@ -105,7 +105,7 @@ void main()
 """)
     assert "#extension" not in src and "precision" not in src and "highp" not in src and "precise" not in src
     assert src.count("helper(") == 2      # the prototype is gone (a member function is declared once); definition + call remain
-    assert "RFG float helper( float a,  float &b,  vec2 &c, const  float d[2])" in src
+    assert "RFG float helper( float a,  float &b,  vec2 &c, const  float (&d)[2])" in src      # an array by value: a reference to a const array
     assert "b = a * 2.f; c.yx = c.xy; return 1e-3f + d[1] + .5f + 3.0;" in src
     assert "float x = 1.0f;  vec4 o = mk_vec4(x, 0, 1u, true);" in src
     assert "float arr[2] = {1.0f, 2.0f};" in src
@@ -490,6 +490,113 @@ def test_conv2d_weights_fills_its_block_from_invocations_beyond_a_small_frame():
     want = np.zeros(49, np.float32)
     want[24] = 1.0      # sigma <= 0: the delta kernel
     assert np.array_equal(buf[:49], want) and np.array_equal(o, img)
+
+
+CONSTRUCT_HEAD = """#version 450
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform readonly image2D input_image;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+"""
+# body of the file -> the texel it stores at (5, 3), worked out by hand
+CONSTRUCTS = {
+    "nested structs": ("struct In { vec2 a; float k[2]; }; struct Out { In i; vec4 v[2]; };\nvoid main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); Out o; o.i.a = vec2(1.0, 2.0); o.i.k[1] = 3.0; "
+                       "o.v[0] = vec4(o.i.a, o.i.k[1], 0.0); imageStore(output_image, p, o.v[0]); }", [1, 2, 3, 0]),
+    "arrays of arrays": ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); float m[2][3]; for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) m[i][j] = float(i * 3 + j); "
+                         "imageStore(output_image, p, vec4(m[1][2], m[0][1], m.length(), m[0].length())); }", [5, 1, 2, 3]),
+    "integer built-ins": ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); ivec2 a = abs(p - 5); ivec2 b = min(a, 3); ivec2 c = max(b, ivec2(1)); int s = sign(p.x - 4); uvec2 u = uvec2(p) % 3u; "
+                          "int k = clamp(p.x, 1, 4); imageStore(output_image, p, vec4(c, s + k, u.x + u.y)); }", [1, 2, 5, 2]),
+    "loops": ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); float s = 0.0; int i = 0; while (true) { if (i >= 8) break; ++i; if ((i & 1) == 0) continue; s += float(i); } "
+              "for (;;) { s *= 0.5; if (s < 1.0) break; } do { s += 1.0; } while (s < 3.0); imageStore(output_image, p, vec4(s)); }", [3.5, 3.5, 3.5, 3.5]),
+    "conversions": ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); float f = -1.5 + float(p.x); int i = int(f); uint u = uint(max(i, 0)); bool b = bool(i); vec4 v = vec4(ivec4(i, u, b, 2)); "
+                    "ivec3 iv = ivec3(vec3(1.7, -1.7, 2.5)); bvec2 bv = bvec2(p); imageStore(output_image, p, v + vec4(iv, float(bv.x) + float(bv.y))); }", [4, 2, 3, 4]),
+    "overloads": ("float f(float x) { return x * 2.0; }\nvec2 f(vec2 x) { return x * 3.0; }\nint f(int x) { return x + 1; }\n"
+                  "void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); imageStore(output_image, p, vec4(f(1.0), f(vec2(1.0)), f(p.x))); }", [2, 3, 3, 6]),
+    "compound assignment": ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); int a = p.x; a <<= 2; a |= 1; a ^= 6; a %= 7; a >>= 1; a &= 3; uint u = 5u; u *= 3u; u -= 1u; u /= 2u; "
+                            "float f = 1.0; f /= 4.0; f -= 0.125; imageStore(output_image, p, vec4(a, u, f, !(a > 1) || (u < 3u && f > 0.0) ? 1.0 : 0.0)); }", [2, 7, 0.125, 0]),
+    "mixed constructors": ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); vec2 a = vec2(p); vec4 b = vec4(a, 1, p.x); vec3 c = vec3(b); vec4 d = vec4(c.xy, ivec2(3, 4)); vec4 e = vec4(1u, 2, 3.0, true); "
+                           "imageStore(output_image, p, b + d + e); }", [11, 8, 7, 10]),
+    "array comparison": ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); int a[2] = int[](5, 2); int b[2] = int[2](p.x, 2); int c[2] = int[](p.y, 2); "
+                         "imageStore(output_image, p, vec4(a == b ? 1.0 : 0.0, a != b ? 1.0 : 0.0, a == c ? 1.0 : 0.0, a != c ? 1.0 : 0.0)); }", [1, 0, 0, 1]),
+    "struct comparison": ("struct In { ivec2 q; float k[2]; }; struct S { int a; In i; };\nvoid main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); S x = S(1, In(ivec2(5, 3), float[](1.0, 2.0))); "
+                          "S y = S(1, In(p, float[](1.0, 2.0))); S z = y; z.i.k[1] = 2.5; imageStore(output_image, p, vec4(x == y ? 1.0 : 0.0, x != y ? 1.0 : 0.0, x == z ? 1.0 : 0.0, y != z ? 1.0 : 0.0)); }", [1, 0, 0, 1]),
+    "a private global, macros with arguments, precision statements": (
+        "#define SQ(x) ((x) * (x))\n#define TAPS 3\nprecision highp float;\nint counter = 0;\nconst int OFF[TAPS] = int[](-1, 0, 1);\nmat3x3 ident() { return mat3x3(1.0); }\n"
+        "void bump(inout int n) { n++; counter += 2; }\n"
+        "void main() { precision mediump int; ivec2 p = ivec2(gl_GlobalInvocationID.xy); int n = 0; for (int i = 0, j = 2; i < TAPS; ++i, --j) { bump(n); n += OFF[i] * OFF[j]; } mat3 m = ident(); m[1][2] = 0.5; "
+        "vec3 r = m * vec3(1.0, 2.0, 4.0); switch (p.y) { case 3: r.x += 10.0; break; default: r.x = 0.0; } imageStore(output_image, p, vec4(r, SQ(n) + counter)); }", [11, 2, 5, 7]),
+    "arrays by value": ("vec4 total(vec4 v[3]) { return v[0] + v[1] + v[2]; }\nvoid second(float[2] w, out float s) { s = w[1]; }\n"
+                        "void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); vec4 t[3]; for (int i = 0; i < 3; ++i) t[i] = vec4(float(i + p.x)); float s; second(float[](7.0, 9.0), s); "
+                        "imageStore(output_image, p, total(t) + vec4(0, 0, 0, s)); }", [18, 18, 18, 27]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CONSTRUCTS))
+def test_constructs_of_the_language_mean_what_glsl_says(name):
+    body, want = CONSTRUCTS[name]
+    img = util.synthetic(20, 9, util.F32)
+    o = np.zeros_like(img)
+    HostShader("construct", CONSTRUCT_HEAD + body).run({"input_image": img, "output_image": o})
+    assert o[3, 5].tolist() == [float(x) for x in want], (name, o[3, 5])
+
+
+def test_what_c_cannot_express_is_a_compile_error_with_the_files_line():
+    """arrays are values in GLSL: assigning one, returning one and WRITING one that was passed by value have no C++ spelling here --
+    the run-time compiler says so against the file's own line (never a silent difference)"""
+    for body, what in (("void main() { float a[3] = float[](1.0, 2.0, 3.0); float b[3];\n b = a; }", "construct.comp:6"),
+                       ("float[2] two(float x) { return float[2](x, x); }\nvoid main() { }", "construct.comp:5"),
+                       ("void f(float w[2]) {\n\n w[0] = 1.0; }\nvoid main() { }", "construct.comp:7")):
+        with pytest.raises(Exception) as e:
+            HostShader("construct", CONSTRUCT_HEAD + body)
+        assert what in str(e.value), str(e.value)[:400]
+
+
+HISTOGRAM = """#version 450
+// luma histogram of the frame in 64 bins, the brightest code seen, and the count of invocations that ran (frame or not)
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform readonly image2D input_image;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+layout (std430, binding = 2) buffer Hist { uint bins[64]; uint brightest; int darkest; uint invocations; uint first; };
+void main()
+{
+    ivec2 size = imageSize(input_image);
+    ivec2 p = ivec2(gl_GlobalInvocationID.xy);
+    atomicAdd(invocations, 1);
+    if (p.x >= size.x || p.y >= size.y) return;
+    vec4 t = imageLoad(input_image, p);
+    float y = clamp(dot(t.rgb, vec3(0.25, 0.5, 0.25)), 0.0, 1.0);
+    uint code = uint(y * 255.0);
+    atomicAdd(bins[code >> 2], 1u);
+    atomicMax(brightest, code);
+    atomicMin(darkest, int(code) - 300);
+    atomicCompSwap(first, 0u, 7u);
+    atomicOr(first, 8u);
+    imageStore(output_image, p, t);
+}
+"""
+
+
+def histogram_of(img):
+    f = np.float32
+    y = np.clip((img[..., 0] * f(0.25) + img[..., 1] * f(0.5)) + img[..., 2] * f(0.25), f(0), f(1))
+    return (y * f(255.0)).astype(np.uint32)
+
+
+def test_atomic_functions_on_a_storage_block():
+    """GLSL's atomic memory functions (4.50 section 8.11) are the way invocations of a compute filter meet in a block: a histogram node"""
+    W, H = 37, 23
+    img = util.synthetic(W, H, util.F32)
+    o = np.zeros_like(img)
+    buf = np.zeros(68, np.uint32)
+    HostShader("histogram", HISTOGRAM).run({"input_image": img, "output_image": o}, None, {"Hist": buf.view(np.uint8)})
+    code = histogram_of(img)
+    assert np.array_equal(buf[:64], np.bincount((code >> 2).ravel(), minlength=64))
+    assert buf[64] == code.max() and buf[65].view(np.int32) == int(code.min()) - 300
+    assert buf[66] == 48 * 32 and buf[67] == 15 and np.array_equal(o, img)      # every invocation of the 3 x 2 workgroups ran; 0 -> 7 once, then | 8
+    with pytest.raises(Exception):      # float memory: not an atomic of GLSL 4.50 (a static_assert of the prelude, as glslc's type check)
+        HostShader("histogram_bad", HISTOGRAM.replace("atomicAdd(bins[code >> 2], 1u);", "atomicAdd(t.x, 1.0);"))
+    with pytest.raises(rf.RfError) as e:
+        rf.glsl_translate("counter", HISTOGRAM.replace("void main()", "layout (binding = 5) uniform atomic_uint counter;\nvoid main()"))
+    assert "counter.comp:" in str(e.value) and "atomic_uint" in str(e.value)
 
 
 # ---- planning and the gfx950 code objects ---------------------------------------------------------------------------------------------

@@ -279,6 +279,114 @@ kk: kitchen { gain: 1.5, shift: 3, flip: %s, mask: 5, bias: 0.25 }
     util.assert_same(got, kitchen(img, other, 1.5, 3, flip, 5, 0.25), "kitchen flip=%s" % flip)
 
 
+# ---- atomic memory functions: invocations meeting in a storage block (a histogram node and a node that reads it) -----------------------------
+HIST_GLOBAL = """#version 450
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform readonly image2D input_image;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+layout (std430, binding = 2) buffer Hist { uint bins[64]; uint brightest; uint texels; };
+void main()
+{
+    ivec2 size = imageSize(input_image);
+    ivec2 p = ivec2(gl_GlobalInvocationID.xy);
+    if (p.x >= size.x || p.y >= size.y) return;
+    vec4 t = imageLoad(input_image, p);
+    uint code = uint(clamp(dot(t.rgb, vec3(0.25, 0.5, 0.25)), 0.0, 1.0) * 255.0);
+    atomicAdd(bins[code >> 2], 1u);
+    atomicMax(brightest, code);
+    atomicAdd(texels, 1u);
+    imageStore(output_image, p, t);
+}
+"""
+
+# the same block filled the way compute filters usually do it: a histogram per workgroup in shared memory, flushed by 64 invocations
+HIST_SHARED = """#version 450
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform readonly image2D input_image;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+layout (std430, binding = 2) buffer Hist { uint bins[64]; uint brightest; uint texels; };
+shared uint local_bins[64];
+shared uint local_max;
+void main()
+{
+    ivec2 size = imageSize(input_image);
+    ivec2 p = ivec2(gl_GlobalInvocationID.xy);
+    uint l = gl_LocalInvocationIndex;
+    if (l < 64u) local_bins[l] = 0u;
+    if (l == 64u) local_max = 0u;
+    barrier();
+    bool inside = p.x < size.x && p.y < size.y;
+    if (inside) {
+        vec4 t = imageLoad(input_image, p);
+        uint code = uint(clamp(dot(t.rgb, vec3(0.25, 0.5, 0.25)), 0.0, 1.0) * 255.0);
+        atomicAdd(local_bins[code >> 2], 1u);
+        atomicMax(local_max, code);
+        imageStore(output_image, p, t);
+    }
+    barrier();
+    if (l < 64u && local_bins[l] != 0u) { atomicAdd(bins[l], local_bins[l]); atomicAdd(texels, local_bins[l]); }
+    if (l == 64u) atomicMax(brightest, local_max);
+}
+"""
+
+HIST_APPLY = """#version 450
+// out = in scaled so the brightest luma code of the frame becomes 255, rgb further scaled by the share of texels at or below the texel's bin
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform readonly image2D input_image;
+layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
+layout (std430, binding = 2) readonly buffer Hist { uint bins[64]; uint brightest; uint texels; };
+void main()
+{
+    ivec2 size = imageSize(output_image);
+    ivec2 p = ivec2(gl_GlobalInvocationID.xy);
+    if (p.x >= size.x || p.y >= size.y) return;
+    vec4 t = imageLoad(input_image, p);
+    uint code = uint(clamp(dot(t.rgb, vec3(0.25, 0.5, 0.25)), 0.0, 1.0) * 255.0);
+    uint below = 0u;
+    for (uint b = 0u; b <= (code >> 2); ++b) below += bins[b];
+    float share = float(below) / float(texels);
+    float gain = 255.0 / float(max(brightest, 1u));
+    imageStore(output_image, p, vec4(t.rgb * gain * share, t.a));
+}
+"""
+
+
+def hist_apply(img, frames=1):
+    f = np.float32
+    y = np.clip((img[..., 0] * f(0.25) + img[..., 1] * f(0.5)) + img[..., 2] * f(0.25), f(0), f(1))
+    code = (y * f(255.0)).astype(np.uint32)
+    bins = np.bincount((code >> 2).ravel(), minlength=64).astype(np.uint64) * frames      # the block is never cleared (nor is the reference's): frames add up
+    below = np.cumsum(bins)[code >> 2]
+    share = (below.astype(f) / f(code.size * frames)).astype(f)
+    gain = f(255.0) / f(max(int(code.max()), 1))
+    out = img.copy()
+    out[..., :3] = (img[..., :3] * gain) * share[..., None]
+    return out
+
+
+@pytest.mark.parametrize("source", ["global", "shared"])
+def test_a_histogram_node_fills_a_block_with_atomics_and_the_next_node_reads_it(ctx, glsl_dir, source):
+    text = HIST_GLOBAL if source == "global" else HIST_SHARED
+    (glsl_dir / "histogram.comp").write_text(text)
+    (glsl_dir / "hist_apply.comp").write_text(HIST_APPLY)
+    r = rf.glsl_reflect("histogram", text)
+    assert r["grouped"] == (source == "shared") and not r["point"] and not r["stencil"]
+    cfg = "input -> hh -> ha -> output\nhh:Hist -> ha:Hist\nhh: histogram {}\nha: hist_apply {}"
+    assert glsl_launches(cfg) == ["hh", "ha"]
+    for W, H in ((250, 131), (64, 64), (7, 3)):
+        img = util.synthetic(W, H, util.F32, seed=W)
+        util.assert_same(util.run_hip(ctx, cfg, img), hist_apply(img), "%s histogram %dx%d" % (source, W, H))
+    # a second frame through the same graph: the block keeps what the first frame added (every invocation counted exactly once per frame)
+    img = util.synthetic(120, 50, util.F32, seed=5)
+    g = rf.Graph(ctx, rf.Config(cfg), 120, 50, util.F32)
+    g.upload_raw(img)
+    g.execute()
+    g.execute()
+    g.wait()
+    util.assert_same(g.download_raw(), hist_apply(img, frames=2), "two frames")
+    g.close()
+
+
 # ---- row strips: the launch split into interior and boundary rows (the geometry of the halo exchange, one GPU) ----------------------------
 def test_a_stencil_shader_split_into_row_ranges_gives_the_same_frame(ctx, glsl_dir, monkeypatch):
     """both files state `#pragma rf radius 2`: the launch radius of a row-strip partition"""
