@@ -311,27 +311,100 @@ void rewrite(std::vector<Tok>& v, size_t b, size_t e, const Ctx& cx)
             if (q < e) { for (size_t k = i; k <= q; ++k) v[k].drop = true; i = q; continue; }
         }
         const bool basic = vector_types().count(t.s) || scalar_types().count(t.s);
-        if ((basic || cx.structs.count(t.s)) && n < e && is(v[n], "[")) {
-            // T[](a, b, c) / T[3](a, b, c): an array constructor -> {a, b, c}
-            const size_t rb = match(v, n, e), p = next_live(v, rb + 1, e);
-            if (p < e && is(v[p], "(")) {
-                const size_t q = match(v, p, e);
-                for (size_t k = i; k <= rb; ++k) v[k].drop = true;
-                v[p].s = "{";
-                v[q].s = "}";
+        const bool is_type = basic || cx.structs.count(t.s);
+        // Arrays are VALUES in GLSL (assigned, returned, passed and compared as wholes): a sized array type T[n] becomes rfg_arr<T, (n)>
+        // (rf_glsl_dev.h: a struct around the C array).  Subscripts [first, q): their sizes, outermost first; false if one is `[]`.
+        auto subscripts = [&](size_t first, size_t& q, std::vector<std::string>& dims) {
+            bool sized = true;
+            q = first;
+            while (q < e && is(v[q], "[")) {
+                const size_t rb = match(v, q, e);
+                std::string d;
+                for (size_t k = q + 1; k < rb; ++k)
+                    if (!v[k].drop) d += (d.empty() ? "" : " ") + v[k].s;
+                sized = sized && !d.empty();
+                dims.push_back(d);
+                q = next_live(v, rb + 1, e);
+            }
+            return sized;
+        };
+        auto array_type = [](const std::string& base, const std::vector<std::string>& dims) {
+            std::string ty = base;
+            for (size_t k = dims.size(); k-- > 0;) ty = "rfg_arr<" + ty + ", (" + dims[k] + ")>";
+            return ty;
+        };
+        if (is_type && n < e && is(v[n], "[")) {
+            size_t q = n;
+            std::vector<std::string> dims;
+            const bool sized = subscripts(n, q, dims);
+            if (q < e && is(v[q], "(")) {
+                // T[](a, b, c) / T[3](a, b, c): an array constructor -> {a, b, c} / rfg_arr<T, (3)>{a, b, c}
+                const size_t close = match(v, q, e);
+                for (size_t k = n; k < q; ++k) v[k].drop = true;
+                if (sized) t.s = array_type(t.s, dims);
+                else t.drop = true;
+                v[q].s = "{";
+                v[close].s = "}";
+                continue;
+            }
+            if (q < e && v[q].k == T_ID) {
+                // float[3] w  (GLSL's other spelling of  float w[3]), or the return type of a function
+                if (sized) {
+                    for (size_t k = n; k < q; ++k) v[k].drop = true;
+                    t.s = array_type(t.s, dims);
+                } else {      // float[] w = float[](...): a C array whose initialiser says its size (not a value: cannot be assigned as a whole)
+                    std::string text;
+                    for (size_t k = n; k < q; ++k) { if (!v[k].drop) text += v[k].s; v[k].drop = true; }
+                    v[q].post = text + v[q].post;
+                }
                 continue;
             }
         }
-        if ((basic || cx.structs.count(t.s)) && n < e && is(v[n], "[")) {
-            // float[3] w  (GLSL's other spelling of  float w[3]):  the dimensions move behind the name
-            size_t rb = match(v, n, e), q = next_live(v, rb + 1, e);
-            while (q < e && is(v[q], "[")) { rb = match(v, q, e); q = next_live(v, rb + 1, e); }
-            const size_t after = q < e ? next_live(v, q + 1, e) : e;
-            if (q < e && v[q].k == T_ID && !(after < e && is(v[after], "("))) {
-                std::string dims;
-                for (size_t k = n; k <= rb; ++k) { if (!v[k].drop) dims += v[k].s; v[k].drop = true; }
-                v[q].post = dims + v[q].post;
-                continue;
+        if (is_type && n < e && v[n].k == T_ID) {
+            // T a[3], b, c[2][2] = ...;  -- each declarator with subscripts gets the array type; a list whose declarators differ is split
+            const size_t after_name = next_live(v, n + 1, e);
+            if (after_name < e && !is(v[after_name], "(")) {
+                const std::string base = t.s;
+                size_t prev = i;
+                while (prev > b && v[prev - 1].drop) --prev;
+                const bool is_const = prev > b && v[prev - 1].k == T_ID && v[prev - 1].s == "const";
+                size_t name = n, sep = i;      // sep: the token that carries this declarator's type (the type token, then the commas)
+                bool first = true;
+                std::string first_ty;
+                for (;;) {
+                    size_t q = next_live(v, name + 1, e);
+                    std::vector<std::string> dims;
+                    const size_t d0 = q;
+                    const bool sized = subscripts(d0, q, dims);
+                    std::string ty = base;
+                    if (!dims.empty() && sized) {
+                        for (size_t k = d0; k < q; ++k) v[k].drop = true;
+                        ty = array_type(base, dims);
+                    }
+                    if (first) v[sep].s = first_ty = ty;
+                    else if (ty != first_ty) v[sep].s = std::string("; ") + (is_const ? "const " : "") + ty;
+                    first = false;
+                    // over the initialiser to the `,` that starts another declarator
+                    int depth = 0;
+                    while (q < e) {
+                        if (!v[q].drop) {
+                            if (is(v[q], "(") || is(v[q], "[") || is(v[q], "{")) ++depth;
+                            else if (is(v[q], ")") || is(v[q], "]") || is(v[q], "}")) { if (depth-- == 0) break; }
+                            else if (depth == 0 && (is(v[q], ",") || is(v[q], ";"))) break;
+                        }
+                        ++q;
+                    }
+                    if (q >= e || !is(v[q], ",")) break;
+                    const size_t nn = next_live(v, q + 1, e);
+                    if (nn >= e || v[nn].k != T_ID || vector_types().count(v[nn].s) || scalar_types().count(v[nn].s) || cx.structs.count(v[nn].s) || v[nn].s == "const" ||
+                        v[nn].s == "in" || v[nn].s == "out" || v[nn].s == "inout" || dropped_qualifiers().count(v[nn].s))
+                        break;      // a parameter list: the next parameter starts with its type
+                    const size_t an = next_live(v, nn + 1, e);
+                    if (an >= e || !(is(v[an], "[") || is(v[an], "=") || is(v[an], ",") || is(v[an], ";"))) break;
+                    sep = q;
+                    name = nn;
+                }
+                // (the declarators are visited again as identifiers by this loop: nothing of them is a type)
             }
         }
         if (call && vector_types().count(t.s)) { t.s = "mk_" + t.s; continue; }
@@ -691,21 +764,9 @@ struct Translator {
                     else if (v[k].s != "const" && !dropped_qualifiers().count(v[k].s)) pname = k;      // the last identifier outside brackets: the name
                 }
             }
-            bool array = false, is_const = false;
-            for (size_t k = pb; k < pe; ++k) {
-                array = array || is(v[k], "[");
-                is_const = is_const || (v[k].k == T_ID && v[k].s == "const");
-            }
-            // an array passed by value: C++ hands the function the caller's array, GLSL a copy -- the same thing as long as the function does
-            // not write it, which `const` makes the compiler check (a write is then an error with file and line, not a silent difference)
-            // (a reference to a const array: an array constructor -- braces here -- can be passed as the argument, a pointer could not take it)
-            if (array && !by_ref && pb < pe && pname < pe) {
-                if (!is_const) v[pb].pre += "const ";
-                by_ref = true;
-            }
-            if (by_ref) {
+            if (by_ref) {      // (an array parameter: its subscripts become part of the type, rewrite() -- `rfg_arr<float, (3)> &w`; by value it is a copy, as in GLSL)
                 if (pname >= pe) fail(v[pb].line, "an out parameter without a name");
-                v[pname].s = array ? "(&" + v[pname].s + ")" : "&" + v[pname].s;
+                v[pname].s = "&" + v[pname].s;
             }
             pb = pe + 1;
         }

@@ -18,7 +18,7 @@
 //                           partition must exchange or over-fetch for the node.  A file without it runs on one GPU only.
 // Translation: globals become members of `template <class RfgPx> struct RfgShader`, functions its member functions (so every
 // function sees every uniform, image and built-in variable, in any order); `vecN(...)` constructors become mk_vecN(...),
-// array constructors braces, `out` / `inout` parameters references, literals `float`, `a == b` a call (one bool also for vectors); `shared` variables move in front of
+// array constructors braces, sized arrays `rfg_arr<T, (n)>` (values, as in GLSL), `out` / `inout` parameters references, literals `float`, `a == b` a call (one bool also for vectors); `shared` variables move in front of
 // the struct as LDS variables; `precise`, precision qualifiers and prototypes go.  Not translated (the file is refused with
 // a message, as the reference refuses a file that does not compile: Option::None + warning, shader.rs:92): samplers other
 // than sampler2D, images other than image2D, nested structs in blocks, unsized arrays, double precision, image atomics and atomic counters

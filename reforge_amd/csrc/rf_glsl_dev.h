@@ -323,6 +323,19 @@ template <class A, class B> RFG bool rfg_eq(A a, B b) { return a == b; }
 RFG_EQ(vec2, 2) RFG_EQ(vec3, 3) RFG_EQ(vec4, 4) RFG_EQ(ivec2, 2) RFG_EQ(ivec3, 3) RFG_EQ(ivec4, 4) RFG_EQ(uvec2, 2) RFG_EQ(uvec3, 3) RFG_EQ(uvec4, 4)
 #undef RFG_EQ
 template <class V, int N> RFG bool rfg_eq(const matN<V, N>& a, const matN<V, N>& b) { bool r = true; for (int i = 0; i < N; ++i) r = r && rfg_eq(a.c[i], b.c[i]); return r; }
+// An array with a stated size: a value, as in GLSL (copied when assigned, passed or returned; compared element by element).  An aggregate:
+// `rfg_arr<float, 3> w = {a, b, c}` and `return rfg_arr<float, 2>{x, y}` are what the translator writes for GLSL's array constructors.
+template <class T, int N> struct rfg_arr {
+    T v[N];
+    template <class I> RFG T& operator[](I i) { return v[i]; }
+    template <class I> RFG const T& operator[](I i) const { return v[i]; }
+};
+template <class T, int N> RFG bool rfg_eq(const rfg_arr<T, N>& a, const rfg_arr<T, N>& b)
+{
+    bool r = true;
+    for (int i = 0; i < N; ++i) r = r && rfg_eq(a.v[i], b.v[i]);
+    return r;
+}
 template <class T, int N> RFG bool rfg_eq(const T (&a)[N], const T (&b)[N])      // arrays compare element by element (C++ would compare their addresses)
 {
     bool r = true;
@@ -333,6 +346,7 @@ template <class A, class B> RFG bool rfg_ne(const A& a, const B& b) { return !rf
 
 // name.length() (the translator writes rfg_length(name)): elements of an array, components of a vector
 template <class T, int N> RFG constexpr int rfg_length(const T (&)[N]) { return N; }
+template <class T, int N> RFG constexpr int rfg_length(const rfg_arr<T, N>&) { return N; }
 RFG constexpr int rfg_length(vec2) { return 2; }
 RFG constexpr int rfg_length(vec3) { return 3; }
 RFG constexpr int rfg_length(vec4) { return 4; }
