@@ -240,7 +240,10 @@ const Compiled* compile_expr(const std::string& expr, const std::vector<int>& us
     // window is a register copy, which only pays when those loops are unrolled -- a 5 x 5 tap loop over an inlined body is beyond
     // the compiler's default threshold, so it is raised for these kernels (their bodies are a few hundred instructions).
     const bool node = expr.find("user_node_kernel") != std::string::npos || expr.find("glsl_node_kernel") != std::string::npos;
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", wpb.c_str(), "-mllvm", "-unroll-threshold=6000"};
+    // -flax-vector-conversions=integer: a float vector and an integer vector of the same size do not convert into each other by
+    // REINTERPRETING their bits (this clang's default: `vec2(1.5) * ivec2(p)` of a GLSL file would compile and multiply by garbage;
+    // GLSL converts the values -- here the file is refused and told to spell the constructor); int and uint vectors still mix, as in GLSL
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", wpb.c_str(), "-mllvm", "-unroll-threshold=6000", "-flax-vector-conversions=integer"};
     rc = r->AddNameExpression(prog, expr.c_str());
     if (rc == 0) rc = r->CompileProgram(prog, node ? 7 : 5, opts);
     if (rc != 0) {

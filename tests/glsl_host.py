@@ -84,6 +84,10 @@ class Image(C.Structure):
     _fields_ = [("base", C.c_void_p), ("pitch", C.c_ulonglong)]
 
 
+# as rf_jit.cpp compiles the same source for the device: no contraction, no bit-reinterpreting conversions between float and integer vectors
+FLAGS = ["-std=c++17", "-O1", "-ffp-contract=off", "-flax-vector-conversions=integer", "-fPIC", "-shared", "-w"]
+
+
 class HostShader:
     """`text` compiled for the host.  run(images, params, buffers) executes one dispatch."""
 
@@ -95,7 +99,7 @@ class HostShader:
         if self.reflection["grouped"]:
             raise ValueError("%s.comp uses workgroup-shared memory or barrier(): not runnable on the host" % type_name)
         code = DRIVER.replace("@SOURCE@", src).replace("@NS@", ns)
-        key = hashlib.sha256((code + open(os.path.join(ROOT, "reforge_amd", "csrc", "rf_glsl_dev.h")).read()).encode()).hexdigest()[:20]
+        key = hashlib.sha256((" ".join(FLAGS) + code + open(os.path.join(ROOT, "reforge_amd", "csrc", "rf_glsl_dev.h")).read()).encode()).hexdigest()[:20]
         os.makedirs(CACHE, exist_ok=True)
         so = os.path.join(CACHE, "g_%s.so" % key)
         if not os.path.exists(so):
@@ -103,7 +107,7 @@ class HostShader:
             with open(cpp, "w") as f:
                 f.write(code)
             tmp = so + ".tmp%d" % os.getpid()
-            r = subprocess.run([CLANG, "-std=c++17", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-w", "-I", os.path.join(ROOT, "reforge_amd", "csrc"), cpp, "-o", tmp, "-lm"],
+            r = subprocess.run([CLANG] + FLAGS + ["-I", os.path.join(ROOT, "reforge_amd", "csrc"), cpp, "-o", tmp, "-lm"],
                                capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("host compile of %s.comp failed:\n%s" % (type_name, r.stderr[-3000:]))

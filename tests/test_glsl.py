@@ -550,6 +550,11 @@ def test_what_c_cannot_express_is_a_compile_error_with_the_files_line():
     with pytest.raises(Exception) as e:
         HostShader("construct", CONSTRUCT_HEAD + body)
     assert "construct.comp:8" in str(e.value), str(e.value)[:400]
+    # GLSL converts an integer vector to a float vector where the two meet; clang's vectors would REINTERPRET the bits unless told not to
+    # (-flax-vector-conversions=integer, rf_jit.cpp): the file is refused and has to spell the constructor
+    with pytest.raises(Exception) as e:
+        HostShader("construct", CONSTRUCT_HEAD + "void main() {\n ivec2 p = ivec2(gl_GlobalInvocationID.xy);\n vec2 c = vec2(1.5) * p; imageStore(output_image, p, vec4(c, 0.0, 0.0)); }")
+    assert "construct.comp:7" in str(e.value) and "cannot convert between vector values" in str(e.value), str(e.value)[:400]
 
 
 HISTOGRAM = """#version 450
