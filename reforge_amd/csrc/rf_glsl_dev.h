@@ -158,6 +158,38 @@ RFG vec4 step(float e, vec4 x) { return step(mk_vec4(e), x); }
 RFG float clamp(float x, float lo, float hi) { return min(max(x, lo), hi); }
 RFG int clamp(int x, int lo, int hi) { return min(max(x, lo), hi); }
 RFG uint clamp(uint x, uint lo, uint hi) { return min(max(x, lo), hi); }
+// min / max / clamp of scalars of DIFFERENT types (`max(x, 0)`, `clamp(i, 0.0, 1.0)`): GLSL converts int -> uint -> float and takes the
+// overload of the widest operand; C++ would call the three overloads above ambiguous
+template <class T> struct rfg_rank { static constexpr int v = -1; };
+template <> struct rfg_rank<int> { static constexpr int v = 0; };
+template <> struct rfg_rank<uint> { static constexpr int v = 1; };
+template <> struct rfg_rank<float> { static constexpr int v = 2; };
+template <int R> struct rfg_of_rank {};
+template <> struct rfg_of_rank<0> { typedef int type; };
+template <> struct rfg_of_rank<1> { typedef uint type; };
+template <> struct rfg_of_rank<2> { typedef float type; };
+template <class A, class B, class C = A> struct rfg_widest {
+    static constexpr int a = rfg_rank<A>::v, b = rfg_rank<B>::v, c = rfg_rank<C>::v;
+    static constexpr bool mixed = a >= 0 && b >= 0 && c >= 0 && !(a == b && b == c);
+    static constexpr int r = a > b ? (a > c ? a : c) : (b > c ? b : c);
+};
+template <bool M, int R> struct rfg_mixed {};
+template <int R> struct rfg_mixed<true, R> { typedef typename rfg_of_rank<R>::type type; };
+template <class A, class B> RFG typename rfg_mixed<rfg_widest<A, B>::mixed, rfg_widest<A, B>::r>::type min(A x, B y)
+{
+    typedef typename rfg_of_rank<rfg_widest<A, B>::r>::type T;
+    return min((T)x, (T)y);
+}
+template <class A, class B> RFG typename rfg_mixed<rfg_widest<A, B>::mixed, rfg_widest<A, B>::r>::type max(A x, B y)
+{
+    typedef typename rfg_of_rank<rfg_widest<A, B>::r>::type T;
+    return max((T)x, (T)y);
+}
+template <class A, class B, class C> RFG typename rfg_mixed<rfg_widest<A, B, C>::mixed, rfg_widest<A, B, C>::r>::type clamp(A x, B lo, C hi)
+{
+    typedef typename rfg_of_rank<rfg_widest<A, B, C>::r>::type T;
+    return clamp((T)x, (T)lo, (T)hi);
+}
 RFG float mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
 RFG float mix(float x, float y, bool a) { return a ? y : x; }
 RFG float smoothstep(float e0, float e1, float x)

@@ -513,6 +513,9 @@ CONSTRUCTS = {
                   "void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); imageStore(output_image, p, vec4(f(1.0), f(vec2(1.0)), f(p.x))); }", [2, 3, 3, 6]),
     "compound assignment": ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); int a = p.x; a <<= 2; a |= 1; a ^= 6; a %= 7; a >>= 1; a &= 3; uint u = 5u; u *= 3u; u -= 1u; u /= 2u; "
                             "float f = 1.0; f /= 4.0; f -= 0.125; imageStore(output_image, p, vec4(a, u, f, !(a > 1) || (u < 3u && f > 0.0) ? 1.0 : 0.0)); }", [2, 7, 0.125, 0]),
+    "built-ins with operands of different types": ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); uint u = 7u; float a = max(p.x, 5.5) + min(2.5, p.y); uint b = max(p.x, u) + min(u, 9); "
+                                                   "float c = clamp(p.x, 0.0, 4.5) + clamp(2.75, 0, 1) + clamp(p.y, 0u, 2.5); float d = mix(0, 10, 0.25) + pow(2, 3.0) + sqrt(p.x - 1) + step(4, 4.5) + mod(7, 4.0); "
+                                                   "imageStore(output_image, p, vec4(a, b, c, d)); }", [8, 14, 8, 16.5]),
     "mixed constructors": ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); vec2 a = vec2(p); vec4 b = vec4(a, 1, p.x); vec3 c = vec3(b); vec4 d = vec4(c.xy, ivec2(3, 4)); vec4 e = vec4(1u, 2, 3.0, true); "
                            "imageStore(output_image, p, b + d + e); }", [11, 8, 7, 10]),
     "array comparison": ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); int a[2] = int[](5, 2); int b[2] = int[2](p.x, 2); int c[2] = int[](p.y, 2); "
