@@ -197,10 +197,17 @@ RFG float smoothstep(float e0, float e1, float x)
     const float t = clamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
     return t * t * (3.0f - 2.0f * t);
 }
+#ifndef RFG_SPLIT_FMA
 RFG float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
 RFG vec2 fma(vec2 a, vec2 b, vec2 c) { return __builtin_elementwise_fma(a, b, c); }
 RFG vec3 fma(vec3 a, vec3 b, vec3 c) { return __builtin_elementwise_fma(a, b, c); }
 RFG vec4 fma(vec4 a, vec4 b, vec4 c) { return __builtin_elementwise_fma(a, b, c); }
+#else   // tests only (tests/test_glsl_mesa.py, host compile): fma() as a software rasteriser without fused hardware evaluates it -- two roundings
+RFG float fma(float a, float b, float c) { return a * b + c; }
+RFG vec2 fma(vec2 a, vec2 b, vec2 c) { return a * b + c; }
+RFG vec3 fma(vec3 a, vec3 b, vec3 c) { return a * b + c; }
+RFG vec4 fma(vec4 a, vec4 b, vec4 c) { return a * b + c; }
+#endif
 RFG_FV3(clamp) RFG_FV3S(clamp) RFG_FV3(mix) RFG_FV3(smoothstep)
 RFG_V3(ivec, clamp) RFG_V3S(ivec, int, clamp) RFG_V3(uvec, clamp) RFG_V3S(uvec, uint, clamp)
 RFG vec2 mix(vec2 x, vec2 y, float a) { return mix(x, y, mk_vec2(a)); }

@@ -91,7 +91,9 @@ FLAGS = ["-std=c++17", "-O1", "-ffp-contract=off", "-flax-vector-conversions=int
 class HostShader:
     """`text` compiled for the host.  run(images, params, buffers) executes one dispatch."""
 
-    def __init__(self, type_name, text):
+    def __init__(self, type_name, text, split_fma=False):
+        """split_fma: fma() evaluated with two roundings (a * b + c), what Mesa's llvmpipe does -- for tests/test_glsl_mesa.py only"""
+        flags = FLAGS + (["-DRFG_SPLIT_FMA"] if split_fma else [])
         self.type_name = type_name
         self.reflection = rf.glsl_reflect(type_name, text)
         src = rf.glsl_translate(type_name, text)
@@ -99,7 +101,7 @@ class HostShader:
         if self.reflection["grouped"]:
             raise ValueError("%s.comp uses workgroup-shared memory or barrier(): not runnable on the host" % type_name)
         code = DRIVER.replace("@SOURCE@", src).replace("@NS@", ns)
-        key = hashlib.sha256((" ".join(FLAGS) + code + open(os.path.join(ROOT, "reforge_amd", "csrc", "rf_glsl_dev.h")).read()).encode()).hexdigest()[:20]
+        key = hashlib.sha256((" ".join(flags) + code + open(os.path.join(ROOT, "reforge_amd", "csrc", "rf_glsl_dev.h")).read()).encode()).hexdigest()[:20]
         os.makedirs(CACHE, exist_ok=True)
         so = os.path.join(CACHE, "g_%s.so" % key)
         if not os.path.exists(so):
@@ -107,7 +109,7 @@ class HostShader:
             with open(cpp, "w") as f:
                 f.write(code)
             tmp = so + ".tmp%d" % os.getpid()
-            r = subprocess.run([CLANG] + FLAGS + ["-I", os.path.join(ROOT, "reforge_amd", "csrc"), cpp, "-o", tmp, "-lm"],
+            r = subprocess.run([CLANG] + flags + ["-I", os.path.join(ROOT, "reforge_amd", "csrc"), cpp, "-o", tmp, "-lm"],
                                capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("host compile of %s.comp failed:\n%s" % (type_name, r.stderr[-3000:]))

@@ -1,0 +1,211 @@
+"""shaders/*.comp and the translator's reading of GLSL against an INDEPENDENT GLSL implementation: Mesa's GLSL 4.50 compiler with its
+llvmpipe CPU back end (tests/mesa_glsl.py, tests/native/mesa_glsl.c; the driver ships in the image, no X server is needed).
+
+The reference compiles a filter file with shaderc and runs it on a Vulkan device (src/vulkan/shader.rs:73-93, command.rs:166-194); neither
+exists here, and until this file the text of shaders/*.comp had only ever been read by rf_glsl.cpp.  What is pinned:
+  * every shipped .comp is GLSL 4.50 that a GLSL compiler accepts;
+  * on rgba32f images Mesa's result and the translation's are the SAME BITS for every shipped shader, once fma() is evaluated as
+    llvmpipe evaluates it (a * b + c, two roundings: HostShader(split_fma=True)) -- so the only difference between Mesa and the product
+    is the ONE rounding of fma() that DESIGN.md section 3 specifies (what GPUs with fused hardware do), and it stays within a few ulp;
+  * the language-construct table of tests/test_glsl.py (hand-worked expectations), storage blocks, atomics, shared memory and barrier():
+    Mesa computes what the table and the numpy models say;
+  * rgba8 images: GL leaves the UNORM8 conversions to the implementation, so codes may differ by one (asserted: never more, and rarely)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import reforge_amd as rf
+from oracle import graph as ograph
+from oracle import pixel
+from tests import util
+from tests.glsl_host import HostShader
+from tests.mesa_glsl import MesaCompileError, MesaShader, runner, version, why_not
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHADERS = os.path.join(ROOT, "shaders")
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import glsl_weights  # noqa: E402
+
+pytestmark = pytest.mark.skipif(runner() is None, reason="Mesa's software rasteriser is not usable here: " + why_not())
+
+
+def text_of(t):
+    with open(os.path.join(SHADERS, t + ".comp")) as f:
+        return f.read()
+
+
+def gparams(sigma, radius):
+    return dict({"sigma": sigma}, **{"w%d" % i: w for i, w in enumerate(glsl_weights.weights(sigma, radius))})
+
+
+def cases(fmt):
+    """(type, images, params, buffers) for every shipped shader"""
+    W, H = 37, 23
+    img = util.synthetic(W, H, fmt)
+    other = util.synthetic(W, H, fmt, seed=77)
+    z = lambda: np.zeros_like(img)      # noqa: E731
+    K = 7
+    w = ograph.default_conv_weights(K, 1.5).astype(np.float32)
+    buf = np.zeros(961, np.float32)
+    buf[:K * K] = w.ravel()
+    blurred = pixel.gaussian(img, 4, sigma=2.0)
+    return [
+        ("gaussian5", {"input_image": img, "output_image": z()}, gparams(1.0, 2), None),
+        ("gaussian9", {"input_image": img, "output_image": z()}, gparams(2.0, 4), None),
+        ("gaussian", {"input_image": img, "output_image": z()}, dict(gparams(2.5, 7), radius=7), None),
+        ("colour_grade", {"input_image": img, "output_image": z()}, {"slope": 1.1, "offset": -0.02, "saturation": 1.2}, None),
+        ("colour_grade_inplace", {"image": img.copy()}, {"slope": 0.9, "offset": 0.03, "saturation": 0.4}, None),
+        ("sharpen", {"input_image": img, "output_image": z()}, {"amount": 0.75}, None),
+        ("combination", {"input_image0": img, "input_image1": other, "output_image": z()}, {"mix": 0.3}, None),
+        ("split_luma", {"input_image": img, "luma_image": z(), "chroma_image": z()}, None, None),
+        ("conv2d", {"input_image": img, "output_image": z()}, {"ksize": K}, {"ConvWeights": buf}),
+        ("invert", {"input_image": img, "output_image": z()}, {"enabled": 1, "strength": 0.7}, None),
+        ("edge_detect", {"input_image": img, "output_image": z()}, {"scale": 1.5}, None),
+        ("local_contrast", {"input_image": img, "output_image": z()}, {"amount": 0.8}, None),
+        ("pulse", {"input_image": img, "output_image": z()}, {"_rf_time": 1234.0}, None),
+        ("unsharp_mask", {"input_image": img, "blurred_image": blurred, "output_image": z(), "mask_image": z()}, {"amount": 1.5, "threshold": 0.02}, None),
+    ]
+
+
+def both_ways(t, text, images, params, buffers):
+    """{image name: (Mesa's texels, the translation's with fma() split)} for every image the shader may write"""
+    written = [i["name"] for i in rf.glsl_reflect(t, text)["images"] if not i["readonly"] and i["name"] in images]
+    mesa = MesaShader(t, text).run({k: v.copy() for k, v in images.items()}, params, None if buffers is None else {k: v.copy() for k, v in buffers.items()})
+    ours = {k: v.copy() for k, v in images.items()}
+    HostShader(t, text, split_fma=True).run(ours, params, None if buffers is None else {k: v.copy() for k, v in buffers.items()})
+    return {k: (mesa[k], ours[k]) for k in written}
+
+
+def test_mesa_is_what_it_says():
+    assert "llvmpipe" in version() and "GLSL 4." in version(), version()
+
+
+def test_every_shipped_shader_is_covered():
+    shipped = sorted(f[:-5] for f in os.listdir(SHADERS) if f.endswith(".comp"))
+    assert sorted(set(c[0] for c in cases(util.F32)) | {"conv2d_weights"}) == shipped      # conv2d_weights: its own test below (it calls exp())
+
+
+def test_mesa_and_the_translation_compute_the_same_bits_on_rgba32f():
+    for t, images, params, buffers in cases(util.F32):
+        for name, (mesa, ours) in both_ways(t, text_of(t), images, params, buffers).items():
+            util.assert_same(mesa, ours, "%s.comp %s: Mesa llvmpipe vs rf_glsl.cpp's translation (fma split on both sides)" % (t, name))
+
+
+def test_the_one_rounding_of_fma_is_all_that_separates_mesa_from_the_oracle():
+    """the product (and the oracle) evaluate fma() with ONE rounding; llvmpipe with two.  edge_detect's fmas multiply by 2 (exact either way):
+    there Mesa gives the oracle's bits.  Everywhere else the difference is a few ulp of the values involved."""
+    old = util.register_user_types()
+    try:
+        img = util.synthetic(37, 23, util.F32)
+        want = util.run_oracle("input -> nn -> output\nnn: edge_detect { scale: 1.5 }", img)
+    finally:
+        rf.set_shader_path(old)
+    got = MesaShader("edge_detect", text_of("edge_detect")).run({"input_image": img, "output_image": np.zeros_like(img)}, {"scale": 1.5})["output_image"]
+    util.assert_same(got, want, "edge_detect.comp on Mesa vs the oracle")
+    for t, oracle in (("gaussian9", lambda: pixel.gaussian(img, 4, sigma=2.0)), ("sharpen", lambda: pixel.sharpen(img, 0.75)), ("colour_grade", lambda: pixel.colour_grade(img, 1.1, -0.02, 1.2))):
+        c = next(c for c in cases(util.F32) if c[0] == t)
+        got = MesaShader(t, text_of(t)).run(c[1], c[2])["output_image"]
+        assert np.abs(got - oracle()).max() < 2e-6, t      # values of order 1: a few ulp
+
+
+def test_rgba8_images_differ_from_the_translation_by_at_most_one_code():
+    """UNORM8 <-> float is the implementation's in GL (this library: exact c / 255 on load, clamp * 255 round-to-nearest-even on store,
+    DESIGN.md section 3): most shaders give the same codes, none differs by more than one"""
+    same = 0
+    for t, images, params, buffers in cases(util.U8):
+        for name, (mesa, ours) in both_ways(t, text_of(t), images, params, buffers).items():
+            d = np.abs(mesa.astype(int) - ours.astype(int))
+            assert d.max() <= 1 and (d > 0).mean() < 0.08, (t, name, d.max(), (d > 0).mean())
+            same += int(d.max() == 0)
+    assert same >= 10
+
+
+def test_conv2d_weights_fills_the_same_block_up_to_exp():
+    buf_m, buf_o = np.zeros(961, np.float32), np.zeros(961, np.float32)
+    img = util.synthetic(20, 9, util.F32)
+    MesaShader("conv2d_weights", text_of("conv2d_weights")).run({"input_image": img, "output_image": np.zeros_like(img)}, {"ksize": 7, "sigma": 1.5}, {"ConvWeights": buf_m})
+    HostShader("conv2d_weights", text_of("conv2d_weights"), split_fma=True).run({"input_image": img, "output_image": np.zeros_like(img)}, {"ksize": 7, "sigma": 1.5}, {"ConvWeights": buf_o})
+    assert np.abs(buf_m - buf_o).max() < 1e-7 and abs(float(buf_m[:49].sum()) - 1.0) < 1e-6 and not buf_m[49:].any()      # exp() is each implementation's own
+
+
+# ---- the language: the hand-worked construct table of tests/test_glsl.py, computed by Mesa ----------------------------------------------------
+from tests.test_glsl import CONSTRUCT_HEAD, CONSTRUCTS, HISTOGRAM, histogram_of  # noqa: E402
+
+# what GLSL 4.50 itself does not allow (this library's translation is more permissive there, never different)
+NOT_GLSL_450 = set()
+
+
+@pytest.mark.parametrize("name", sorted(CONSTRUCTS))
+def test_mesa_computes_what_the_construct_table_says(name):
+    body, want = CONSTRUCTS[name]
+    img = util.synthetic(20, 9, util.F32)
+    try:
+        got = MesaShader("construct", CONSTRUCT_HEAD + body).run({"input_image": img, "output_image": np.zeros_like(img)})["output_image"]
+    except MesaCompileError as e:
+        if name in NOT_GLSL_450:
+            pytest.skip("not GLSL 4.50: " + str(e)[-200:])
+        raise
+    assert got[3, 5].tolist() == [float(x) for x in want], (name, got[3, 5])
+
+
+def test_atomic_functions_on_a_storage_block_on_mesa():
+    W, H = 37, 23
+    img = util.synthetic(W, H, util.F32)
+    buf = np.zeros(68, np.uint32)
+    out = MesaShader("histogram", HISTOGRAM).run({"input_image": img, "output_image": np.zeros_like(img)}, None, {"Hist": buf})["output_image"]
+    code = histogram_of(img)
+    assert np.array_equal(buf[:64], np.bincount((code >> 2).ravel(), minlength=64))
+    assert buf[64] == code.max() and buf[65].view(np.int32) == int(code.min()) - 300
+    assert buf[66] == 48 * 32 and buf[67] == 15 and np.array_equal(out, img)
+
+
+def test_shared_memory_barrier_and_the_kitchen_sink_on_mesa():
+    from tests.test_gpu_glsl import HIST_APPLY, HIST_SHARED, KITCHEN, KITCHEN_FILL, TILE_BLUR, box3, hist_apply, kitchen
+    img = util.synthetic(70, 37, util.F32)
+    z = np.zeros_like(img)
+    got = MesaShader("tile_blur", TILE_BLUR).run({"input_image": img, "output_image": z.copy()})["output_image"]
+    util.assert_same(got, box3(img), "tile_blur (shared memory, barrier) on Mesa vs the numpy model the GPU test uses")
+    # a histogram per workgroup in shared memory, flushed with atomics; the node that reads the block
+    hist = np.zeros(66, np.uint32)
+    MesaShader("histogram", HIST_SHARED).run({"input_image": img, "output_image": z.copy()}, None, {"Hist": hist})
+    got = MesaShader("hist_apply", HIST_APPLY).run({"input_image": img, "output_image": z.copy()}, None, {"Hist": hist})["output_image"]
+    util.assert_same(got, hist_apply(img), "histogram -> hist_apply on Mesa vs the numpy model")
+    # structs, matrices, out parameters, array parameters, swizzles, bool / uint uniforms, two storage blocks, a second input image
+    other = util.run_oracle("input -> gg -> output\ngg: colour_grade { slope: 0.5, offset: 0.25, saturation: 1.0 }", img)
+    lut = np.zeros(12, np.float32)
+    MesaShader("kitchen_fill", KITCHEN_FILL).run({"input_image": img, "output_image": z.copy()}, None, {"Lut": lut})
+    assert lut.tolist() == [0.125 * i for i in range(8)] + [1.0, 2.0, 3.0, 0.5]
+    for flip in (0, 1):
+        got = MesaShader("kitchen", KITCHEN).run({"input_image": img, "other_image": other, "output_image": z.copy()}, {"gain": 1.5, "shift": 3, "flip": flip, "mask": 5, "bias": 0.25},
+                                                 {"Lut": lut, "Stats": np.zeros(4, np.uint32)})["output_image"]
+        util.assert_same(got, kitchen(img, other, 1.5, 3, bool(flip), 5, 0.25), "kitchen flip=%d on Mesa vs the numpy model" % flip)
+
+
+@pytest.mark.parametrize("params", [(0.0, 0.0, 1.0), (0.37, -1.25, 1.0), (3.5, 40.0, 0.75)])
+def test_the_graphs_sampler_filters_as_a_gl_sampler_with_the_same_parameters(params):
+    """texture() / texelFetch() / textureSize() through reforge's one sampler -- LINEAR, U clamp-to-edge, V REPEAT (vkutils.rs:358-365: the
+    second address mode is never set) -- against a GL sampler object set up the same way: the same texels with the same weights up to the
+    filter's own arithmetic (llvmpipe's lerp rounds differently: 1e-6 of values of order 1; one code on rgba8)"""
+    from tests.test_glsl import RESAMPLE, resample
+    img = util.synthetic(45, 23, util.F32)
+    run = lambda text, im: MesaShader("resample", text).run({"source": im, "output_image": np.zeros_like(im)}, {"shift_x": params[0], "shift_y": params[1], "zoom": params[2]})["output_image"]      # noqa: E731
+    got = run(RESAMPLE, img)
+    assert np.abs(got - resample(img, *params)).max() < 4e-6
+    assert np.array_equal(got[..., 3], img[:, ::-1, 3])      # texelFetch: exact
+    img8 = util.synthetic(45, 23, util.U8)
+    got8 = run(RESAMPLE.replace("rgba32f", "rgba8"), img8)
+    want8 = np.clip(np.rint(np.clip(resample(img8, *params), 0, 1) * 255), 0, 255).astype(np.uint8)
+    assert np.abs(got8.astype(int) - want8.astype(int)).max() <= 1
+
+
+def test_what_mesa_refuses_the_translator_refuses_or_the_run_time_compiler_does():
+    """files outside GLSL 4.50: Mesa's compiler rejects them; here either rf_glsl.cpp does, or the translation fails to compile"""
+    head = CONSTRUCT_HEAD
+    for body in ("void main() { imageStore(output_image, ivec2(0), imageLoad(input_image, gl_GlobalInvocationID.xy)); }",      # a uvec2 coordinate
+                 "void main() { vec4 v = imageLoad(input_image, ivec2(0)); atomicAdd(v.x, 1.0); imageStore(output_image, ivec2(0), v); }"):      # float atomics
+        with pytest.raises(MesaCompileError):
+            MesaShader("bad", head + body).run({"input_image": np.zeros((4, 4, 4), np.float32), "output_image": np.zeros((4, 4, 4), np.float32)})
+        with pytest.raises(Exception):
+            HostShader("bad", head + body)
