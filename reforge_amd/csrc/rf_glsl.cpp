@@ -18,6 +18,7 @@ struct Tok {
     std::string s;       // the text that is emitted (rewritten in place)
     std::string ws;      // what stood in front of it: white space; comments are reduced to their line breaks
     std::string pre, post;   // inserted around it (emitted even when the token itself is dropped)
+    std::string outer;       // inserted in front of `pre`: the opening of a call that encloses what `pre` opens (rfg_xor( around rfg_eq( )
     int line = 1;
     bool drop = false;   // emit the white space only
 };
@@ -251,6 +252,65 @@ void rewrite_equality(std::vector<Tok>& v, size_t b, size_t e)
     }
 }
 
+// a ^^ b (GLSL's logical exclusive or; C++ has no such operator) -> rfg_xor(a, b).  It binds tighter than || only: the operands reach
+// back / forward to the enclosing bracket, `,` `;` `?` `:`, an assignment, `||` or another ^^ (left-associative: the LAST one of a chain is
+// rewritten first, its left operand the chain in front of it).  Runs before rewrite_equality, whose scans stop at the comma written here.
+void rewrite_logical_xor(std::vector<Tok>& v, size_t b, size_t e)
+{
+    auto live = [&](size_t i) { return !v[i].drop; };
+    auto punct = [&](size_t i, char c) { return i < e && live(i) && v[i].k == T_PUNCT && v[i].s.size() == 1 && v[i].s[0] == c; };
+    auto glued = [&](size_t i) { return v[i].ws.empty() && v[i].pre.empty() && v[i].outer.empty(); };
+    for (size_t i = e; i-- > b + 1;) {
+        if (!punct(i - 1, '^') || !punct(i, '^') || !glued(i)) continue;
+        const size_t op = i - 1;
+        size_t lb = op;
+        int depth = 0;
+        while (lb > b) {
+            const size_t k = lb - 1;
+            if (!live(k)) { --lb; continue; }
+            if (v[k].k == T_PUNCT) {
+                const char c = v[k].s[0];
+                if (c == ')' || c == ']' || c == '}') ++depth;
+                else if (c == '(' || c == '[' || c == '{') { if (depth == 0) break; --depth; }
+                else if (depth == 0) {
+                    if (c == ',' || c == ';' || c == '?' || c == ':') break;
+                    if (c == '|' && k > b && punct(k - 1, '|') && glued(k)) break;      // ||
+                    if (c == '=') {
+                        const bool compare = (k > b && live(k - 1) && v[k - 1].k == T_PUNCT && glued(k) && std::string("=!<>").find(v[k - 1].s[0]) != std::string::npos) ||
+                                             (punct(k + 1, '=') && glued(k + 1));
+                        if (!compare) break;      // an assignment
+                    }
+                }
+            } else if (depth == 0 && v[k].k == T_ID && (v[k].s == "return" || v[k].s == "case")) break;
+            --lb;
+        }
+        while (lb < op && !live(lb)) ++lb;
+        size_t re = i + 1;
+        depth = 0;
+        while (re < e) {
+            if (live(re) && v[re].k == T_PUNCT) {
+                const char c = v[re].s[0];
+                if (c == '(' || c == '[' || c == '{') ++depth;
+                else if (c == ')' || c == ']' || c == '}') { if (depth == 0) break; --depth; }
+                else if (depth == 0) {
+                    if (c == ',' || c == ';' || c == '?' || c == ':') break;
+                    if (c == '|' && punct(re + 1, '|') && glued(re + 1)) break;
+                    if (c == '^' && punct(re + 1, '^') && glued(re + 1)) break;
+                }
+            }
+            ++re;
+        }
+        if (lb >= op || re <= i + 1) throw Fail{v[op].line, "cannot find the operands of this ^^"};
+        size_t last = re - 1;
+        while (last > i && !live(last)) --last;
+        v[lb].outer += "rfg_xor(";
+        v[op].s = ",";
+        v[i].drop = true;
+        v[last].post += ")";
+        i = op;      // (the loop's i-- moves in front of the operator)
+    }
+}
+
 // the rewrites that need no knowledge of where a token stands: [b, e)
 void rewrite(std::vector<Tok>& v, size_t b, size_t e, const Ctx& cx)
 {
@@ -419,6 +479,7 @@ void rewrite(std::vector<Tok>& v, size_t b, size_t e, const Ctx& cx)
         if (cx.ssbo_scalars.count(t.s)) { t.s = "(*rfg_p_" + t.s + ")"; continue; }
         if (cx.ssbo_instances.count(t.s) && n < e && is(v[n], ".")) { v[n].s = "->"; continue; }
     }
+    rewrite_logical_xor(v, b, e);
     rewrite_equality(v, b, e);
 }
 
@@ -426,7 +487,7 @@ std::string emit(const std::vector<Tok>& v, size_t b, size_t e)
 {
     std::string o;
     for (size_t i = b; i < e; ++i) {
-        o += v[i].ws + v[i].pre;
+        o += v[i].ws + v[i].outer + v[i].pre;
         if (!v[i].drop) o += v[i].s;
         o += v[i].post;
     }

@@ -382,6 +382,7 @@ template <class T, int N> RFG bool rfg_eq(const T (&a)[N], const T (&b)[N])     
     return r;
 }
 template <class A, class B> RFG bool rfg_ne(const A& a, const B& b) { return !rfg_eq(a, b); }
+RFG bool rfg_xor(bool a, bool b) { return a != b; }      // a ^^ b
 
 // name.length() (the translator writes rfg_length(name)): elements of an array, components of a vector
 template <class T, int N> RFG constexpr int rfg_length(const T (&)[N]) { return N; }

@@ -240,12 +240,63 @@ const Compiled* compile_expr(const std::string& expr, const std::vector<int>& us
     // window is a register copy, which only pays when those loops are unrolled -- a 5 x 5 tap loop over an inlined body is beyond
     // the compiler's default threshold, so it is raised for these kernels (their bodies are a few hundred instructions).
     const bool node = expr.find("user_node_kernel") != std::string::npos || expr.find("glsl_node_kernel") != std::string::npos;
-    // -flax-vector-conversions=integer: a float vector and an integer vector of the same size do not convert into each other by
-    // REINTERPRETING their bits (this clang's default: `vec2(1.5) * ivec2(p)` of a GLSL file would compile and multiply by garbage;
-    // GLSL converts the values -- here the file is refused and told to spell the constructor); int and uint vectors still mix, as in GLSL
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", wpb.c_str(), "-mllvm", "-unroll-threshold=6000", "-flax-vector-conversions=integer"};
+    // -fwrapv (units that hold a GLSL file only): GLSL's int arithmetic wraps; C++ calls the overflow undefined and may optimise on that
+    bool glsl = false;
+    for (int id : users) {
+        const UserStage* u = user_stage_by_id(id);
+        glsl = glsl || (u && u->glsl);
+    }
+    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", wpb.c_str()};
+    if (node) { opts.push_back("-mllvm"); opts.push_back("-unroll-threshold=6000"); }
+    if (glsl) opts.push_back("-fwrapv");
+    if (glsl) {
+        // A float vector and an integer vector of the same size convert into each other by REINTERPRETING their bits under this clang's
+        // default (-flax-vector-conversions=all): `vec2(p) / imageSize(image)` of a GLSL file would compile and divide by garbage, where GLSL
+        // converts the values.  The strict mode cannot be the mode of the build (the run-time compiler's own header needs the lax one),
+        // so the unit is parsed once more in strict mode and only the errors that lie in a .comp file count: the file is refused and
+        // told to spell the constructor.  (int and uint vectors still mix, as in GLSL.)
+        RtcProgram check = nullptr;
+        if (r->CreateProgram(&check, source, "rf_stream_jit.hip", 0, nullptr, nullptr) == 0) {
+            std::vector<const char*> strict = opts;
+            strict.push_back("-flax-vector-conversions=integer");
+            strict.push_back("-ferror-limit=0");
+            r->AddNameExpression(check, expr.c_str());
+            if (r->CompileProgram(check, (int)strict.size(), strict.data()) != 0) {
+                size_t ls = 0;
+                r->GetProgramLogSize(check, &ls);
+                std::string log(ls, 0);
+                if (ls) r->GetProgramLog(check, &log[0]);
+                std::string found;
+                size_t at = 0;
+                while (at < log.size()) {
+                    size_t nl = log.find('\n', at);
+                    if (nl == std::string::npos) nl = log.size();
+                    const std::string line = log.substr(at, nl - at);
+                    const size_t comp = line.find(".comp:"), er = line.find(": error:");
+                    if (comp != std::string::npos && er != std::string::npos && comp < er) {
+                        found = line;
+                        // the line of the file and the caret under it
+                        for (int extra = 0; extra < 2 && nl < log.size(); ++extra) {
+                            const size_t n2 = log.find('\n', nl + 1);
+                            found += "\n" + log.substr(nl + 1, (n2 == std::string::npos ? log.size() : n2) - nl - 1);
+                            nl = n2 == std::string::npos ? log.size() : n2;
+                        }
+                        break;
+                    }
+                    at = nl + 1;
+                }
+                if (!found.empty()) {
+                    r->DestroyProgram(&check);
+                    r->DestroyProgram(&prog);
+                    err = found + "\n(GLSL converts an integer vector to a float vector where the two meet; here the conversion has to be written: vec2(p), vec4(size, size), ...)";
+                    return nullptr;
+                }
+            }
+            r->DestroyProgram(&check);
+        }
+    }
     rc = r->AddNameExpression(prog, expr.c_str());
-    if (rc == 0) rc = r->CompileProgram(prog, node ? 7 : 5, opts);
+    if (rc == 0) rc = r->CompileProgram(prog, (int)opts.size(), opts.data());
     if (rc != 0) {
         size_t ls = 0;
         r->GetProgramLogSize(prog, &ls);

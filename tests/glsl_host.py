@@ -85,7 +85,7 @@ class Image(C.Structure):
 
 
 # as rf_jit.cpp compiles the same source for the device: no contraction, no bit-reinterpreting conversions between float and integer vectors
-FLAGS = ["-std=c++17", "-O1", "-ffp-contract=off", "-flax-vector-conversions=integer", "-fPIC", "-shared", "-w"]
+FLAGS = ["-std=c++17", "-O1", "-ffp-contract=off", "-flax-vector-conversions=integer", "-fwrapv", "-fPIC", "-shared", "-w"]
 
 
 class HostShader:

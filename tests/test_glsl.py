@@ -609,6 +609,18 @@ def test_atomic_functions_on_a_storage_block():
     assert "counter.comp:" in str(e.value) and "atomic_uint" in str(e.value)
 
 
+def test_an_integer_vector_where_a_float_vector_is_meant_is_refused_by_the_run_time_compiler_too(glsl_dir, tmp_path, monkeypatch):
+    """the product's compile (hiprtc, rf_jit.cpp): the strict second parse finds what the default mode would turn into a reinterpretation of bits"""
+    monkeypatch.setenv("RF_JIT_CACHE_DIR", str(tmp_path / "cache"))
+    bad = GAIN.replace("vec4(c.rgb * gain + bias, c.a)", "vec4(c.rg * gain + bias, vec2(0.5) * p)")
+    (glsl_dir / "scaled.comp").write_text(bad)
+    with pytest.raises(rf.RfError) as e:
+        rf.Plan(rf.Config("input -> ss -> output\nss: scaled { gain: 2.0 }"), rf.RF_GRAPH_GLSL_NODES).jit_compile(rf.RF_FORMAT_RGBA32F)
+    assert "scaled.comp:12" in str(e.value) and "cannot convert between vector values" in str(e.value) and "vec2(p)" in str(e.value)
+    (glsl_dir / "scaled.comp").write_text(bad.replace("vec2(0.5) * p", "vec2(0.5) * vec2(p)"))
+    rf.Plan(rf.Config("input -> ss -> output\nss: scaled { gain: 2.0 }"), rf.RF_GRAPH_GLSL_NODES).jit_compile(rf.RF_FORMAT_RGBA32F)
+
+
 # ---- planning and the gfx950 code objects ---------------------------------------------------------------------------------------------
 def test_a_type_that_is_a_comp_file_plans_as_a_node_of_its_own(glsl_dir):
     for t in ("gaussian5", "colour_grade", "sharpen"):
