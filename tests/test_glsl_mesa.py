@@ -228,6 +228,33 @@ def test_the_graphs_sampler_filters_as_a_gl_sampler_with_the_same_parameters(par
     assert np.abs(got8.astype(int) - want8.astype(int)).max() <= 1
 
 
+def test_the_references_own_kernel_compiles_on_mesa_and_runs_like_its_translation():
+    """shaders/passthrough.comp of the reference (its one kernel; read where it lies, never copied): its qualifier says rgba8 and the
+    reference runs it on the graph's format (main.rs:60) -- here on both"""
+    path = "/root/reference/shaders/passthrough.comp"
+    if not os.path.exists(path):
+        pytest.skip("the reference is not on this machine")
+    with open(path) as f:
+        text = f.read()
+    for fmt in (util.F32, util.U8):
+        img = util.synthetic(37, 23, fmt)
+        (mesa, ours), = both_ways("passthrough", text, {"input_image": img, "output_image": np.zeros_like(img)}, None, None).values()
+        util.assert_same(mesa, ours, "the reference's passthrough.comp")
+        util.assert_same(mesa, img, "... is the identity")
+
+
+def test_the_dispatch_and_the_frame_edges_are_the_references():
+    """ceil(W/16) x ceil(H/16) workgroups whatever local_size the file declares (command.rs:167-168): a file with 8 x 4 covers part of the
+    frame; loads outside the frame give zero and stores outside are dropped (GL's rule for images; what rf_glsl_dev.h does)"""
+    text = CONSTRUCT_HEAD.replace("local_size_x = 16, local_size_y = 16", "local_size_x = 8, local_size_y = 4") + (
+        "void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); precise vec4 a = imageLoad(input_image, p - ivec2(3, 2)) + imageLoad(input_image, p + ivec2(30, 20)); "
+        "a = a + vec4(1.0); imageStore(output_image, p + ivec2(2, 1), a); }")      # (precise: Mesa re-associates sums that are not)
+    img = util.synthetic(37, 23, util.F32)
+    (mesa, ours), = both_ways("partial", text, {"input_image": img, "output_image": np.zeros_like(img)}, None, None).values()
+    util.assert_same(mesa, ours, "partial coverage, out-of-frame loads and stores")
+    assert (mesa[:, :, 0] != 0).sum() == 24 * 8      # 3 x 2 workgroups of 8 x 4 invocations, each storing inside the frame
+
+
 def test_what_mesa_refuses_the_translator_refuses_or_the_run_time_compiler_does():
     """files outside GLSL 4.50: Mesa's compiler rejects them; here either rf_glsl.cpp does, or the translation fails to compile"""
     head = CONSTRUCT_HEAD
