@@ -133,6 +133,7 @@ class MesaShader:
             open(os.path.join(d, "job"), "w").write("\n".join(job) + "\n")
             gx, gy = groups or ((W + 15) // 16, (H + 15) // 16)
             r = subprocess.run([exe, comp, str(W), str(H), str(gx), str(gy), os.path.join(d, "job")], capture_output=True, text=True, timeout=600)
+            self.last_log = r.stderr      # (scripts/mesa_baseline.py reads the runner's timing line)
             if r.returncode == 3:
                 raise MesaCompileError(r.stderr)
             assert r.returncode == 0, (r.returncode, r.stderr[-2000:])

@@ -3,7 +3,7 @@
 // 4.5 core context is made current on a drawable nobody looks at, and the shader is dispatched over images / a uniform block / storage blocks read
 // from files.  An INDEPENDENT GLSL implementation (Mesa's compiler front end and its CPU back end): tests/test_glsl_mesa.py compares what
 // it computes for shaders/*.comp and for the language-construct cases with the oracle and with librfhip's own translation of the same text.
-// Nothing of the product links or runs this.
+// Nothing of the product links or runs this.  (-D_POSIX_C_SOURCE not needed: gcc's default is gnu17.)
 //
 //   mesa_glsl <shader.comp> <W> <H> <groups_x> <groups_y> <job file>        job file, one resource per line:
 //     image   <binding> <rgba32f|rgba8> <in.raw|-> <out.raw|->      a W x H texture bound as an image (imageLoad / imageStore)
@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <GL/glcorearb.h>
 #include <GL/internal/dri_interface.h>
@@ -212,6 +213,18 @@ int main(int argc, char** argv)
     glDispatchCompute((GLuint)gx, (GLuint)gy, 1);
     glMemoryBarrier(GL_ALL_BARRIER_BITS);
     glFinish();
+    if (getenv("RF_MESA_REPEAT")) {      // scripts/mesa_baseline.py: the time of a dispatch on this machine's cores (the shader must not accumulate)
+        const int n = atoi(getenv("RF_MESA_REPEAT"));
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int i = 0; i < n; ++i) {
+            glDispatchCompute((GLuint)gx, (GLuint)gy, 1);
+            glMemoryBarrier(GL_ALL_BARRIER_BITS);
+        }
+        glFinish();
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        fprintf(stderr, "mesa_glsl: dispatch_ms %.4f\n", ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6) / (n > 0 ? n : 1));
+    }
     for (int i = 0; i < n_out; ++i) {
         void* data = malloc(outs[i].bytes);
         if (outs[i].kind == 0) {
