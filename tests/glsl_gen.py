@@ -206,7 +206,7 @@ class Gen:
 
     def statement(self):
         r = self.r
-        k = r.randrange(14)
+        k = r.randrange(18)
         if k <= 2:
             self.declare("float", self.f())
         elif k == 3:
@@ -244,6 +244,28 @@ class Gen:
             self.lines.append("    precise float %s; swap_sum(%s, %s);" % (o, b2, o))
             self.lines.append("    %s = clamp(%s + (%s == %s ? 1.0 : 0.0), -8.0, 8.0);" % (o, o, a, b2))
             self.vars["float"].append(o)
+        elif k == 14:      # matrices: constructors, products, transpose, columns
+            m, n2 = self.name(), self.name()
+            dim = r.choice([2, 3])
+            vt = "vec%d" % dim
+            cols = ", ".join(self.v(dim, 2) for _ in range(dim))
+            self.lines.append("    mat%d %s = mat%d(%s);" % (dim, m, dim, cols))
+            self.lines.append("    mat%d %s = %s;" % (dim, n2, r.choice(["transpose(%s)" % m, "%s * mat%d(0.5)" % (m, dim), "mat%d(%s)" % (dim, self.f(2)), "%s * 0.25 + %s" % (m, m)])))
+            self.lines.append("    precise %s %s_c = %s[%d];" % (vt, m, n2, r.randrange(dim)))
+            self.lines.append("    %s_c = clamp(%s_c, %s(-8.0), %s(8.0));" % (m, m, vt, vt))
+            self.vars[vt].append(m + "_c")
+        elif k == 15:      # switch, while, a helper with an inout parameter and an early return
+            a = self.name()
+            self.lines.append("    precise float %s = %s;" % (a, self.bounded("float", self.f(1))))
+            self.lines.append("    switch (abs(%s) %% 4) { case 0: %s += 0.5; break; case 1: %s = -%s; case 2: %s *= 0.5; break; default: bump(%s, %s); }" % (
+                self.atom_i(2), a, a, a, a, a, self.i(2)))
+            self.lines.append("    { int guard = 0; while (%s > 0.25 && guard < 6) { %s *= 0.5; ++guard; } }" % (a, a))
+            self.vars["float"].append(a)
+        elif k == 16:      # integer vectors
+            q = self.name()
+            self.lines.append("    ivec3 %s = ivec3(%s, %s) %s ivec3(%s);" % (q, self.pick("ivec2"), self.i(2), r.choice(["+", "-", "*", "&", "|", "^"]), self.i(2)))
+            self.lines.append("    uvec2 %s_u = uvec2(%s.zx) >> uvec2(%s & 7, 3) ;" % (q, q, self.atom_i(2)))
+            self.declare("int", "%s.x + %s.y - %s.z + int(%s_u.x & 255u) + int(bitfieldInsert(%s, %s, %d, %d) & 0xfffu)" % (q, q, q, q, self.u(2), self.u(2), r.randrange(0, 8), r.randrange(1, 8)))
         else:      # structs
             s, o = self.name(), self.name()
             self.lines.append("    Pair %s = Pair(%s, %s);" % (s, self.v(2, 1), self.i(1)))
@@ -283,6 +305,7 @@ class Gen:
             acc.append("o.xy += vec2(%s & 127) * 0.0078125;" % v)
         body = "\n".join(self.lines + ["    " + a for a in acc] + ["    imageStore(output_image, p, o);"])
         helpers = ("struct Pair { vec2 a; int n; };\n"
+                   "void bump(inout float x, int n) { if (n < 0) { x -= 0.25; return; } for (int i = 0; i < (n & 3); ++i) x += 0.125; }\n"
                    "void swap_sum(float w[3], out float total) { float t = w[0]; w[0] = w[2]; w[2] = t; precise float half_of = w[1] * 0.5; precise float quarter = w[2] * 0.25; "
                    "precise float r = w[0] - half_of; r = r + quarter; total = r; }\n")
         return HEAD + helpers + "void main()\n{\n" + body + "\n}\n"
