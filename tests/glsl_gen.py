@@ -75,7 +75,9 @@ class Gen:
             n = r.choice([2, 3, 4])
             return "dot(%s, %s)" % (self.v(n, d + 1), self.v(n, d + 1))
         if k == 14:
-            return "fma(%s, %s, %s)" % (self.f(d + 1), self.f(d + 1), self.f(d + 1))
+            # (not fma(): Mesa evaluates it with two roundings or with one depending on its operands -- fma(x, 1.25, 3.0) fused where
+            # fma(x, 1.25, y) is split, seed 20178 of profiles/r04_fuzz_glsl_mesa.txt; the shipped shaders' fma()s are covered one by one)
+            return "(%s * %s + %s)" % (self.f(d + 1), self.f(d + 1), self.f(d + 1))
         return "mix(%s, %s, %s)" % (self.f(d + 1), self.f(d + 1), r.choice(["0.25", "0.5", "gain * 0.125"]))
 
     def atom_i(self, d):
