@@ -363,8 +363,8 @@ void main()
     float[3] lift = float[3](0.25, 0.25, 0.25);
     for (int i = 0; i != lift.length(); ++i) c[i] += lift[i];
     if (mat2(1.0) == mat2(1.0, 0.0, 0.0, 1.0)) c.b = 1.0;
-    uint packed = packUnorm4x8(vec4(c.r - 0.25, 0.5, 2.0, -1.0));
-    c.g = unpackUnorm4x8(packed).x + float(bitCount(packed & 0xFFu)) + float(findMSB(uint(p.x + 1))) + float(bitfieldExtract(uint(p.y), 1, 3));
+    uint code4 = packUnorm4x8(vec4(c.r - 0.25, 0.5, 2.0, -1.0));
+    c.g = unpackUnorm4x8(code4).x + float(bitCount(code4 & 0xFFu)) + float(findMSB(uint(p.x + 1))) + float(bitfieldExtract(uint(p.y), 1, 3));
     imageStore(image, p, c);
 }
 """

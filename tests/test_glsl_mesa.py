@@ -166,6 +166,38 @@ def test_generated_shaders_give_the_same_bits_on_mesa_and_through_the_translatio
         util.assert_same(mesa, ours, "generated shader %d: Mesa vs the translation\n%s" % (seed, text))
 
 
+def test_vector_and_matrix_equality_and_the_pack_and_bit_built_ins_on_mesa():
+    """tests/test_glsl.py's EQUALITY shader (== on vectors and matrices is ONE bool, a ternary between && and ==, .length(), packUnorm4x8, findMSB,
+    bitfieldExtract) -- without its specialisation constant, which is Vulkan's GLSL"""
+    from tests.test_glsl import EQUALITY, equality
+    text = EQUALITY.replace("layout (constant_id = 3) const int MODE = 2;", "const int MODE = 2;")
+    img = util.synthetic(37, 21, util.F32)
+    img[3, 5, :3] = 0.0
+    img[4, 6, 0] = img[4, 6, 1]
+    mesa = MesaShader("equality", text).run({"image": img.copy()})["image"]
+    ours = img.copy()
+    HostShader("equality", text).run({"image": ours})
+    util.assert_same(mesa, ours, "EQUALITY: Mesa vs the translation")
+    util.assert_same(mesa, equality(img), "EQUALITY: Mesa vs the numpy model")
+
+
+def test_the_shader_texts_of_the_recognition_tests_are_glsl_and_run_the_same():
+    """GAIN / BOX5 and their near-misses (tests/test_glsl.py: what is and is not a point shader, a translation-invariant stencil): each is
+    GLSL 4.50 to Mesa and gives the translation's bits -- whichever kernel form the product then picks for it"""
+    from tests.test_glsl import BOX5, GAIN, NOT_POINT, NOT_STENCIL
+    img = util.synthetic(40, 19, util.F32)
+    texts = dict({"GAIN": GAIN, "BOX5": BOX5}, **{"not point: " + k: v for k, v in NOT_POINT.items()}, **{"not stencil: " + k: v for k, v in NOT_STENCIL.items()})
+    for name, text in texts.items():
+        try:
+            rf.glsl_translate("recognition", text)
+        except rf.RfError:
+            continue      # a text the translator refuses (a stencil in place): nothing to compare
+        images = {i["name"]: (img if i["readonly"] else np.zeros_like(img)) for i in rf.glsl_reflect("t", text)["images"]}
+        for image_name, (mesa, ours) in both_ways("recognition", text, images, {"gain": 1.5, "bias": 0.25, "reach": 1}, None).items():
+            d = np.abs(mesa.astype(np.float64) - ours.astype(np.float64)).max()
+            assert d <= 4e-6, (name, image_name, d)      # (sums that are not `precise`: Mesa may contract or re-associate them)
+
+
 def test_logical_xor_binds_between_and_and_or():
     body = ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); bool a = p.x > 2, b = p.y > 2, c = p.x == 5; "
             "bool r0 = a ^^ b; bool r1 = a && b ^^ c && a; bool r2 = a ^^ b || c; bool r3 = a ^^ b ^^ c; bool r4 = p.x == 5 ^^ p.y != 3; "
