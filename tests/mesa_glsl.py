@@ -143,3 +143,46 @@ class MesaShader:
                 got = np.fromfile(path, np.uint8)
                 b[:got.size] = got
             return result
+
+
+class FileGraph:
+    """A whole config run the REFERENCE'S WAY with the filter files as the kernels: the config is parsed, the nodes ordered and the images
+    aliased by the oracle's restatement of the reference's planner (oracle/graph.py: config.rs, pipeline_graph.rs:358-497), and every node
+    is ONE dispatch of `shaders/{type}.comp` over ceil(W/16) x ceil(H/16) workgroups (command.rs:166-194) -- executed by `how`:
+    "mesa" (Mesa's GLSL compiler + llvmpipe) or "host" (rf_glsl.cpp's translation compiled for the host, fma() split like llvmpipe's)."""
+
+    def __init__(self, text, img, how, shader_dir):
+        from oracle import graph as ograph
+        from oracle import pixel
+        from tests.glsl_host import HostShader
+        H, W, _ = img.shape
+        g = ograph.GraphOracle(text, W, H, pixel.fmt_of(img))
+        g.upload_raw(img)
+        shaders = {}
+
+        def run_node(info):
+            def image(resource):
+                return g.images[ograph._remap(resource, g.reuse)]
+            if info.type not in shaders:
+                with open(os.path.join(shader_dir, info.type + ".comp")) as f:
+                    src = f.read()
+                shaders[info.type] = MesaShader(info.type, src) if how == "mesa" else HostShader(info.type, src, split_fma=True)
+            sh = shaders[info.type]
+            name_of = {im["binding"]: im["name"] for im in sh.reflection["images"]}
+            block_of = {b["binding"]: b["type_name"] for b in sh.reflection["storage_blocks"]}
+            images, written = {}, {}
+            for r, b in info.input_images:
+                images[name_of[b]] = image(r)
+            for r, b in info.output_images:
+                images.setdefault(name_of[b], image(r))
+                written[name_of[b]] = image(r)
+            buffers = {block_of[b]: g.ssbos[ograph._remap(r, g.ssbo_remap)] for r, b in info.input_ssbos + info.output_ssbos}
+            out = sh.run(images, dict(info.params), buffers or None)
+            if how == "mesa":
+                for name, arr in written.items():
+                    arr[...] = out[name]
+
+        for layer in g.layers:
+            for node in layer:
+                run_node(g.infos[node])
+        self.result = g.download_raw()

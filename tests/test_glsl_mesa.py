@@ -198,6 +198,36 @@ def test_the_shader_texts_of_the_recognition_tests_are_glsl_and_run_the_same():
             assert d <= 4e-6, (name, image_name, d)      # (sums that are not `precise`: Mesa may contract or re-associate them)
 
 
+def graph_texts():
+    g5 = lambda sigma: "gaussian5 { sigma: %s, %s }" % (sigma, glsl_weights.as_params(sigma, 2))      # noqa: E731 -- (weights as parameters: the files' own exp() is each implementation's)
+    g9 = "gaussian9 { sigma: 2.0, %s }" % glsl_weights.as_params(2.0, 4)
+    return {
+        "BASELINE configs[1]: 3-stage chain": util.CHAIN3.replace("gaussian5    { sigma: 1.0 }", g5(1.0)),
+        "BASELINE configs[3]: 5-stage chain": util.CHAIN5.replace("gaussian5    { sigma: 1.0 }", g5(1.0)).replace("gaussian9    { sigma: 2.0 }", g9),
+        "fork / join": util.DIAMOND.replace("gaussian5   { sigma: 1.5 }", g5(1.5)),
+        "two output images": util.SPLIT2.replace("gaussian5 { sigma: 1.0 }", g5(1.0)),
+        "a storage buffer edge": "input -> kw -> cv -> output\nkw:ConvWeights -> cv:ConvWeights\nkw: conv2d_weights { ksize: 7, sigma: 1.5 }\ncv: conv2d { ksize: 7 }",
+        "a point node in place": "input -> aa -> cg:image -> bb -> output\naa: sharpen { amount: 0.5 }\nbb: sharpen { amount: 0.25 }\ncg: colour_grade_inplace { slope: 0.9, offset: 0.03, saturation: 0.4 }",
+    }
+
+
+@pytest.mark.parametrize("name", sorted(graph_texts()))
+def test_whole_graphs_run_the_references_way_with_the_filter_files_as_kernels(name):
+    """the closest thing to a run of the reference's executor that this image allows: the reference's planning (restated) + one dispatch of the
+    node's GLSL file per node on an independent GLSL implementation.  Mesa and the translation give the same frame (fma() split on both
+    sides; the storage-buffer graph up to exp()); the oracle -- one rounding per fma() -- is within 1e-5 of it"""
+    from tests.mesa_glsl import FileGraph
+    text = graph_texts()[name]
+    img = util.synthetic(61, 35, util.F32)
+    mesa = FileGraph(text, img, "mesa", SHADERS).result
+    ours = FileGraph(text, img, "host", SHADERS).result
+    if "storage buffer" in name:
+        assert np.abs(mesa - ours).max() < 1e-6
+    else:
+        util.assert_same(mesa, ours, name + ": Mesa vs the translation, node by node through the graph")
+    assert np.abs(mesa - util.run_oracle(text, img)).max() < 1e-5, name
+
+
 def test_logical_xor_binds_between_and_and_or():
     body = ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); bool a = p.x > 2, b = p.y > 2, c = p.x == 5; "
             "bool r0 = a ^^ b; bool r1 = a && b ^^ c && a; bool r2 = a ^^ b || c; bool r3 = a ^^ b ^^ c; bool r4 = p.x == 5 ^^ p.y != 3; "
