@@ -40,7 +40,11 @@ struct PxU8 {
     typedef uint32_t Raw;
     static constexpr int BPP = 4;
     static Raw load(const char* row, unsigned xoff) { Raw r; memcpy(&r, row + xoff, 4); return r; }
+#ifndef RFG_SPLIT_FMA
     static T4 decode(Raw r) { return T4{(float)(r & 255u) / 255.0f, (float)((r >> 8) & 255u) / 255.0f, (float)((r >> 16) & 255u) / 255.0f, (float)(r >> 24) / 255.0f}; }
+#else   // as llvmpipe decodes UNORM8 (measured, tests/test_glsl_mesa.py): a multiplication by fl(1 / 255) -- the exact quotient for 130 of the 256 codes
+    static T4 decode(Raw r) { const float k = 1.0f / 255.0f; return T4{(float)(r & 255u) * k, (float)((r >> 8) & 255u) * k, (float)((r >> 16) & 255u) * k, (float)(r >> 24) * k}; }
+#endif
     static T4 texel(float x, float y, float z, float w) { return T4{x, y, z, w}; }
     static void store(char* row, unsigned xoff, T4 v)
     {
@@ -92,7 +96,8 @@ class HostShader:
     """`text` compiled for the host.  run(images, params, buffers) executes one dispatch."""
 
     def __init__(self, type_name, text, split_fma=False):
-        """split_fma: fma() evaluated with two roundings (a * b + c), what Mesa's llvmpipe does -- for tests/test_glsl_mesa.py only"""
+        """split_fma: the two choices Mesa's llvmpipe makes differently from this library's specification -- fma() evaluated with two roundings
+        (a * b + c) and UNORM8 texels decoded by a multiplication with fl(1 / 255) -- for tests/test_glsl_mesa.py only"""
         flags = FLAGS + (["-DRFG_SPLIT_FMA"] if split_fma else [])
         self.type_name = type_name
         self.reflection = rf.glsl_reflect(type_name, text)
