@@ -16,16 +16,20 @@ t0 = time.time()
 for seed in range(first, first + count):
     text = generate(seed, statements)
     try:
-        m = MesaShader("gen", text).run({"input_image": img, "output_image": np.zeros_like(img)}, {"gain": 1.5, "shift": 3})["output_image"]
+        bm, bo = np.full(10, 7, np.uint32), np.full(10, 7, np.uint32)      # the Stats block (atomics): starts at 7s on both sides
+        m = MesaShader("gen", text).run({"input_image": img, "output_image": np.zeros_like(img)}, {"gain": 1.5, "shift": 3}, {"Stats": bm})["output_image"]
     except MesaCompileError as e:
         bad += 1; print("seed", seed, "MESA REJECTS:", str(e)[-400:]); continue
     try:
         o = np.zeros_like(img)
-        HostShader("gen", text, split_fma=True).run({"input_image": img, "output_image": o}, {"gain": 1.5, "shift": 3})
+        HostShader("gen", text, split_fma=True).run({"input_image": img, "output_image": o}, {"gain": 1.5, "shift": 3}, {"Stats": bo.view(np.uint8)})
     except Exception as e:
         bad += 1; i = str(e).find("error:"); print("seed", seed, "TRANSLATION FAILS:", str(e)[max(i, 0):max(i, 0) + 500]); continue
     same = m.view(np.uint32) == o.view(np.uint32)
-    if not same.all():
+    if not np.array_equal(bm, bo):
+        bad += 1
+        print("seed", seed, "the Stats block differs:", bm, bo)
+    elif not same.all():
         bad += 1
         y, x, ch = np.argwhere(~same)[0]
         print("seed", seed, "DIFF at", (x, y, ch), m[y, x], o[y, x], "differing", (~same).sum(), "finite", np.isfinite(m).all())

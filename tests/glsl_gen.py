@@ -13,6 +13,7 @@ layout (local_size_x = 16, local_size_y = 16) in;
 layout (binding = 0, rgba32f) uniform readonly image2D input_image;
 layout (binding = 1, rgba32f) uniform writeonly image2D output_image;
 layout (binding = 2) uniform Params { float gain; int shift; };
+layout (std430, binding = 3) buffer Stats { uint counters[8]; int low; uint high; };
 """
 
 SWZ = "xyzw"
@@ -208,7 +209,12 @@ class Gen:
 
     def statement(self):
         r = self.r
-        k = r.randrange(18)
+        k = r.randrange(19)
+        if k == 18:      # invocations meet in a storage block: atomic functions whose result does not depend on their order
+            op = r.randrange(4)      # a counter only ever meets ONE kind of operation (Add then Max is not Max then Add)
+            self.lines.append("    atomic%s(counters[%d + (%s & 1)], %s & 255u);" % (["Add", "Max", "Or", "Xor"][op], 2 * op, self.atom_i(2), "(%s)" % self.u(2)))
+            self.lines.append("    atomicMin(low, %s); atomicMax(high, %s);" % (self.atom_i(2), "(%s)" % self.u(2)))
+            return
         if k <= 2:
             self.declare("float", self.f())
         elif k == 3:

@@ -186,10 +186,11 @@ def test_generated_shaders_give_the_same_bits_on_mesa_and_through_the_translatio
     img = util.synthetic(37, 23, util.F32)
     for seed in range(first, first + 12):
         text = generate(seed, 18)
-        mesa = MesaShader("generated", text).run({"input_image": img, "output_image": np.zeros_like(img)}, {"gain": 1.5, "shift": 3})["output_image"]
+        block_mesa, block_ours = np.full(10, 7, np.uint32), np.full(10, 7, np.uint32)      # Stats: what the atomic functions of the program leave
+        mesa = MesaShader("generated", text).run({"input_image": img, "output_image": np.zeros_like(img)}, {"gain": 1.5, "shift": 3}, {"Stats": block_mesa})["output_image"]
         ours = np.zeros_like(img)
-        HostShader("generated", text, split_fma=True).run({"input_image": img, "output_image": ours}, {"gain": 1.5, "shift": 3})
-        assert np.isfinite(mesa).all()
+        HostShader("generated", text, split_fma=True).run({"input_image": img, "output_image": ours}, {"gain": 1.5, "shift": 3}, {"Stats": block_ours.view(np.uint8)})
+        assert np.isfinite(mesa).all() and np.array_equal(block_mesa, block_ours), (seed, block_mesa, block_ours)
         util.assert_same(mesa, ours, "generated shader %d: Mesa vs the translation\n%s" % (seed, text))
 
 
