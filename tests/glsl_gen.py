@@ -101,7 +101,7 @@ class Gen:
         if k == 4:
             return "(%s %s %s)" % (self.i(d + 1), r.choice(["+", "-", "*", "&", "|", "^"]), self.i(d + 1))
         if k == 5:
-            return "abs(%s) %s (abs(%s) %% 7 + 1)" % (self.atom_i(d + 1), r.choice("/%"), self.atom_i(d + 1))      # operands of % must not be negative (undefined in GLSL)
+            return "(%s & 0xffff) %s ((%s & 7) + 1)" % (self.atom_i(d + 1), r.choice("/%"), self.atom_i(d + 1))      # operands of % must not be negative (undefined in GLSL); abs() would keep INT_MIN
         if k == 6:
             return "((%s) %s ((%s) & 7))" % (self.i(d + 1), r.choice(["<<", ">>"]), self.i(d + 1))
         if k == 7:
@@ -227,7 +227,7 @@ class Gen:
             n = r.choice([2, 3, 4])
             self.declare("vec%d" % n, self.v(n))
         elif k == 8:
-            self.declare("ivec2", r.choice(["p + ivec2(%s, %s)" % (self.i(2), self.i(2)), "abs(ivec2(%s)) %% 50" % self.i(1), "ivec2(vec2(%s, %s))" % (self.f(2), self.f(2)), "abs(p - ivec2(%s))" % self.i(2)]))
+            self.declare("ivec2", r.choice(["p + ivec2(%s, %s)" % (self.i(2), self.i(2)), "(ivec2(%s) & 0xffff) %% 50" % self.i(1), "ivec2(vec2(%s, %s))" % (self.f(2), self.f(2)), "abs(p - ivec2(%s))" % self.i(2)]))
         elif k == 9 and self.vars["vec4"]:      # swizzle l-values and compound assignment
             v = self.pick("vec4")
             sw = "".join(r.sample(SWZ, r.choice([1, 2, 3])))
@@ -248,7 +248,7 @@ class Gen:
         elif k == 12:      # arrays as values, a helper with an out parameter
             a, b2, o = self.name(), self.name(), self.name()
             self.lines.append("    float %s[3] = float[3](%s, %s, %s);" % (a, self.f(2), self.f(2), self.f(2)))
-            self.lines.append("    float %s[3] = %s; %s[%s] = %s;" % (b2, a, b2, "abs(%s) %% 3" % self.atom_i(2), self.f(2)))
+            self.lines.append("    float %s[3] = %s; %s[%s] = %s;" % (b2, a, b2, "(%s & 0xffff) %% 3" % self.atom_i(2), self.f(2)))
             self.lines.append("    precise float %s; swap_sum(%s, %s);" % (o, b2, o))
             self.lines.append("    %s = clamp(%s + (%s == %s ? 1.0 : 0.0), -8.0, 8.0);" % (o, o, a, b2))
             self.vars["float"].append(o)
@@ -265,7 +265,7 @@ class Gen:
         elif k == 15:      # switch, while, a helper with an inout parameter and an early return
             a = self.name()
             self.lines.append("    precise float %s = %s;" % (a, self.bounded("float", self.f(1))))
-            self.lines.append("    switch (abs(%s) %% 4) { case 0: %s += 0.5; break; case 1: %s = -%s; case 2: %s *= 0.5; break; default: bump(%s, %s); }" % (
+            self.lines.append("    switch (%s & 3) { case 0: %s += 0.5; break; case 1: %s = -%s; case 2: %s *= 0.5; break; default: bump(%s, %s); }" % (
                 self.atom_i(2), a, a, a, a, a, self.i(2)))
             self.lines.append("    { int guard = 0; while (%s > 0.25 && guard < 6) { %s *= 0.5; ++guard; } }" % (a, a))
             self.vars["float"].append(a)
