@@ -28,7 +28,11 @@ SHADERS = os.path.join(ROOT, "shaders")
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import glsl_weights  # noqa: E402
 
-pytestmark = pytest.mark.skipif(runner() is None, reason="Mesa's software rasteriser is not usable here: " + why_not())
+@pytest.fixture(autouse=True, scope="module")
+def mesa_or_skip():
+    """(decided when the first test of this file runs, not when it is collected: a `-m gpu` session never builds or starts the runner)"""
+    if runner() is None:
+        pytest.skip("Mesa's software rasteriser is not usable here: " + why_not())
 
 
 def text_of(t):
