@@ -227,7 +227,7 @@ class Gen:
             n = r.choice([2, 3, 4])
             self.declare("vec%d" % n, self.v(n))
         elif k == 8:
-            self.declare("ivec2", r.choice(["p + ivec2(%s, %s)" % (self.i(2), self.i(2)), "(ivec2(%s) & 0xffff) %% 50" % self.i(1), "ivec2(vec2(%s, %s))" % (self.f(2), self.f(2)), "abs(p - ivec2(%s))" % self.i(2)]))
+            self.declare("ivec2", r.choice(["p + ivec2(%s, %s)" % (self.i(2), self.i(2)), "(ivec2(%s) & 0xffff) %% 50" % self.i(1), "ivec2(clamp(vec2(%s, %s), vec2(-100.0), vec2(100.0)))" % (self.f(2), self.f(2)), "abs(p - ivec2(%s))" % self.i(2)]))
         elif k == 9 and self.vars["vec4"]:      # swizzle l-values and compound assignment
             v = self.pick("vec4")
             sw = "".join(r.sample(SWZ, r.choice([1, 2, 3])))
