@@ -387,6 +387,25 @@ def test_a_histogram_node_fills_a_block_with_atomics_and_the_next_node_reads_it(
     g.close()
 
 
+# ---- generated programs: the product on gfx950 against the same translation compiled for the host ----------------------------------------------
+def test_generated_shaders_give_the_host_translations_bits(ctx, glsl_dir):
+    """tests/glsl_gen.py's typed random programs (the ones tests/test_glsl_mesa.py runs on Mesa's GLSL compiler): translated, compiled by hiprtc,
+    dispatched by rf_graph_execute -- against the translation compiled with clang++ for x86.  Correctly rounded division and square root,
+    wrapping int arithmetic, conversions, the integer built-ins on the GPU.  (scripts/fuzz_glsl_gpu.py: the long campaign)"""
+    from tests.glsl_gen import generate
+    from tests.glsl_host import HostShader
+    for seed in range(900, 906):
+        text = generate(seed, 18)
+        name = "gen%d" % seed
+        (glsl_dir / (name + ".comp")).write_text(text)
+        for fmt in (util.F32, util.U8):
+            img = util.synthetic(150, 67, fmt, seed=seed)
+            want = np.zeros_like(img)
+            HostShader(name, text).run({"input_image": img, "output_image": want}, {"gain": 1.5, "shift": 3})
+            got = util.run_hip(ctx, "input -> gn -> output\ngn: %s { gain: 1.5, shift: 3 }" % name, img)
+            util.assert_same(got, want, "generated shader %d, format %d" % (seed, fmt))
+
+
 # ---- row strips: the launch split into interior and boundary rows (the geometry of the halo exchange, one GPU) ----------------------------
 def test_a_stencil_shader_split_into_row_ranges_gives_the_same_frame(ctx, glsl_dir, monkeypatch):
     """both files state `#pragma rf radius 2`: the launch radius of a row-strip partition"""
