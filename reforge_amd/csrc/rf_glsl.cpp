@@ -153,6 +153,15 @@ const std::set<std::string>& dropped_qualifiers()
     static const std::set<std::string> s = {"precise", "highp", "mediump", "lowp", "invariant"};
     return s;
 }
+// words that are names a GLSL file may give its things but that C++ keeps for itself (GLSL reserves most of C++'s others itself): renamed
+const std::set<std::string>& cpp_only_keywords()
+{
+    static const std::set<std::string> s = {"new", "delete", "char", "auto", "register", "signed", "private", "protected", "friend", "operator", "virtual", "try", "catch", "throw",
+                                            "mutable", "explicit", "typename", "and", "or", "xor", "bitand", "bitor", "compl", "and_eq", "or_eq", "xor_eq", "not_eq", "asm", "wchar_t",
+                                            "constexpr", "decltype", "nullptr", "alignas", "alignof", "static_assert", "thread_local", "typeid", "const_cast", "dynamic_cast",
+                                            "reinterpret_cast", "static_cast", "noexcept", "export", "concept", "requires", "char16_t", "char32_t", "final", "override"};
+    return s;
+}
 const std::set<std::string>& atomic_functions()
 {
     static const std::set<std::string> s = {"atomicAdd", "atomicMin", "atomicMax", "atomicAnd", "atomicOr", "atomicXor", "atomicExchange", "atomicCompSwap"};
@@ -317,6 +326,7 @@ void rewrite(std::vector<Tok>& v, size_t b, size_t e, const Ctx& cx)
     for (size_t i = b; i < e; ++i) {
         Tok& t = v[i];
         if (t.drop || t.k != T_ID) continue;
+        if (cpp_only_keywords().count(t.s)) t.s += "_rfg";      // (also behind a dot: a struct member of that name)
         const size_t n = next_live(v, i + 1, e);
         const bool call = n < e && is(v[n], "(");
         const bool after_dot = i > b && is(v[i - 1], ".");
@@ -972,7 +982,10 @@ struct Translator {
                     if (v[k].k == T_ID && (is(v[k + 1], ";") || is(v[k + 1], ",") || is(v[k + 1], "["))) {
                         cx.struct_members.insert(v[k].s);
                         if (!vector_types().count(v[k].s) && !scalar_types().count(v[k].s) && !cx.structs.count(v[k].s))
-                            same += (same.empty() ? "" : " && ") + std::string("rfg_eq(") + v[k].s + ", rfg_o." + v[k].s + ")";
+                        {
+                            const std::string m = v[k].s + (cpp_only_keywords().count(v[k].s) ? "_rfg" : "");      // as rewrite() renames it
+                            same += (same.empty() ? "" : " && ") + std::string("rfg_eq(") + m + ", rfg_o." + m + ")";
+                        }
                     }
                 v[close].pre += "RFG bool operator==(const " + v[i + 1].s + "& rfg_o) const { return " + (same.empty() ? "true" : same) + "; } ";
                 size_t e = close + 1;

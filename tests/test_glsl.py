@@ -516,6 +516,9 @@ CONSTRUCTS = {
     "built-ins with operands of different types": ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); uint u = 7u; float a = max(p.x, 5.5) + min(2.5, p.y); uint b = max(p.x, u) + min(u, 9); "
                                                    "float c = clamp(p.x, 0.0, 4.5) + clamp(2.75, 0, 1) + clamp(p.y, 0u, 2.5); float d = mix(0, 10, 0.25) + pow(2, 3.0) + sqrt(p.x - 1) + step(4, 4.5) + mod(7, 4.0); "
                                                    "imageStore(output_image, p, vec4(a, b, c, d)); }", [8, 14, 8, 16.5]),
+    "names that are C++'s keywords": ("struct Pick { float new; int or; };\nfloat xor(float delete, float char) { return delete - char; }\n"
+                                      "void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); Pick auto = Pick(2.5, p.x); float and = xor(auto.new, 1.0); bool try = auto.or == 5; "
+                                      "imageStore(output_image, p, vec4(and, auto.new, auto.or, try)); }", [1.5, 2.5, 5, 1]),
     "mixed constructors": ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); vec2 a = vec2(p); vec4 b = vec4(a, 1, p.x); vec3 c = vec3(b); vec4 d = vec4(c.xy, ivec2(3, 4)); vec4 e = vec4(1u, 2, 3.0, true); "
                            "imageStore(output_image, p, b + d + e); }", [11, 8, 7, 10]),
     "array comparison": ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); int a[2] = int[](5, 2); int b[2] = int[2](p.x, 2); int c[2] = int[](p.y, 2); "
