@@ -260,6 +260,33 @@ def test_whole_graphs_run_the_references_way_with_the_filter_files_as_kernels(na
     assert np.abs(mesa - util.run_oracle(text, img)).max() < 1e-5, name
 
 
+CORNERS = {
+    "negative division and shifts": "int a = -7 - p.x; int b = 2 + (p.y & 1); imageStore(output_image, p, vec4(a / b, (-a) / -b, a >> 1, (a >> 31) & 7));",
+    "uint / int casts": "uint u = uint(-1 - p.x); int i = int(3000000000u + uint(p.x)); imageStore(output_image, p, vec4(float(u >> 8), float(i >> 8), float(uint(i) >> 30), float(u % 7u)));",
+    "bool conversions": "bool b = bool(float(p.x) - 5.0); bool c = bool(p.y & 2); imageStore(output_image, p, vec4(b, c, float(b) + float(c), int(b) * 3));",
+    "mod and fract of negatives": "precise float x = -2.75 + float(p.x) * 0.5; imageStore(output_image, p, vec4(mod(x, 1.5), fract(x), floor(x), x - 1.5 * floor(x / 1.5)));",
+    "the rounding family": "precise float x = -2.5 + float(p.x) * 0.5; imageStore(output_image, p, vec4(roundEven(x), trunc(x), ceil(x), sign(x)));",
+    "smoothstep step mix": "precise float x = float(p.x) * 0.125; precise vec4 o = vec4(smoothstep(0.25, 0.75, x), step(0.5, x), mix(2.0, 6.0, x), mix(1.0, 3.0, x > 0.5)); imageStore(output_image, p, o);",
+    "integer vectors": "ivec3 a = ivec3(p, p.x - p.y) * ivec3(3, -2, 5); ivec3 b = a / ivec3(2, 3, 4) + (a & ivec3(6)) - (a >> ivec3(1)); imageStore(output_image, p, vec4(b, dot(vec3(b), vec3(1.0))));",
+    "uint vectors wrap": "uvec2 u = uvec2(p) * 4000000000u + uvec2(17u); imageStore(output_image, p, vec4(vec2(u >> 16u), vec2(u & 65535u)));",
+    "matrix arithmetic": "precise mat3 m = mat3(vec3(p, 1), vec3(0.5, 2.0, -1.0), vec3(1.5, 0.25, 3.0)); precise mat3 n = m * transpose(m); precise vec3 v = n * vec3(1.0, -1.0, 0.5); "
+                         "precise vec3 w = vec3(0.5, 1.0, 2.0) * m; imageStore(output_image, p, vec4(v + w, determinant(mat2(m))));",
+}
+
+
+@pytest.mark.parametrize("name", sorted(CORNERS))
+def test_corner_semantics_agree_with_mesa(name):
+    """where C++ and GLSL could part: division and shifts of negative integers, wrapping conversions, bool(), mod / fract of negatives, ties in
+    roundEven, matrix products by columns.  (What does NOT have to agree and does not: the sign of min(0, -0), and everything an implementation
+    approximates -- normalize, inversesqrt, pow, exp / log, the trigonometric functions: Mesa's pow(1.5, 2.0) is 2.2500002.)"""
+    text = CONSTRUCT_HEAD + "void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); " + CORNERS[name] + " }"
+    img = util.synthetic(20, 9, util.F32)
+    mesa = MesaShader("corner", text).run({"input_image": img, "output_image": np.zeros_like(img)})["output_image"]
+    ours = np.zeros_like(img)
+    HostShader("corner", text, split_fma=True).run({"input_image": img, "output_image": ours})
+    util.assert_same(mesa, ours, name)
+
+
 def test_logical_xor_binds_between_and_and_or():
     body = ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); bool a = p.x > 2, b = p.y > 2, c = p.x == 5; "
             "bool r0 = a ^^ b; bool r1 = a && b ^^ c && a; bool r2 = a ^^ b || c; bool r3 = a ^^ b ^^ c; bool r4 = p.x == 5 ^^ p.y != 3; "
