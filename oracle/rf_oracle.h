@@ -18,6 +18,13 @@
  * this build (the reference names them only in comments:
  * src/config/config_grammar.lalrpop:17, src/vulkan/pipeline_graph.rs:462-468)
  * and is specified in DESIGN.md "Node specifications".
+ * Pinned since round 4, against artefacts that are not this build's: the config
+ * grammar (tests/golden/grammar_fixtures.json.gz, derived from the reference's
+ * config_grammar.lalrpop) and the READING OF GLSL by which the shaders/ .comp files restate
+ * this file -- Mesa's GLSL 4.50 compiler + llvmpipe give the same bits as their
+ * translation (tests/test_glsl_mesa.py), up to the one rounding of fma() and the
+ * exact c / 255 of an rgba8 load, both specified here; Mesa's UNORM8 store rounds
+ * ties to even, as rfo_store does.
  *
  * Conventions: images are row-major interleaved RGBA, `pitch` in BYTES.
  * One "invocation" per pixel, one full-frame pass per node
