@@ -186,3 +186,26 @@ class FileGraph:
             for node in layer:
                 run_node(g.infos[node])
         self.result = g.download_raw()
+
+
+def mesa_layout(text):
+    """{(kind, member name): (offset, array stride, matrix stride)} and {(kind, block name): (binding, bytes)} of the blocks of `text`, as Mesa's
+    linker lays them out (program interface queries): an independent reading of std140 / std430 for rf_glsl_reflect to be held against"""
+    exe = runner()
+    assert exe, why_not()
+    with tempfile.TemporaryDirectory() as d:
+        comp = os.path.join(d, "layout.comp")
+        open(comp, "w").write(text)
+        open(os.path.join(d, "job"), "w").write("")
+        r = subprocess.run([exe, comp, "1", "1", "1", "1", os.path.join(d, "job")], capture_output=True, text=True, timeout=300, env=dict(os.environ, RF_MESA_REFLECT="1"))
+        if r.returncode == 3:
+            raise MesaCompileError(r.stderr)
+        assert r.returncode == 0, r.stderr[-1000:]
+    members, blocks = {}, {}
+    for line in r.stdout.split("\n"):
+        w = line.split()
+        if w[:1] == ["block"]:
+            blocks[(w[1], w[2])] = (int(w[4]), int(w[6]))
+        elif w[:1] == ["member"]:
+            members[(w[1], w[2])] = (int(w[4]), int(w[6]), int(w[8]))
+    return members, blocks

@@ -122,6 +122,35 @@ int main(int argc, char** argv)
     glGetProgramiv(prog, GL_LINK_STATUS, &ok);
     if (!ok) { glGetProgramInfoLog(prog, sizeof log, NULL, log); fprintf(stderr, "mesa_glsl: link failed:\n%s\n", log); return 3; }
     glUseProgram(prog);
+    if (getenv("RF_MESA_REFLECT")) {      // the layout of the program's blocks as Mesa computed it: one line per block and per member, then exit
+        GLF(PFNGLGETPROGRAMINTERFACEIVPROC, glGetProgramInterfaceiv) GLF(PFNGLGETPROGRAMRESOURCEIVPROC, glGetProgramResourceiv)
+        GLF(PFNGLGETPROGRAMRESOURCENAMEPROC, glGetProgramResourceName)
+        const GLenum block_kinds[2] = {GL_UNIFORM_BLOCK, GL_SHADER_STORAGE_BLOCK}, var_kinds[2] = {GL_UNIFORM, GL_BUFFER_VARIABLE};
+        for (int k = 0; k < 2; ++k) {
+            GLint n = 0;
+            glGetProgramInterfaceiv(prog, block_kinds[k], GL_ACTIVE_RESOURCES, &n);
+            for (GLint i = 0; i < n; ++i) {
+                const GLenum props[2] = {GL_BUFFER_BINDING, GL_BUFFER_DATA_SIZE};
+                GLint v[2] = {0, 0};
+                char name[256] = "";
+                glGetProgramResourceiv(prog, block_kinds[k], (GLuint)i, 2, props, 2, NULL, v);
+                glGetProgramResourceName(prog, block_kinds[k], (GLuint)i, sizeof name, NULL, name);
+                printf("block %s %s binding %d bytes %d\n", k ? "storage" : "uniform", name, v[0], v[1]);
+            }
+            glGetProgramInterfaceiv(prog, var_kinds[k], GL_ACTIVE_RESOURCES, &n);
+            for (GLint i = 0; i < n; ++i) {
+                const GLenum props[5] = {GL_BLOCK_INDEX, GL_OFFSET, GL_ARRAY_STRIDE, GL_MATRIX_STRIDE, GL_ARRAY_SIZE};
+                GLint v[5] = {0, 0, 0, 0, 0};
+                char name[256] = "";
+                glGetProgramResourceiv(prog, var_kinds[k], (GLuint)i, 5, props, 5, NULL, v);
+                if (v[0] < 0) continue;      // a uniform outside blocks (an image, a sampler)
+                glGetProgramResourceName(prog, var_kinds[k], (GLuint)i, sizeof name, NULL, name);
+                printf("member %s %s offset %d array_stride %d matrix_stride %d count %d\n", k ? "storage" : "uniform", name, v[1], v[2], v[3], v[4]);
+            }
+        }
+        fflush(NULL);
+        _Exit(0);
+    }
     glPixelStorei(GL_PACK_ALIGNMENT, 1);
     glPixelStorei(GL_UNPACK_ALIGNMENT, 1);
 

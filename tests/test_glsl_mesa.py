@@ -287,6 +287,35 @@ def test_corner_semantics_agree_with_mesa(name):
     util.assert_same(mesa, ours, name)
 
 
+def test_block_layouts_are_mesas():
+    """std140 / std430 as rf_glsl_reflect computes them (what spirv-reflect gives the reference: offsets, array strides, padded sizes --
+    pipeline_graph.rs:163, :276-292) against the layout Mesa's linker reports through the program interface queries"""
+    from tests.mesa_glsl import mesa_layout
+    text = """#version 450
+layout (local_size_x = 16, local_size_y = 16) in;
+layout (binding = 0, rgba32f) uniform image2D image;
+layout (std140, binding = 1) uniform Params { float a; vec3 b; float c; vec2 d; int e; float f[3]; mat3 m; vec4 g; bool h; mat2 n; uvec3 u; float tail; };
+layout (std430, binding = 2) buffer Data { float x; vec3 y; float z[5]; vec2 w[3]; mat3 q; ivec4 r; vec3 t[2]; uint last; } data;
+void main() { imageStore(image, ivec2(0), vec4(a + c + d.x + float(e) + f[1] + m[1].x + g.x + float(h) + n[1].y + float(u.x) + tail + b.x) + vec4(data.x + data.y.x + data.z[2] + data.w[1].x + data.q[2].z + float(data.r.w) + data.t[1].z + float(data.last))); }
+"""
+    members, blocks = mesa_layout(text)
+    r = rf.glsl_reflect("layout", text)
+    seen = 0
+    for kind, blks in (("uniform", r["uniform_blocks"]), ("storage", r["storage_blocks"])):
+        for blk in blks:
+            assert blocks[(kind, blk["type_name"])] == (blk["binding"], blk["bytes"]), (blk["type_name"], blocks)
+            for m in blk["members"]:
+                name = (blk["type_name"] + "." if kind == "storage" else "") + m["name"] + ("[0]" if m["dims"] else "")
+                offset, array_stride, matrix_stride = members[(kind, name)]
+                assert offset == m["offset"], (name, offset, m)
+                if m["dims"]:
+                    assert array_stride == m["stride"], (name, array_stride, m)
+                if m["cols"] > 1:
+                    assert matrix_stride * m["cols"] == m["bytes"], (name, matrix_stride, m)
+                seen += 1
+    assert seen == 20 == len(members)
+
+
 def test_logical_xor_binds_between_and_and_or():
     body = ("void main() { ivec2 p = ivec2(gl_GlobalInvocationID.xy); bool a = p.x > 2, b = p.y > 2, c = p.x == 5; "
             "bool r0 = a ^^ b; bool r1 = a && b ^^ c && a; bool r2 = a ^^ b || c; bool r3 = a ^^ b ^^ c; bool r4 = p.x == 5 ^^ p.y != 3; "
