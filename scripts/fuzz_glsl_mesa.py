@@ -10,29 +10,30 @@ from tests.glsl_gen import generate
 runner()
 first, count = int(sys.argv[1]), int(sys.argv[2])
 statements = int(sys.argv[3]) if len(sys.argv) > 3 else 14
-img = util.synthetic(37, 23, util.F32)
+imgs = [util.synthetic(37, 23, util.F32), util.synthetic(37, 23, util.U8)]      # rgba32f, and rgba8 (the UNORM8 load as llvmpipe's: split_fma)
 bad = 0
 t0 = time.time()
 for seed in range(first, first + count):
     text = generate(seed, statements)
-    try:
-        bm, bo = np.full(10, 7, np.uint32), np.full(10, 7, np.uint32)      # the Stats block (atomics): starts at 7s on both sides
-        m = MesaShader("gen", text).run({"input_image": img, "output_image": np.zeros_like(img)}, {"gain": 1.5, "shift": 3}, {"Stats": bm})["output_image"]
-    except MesaCompileError as e:
-        bad += 1; print("seed", seed, "MESA REJECTS:", str(e)[-400:]); continue
-    try:
-        o = np.zeros_like(img)
-        HostShader("gen", text, split_fma=True).run({"input_image": img, "output_image": o}, {"gain": 1.5, "shift": 3}, {"Stats": bo.view(np.uint8)})
-    except Exception as e:
-        bad += 1; i = str(e).find("error:"); print("seed", seed, "TRANSLATION FAILS:", str(e)[max(i, 0):max(i, 0) + 500]); continue
-    same = m.view(np.uint32) == o.view(np.uint32)
-    if not np.array_equal(bm, bo):
-        bad += 1
-        print("seed", seed, "the Stats block differs:", bm, bo)
-    elif not same.all():
-        bad += 1
-        y, x, ch = np.argwhere(~same)[0]
-        print("seed", seed, "DIFF at", (x, y, ch), m[y, x], o[y, x], "differing", (~same).sum(), "finite", np.isfinite(m).all())
+    for img in imgs:
+        try:
+            bm, bo = np.full(10, 7, np.uint32), np.full(10, 7, np.uint32)      # the Stats block (atomics): starts at 7s on both sides
+            m = MesaShader("gen", text).run({"input_image": img, "output_image": np.zeros_like(img)}, {"gain": 1.5, "shift": 3}, {"Stats": bm})["output_image"]
+        except MesaCompileError as e:
+            bad += 1; print("seed", seed, "MESA REJECTS:", str(e)[-400:]); break
+        try:
+            o = np.zeros_like(img)
+            HostShader("gen", text, split_fma=True).run({"input_image": img, "output_image": o}, {"gain": 1.5, "shift": 3}, {"Stats": bo.view(np.uint8)})
+        except Exception as e:
+            bad += 1; i = str(e).find("error:"); print("seed", seed, "TRANSLATION FAILS:", str(e)[max(i, 0):max(i, 0) + 500]); break
+        if not np.array_equal(bm, bo):
+            bad += 1
+            print("seed", seed, img.dtype, "the Stats block differs:", bm, bo)
+        elif m.tobytes() != o.tobytes():
+            bad += 1
+            diff = np.argwhere(m != o)
+            y, x, ch = diff[0]
+            print("seed", seed, img.dtype, "DIFF at", (x, y, ch), m[y, x], o[y, x], "differing", len(diff))
     if (seed - first) % 50 == 49:
         print("progress", seed - first + 1, "shaders,", bad, "bad, %.0f s" % (time.time() - t0), flush=True)
-print("done", count, "shaders of", statements, "statements,", bad, "bad, %.0f s" % (time.time() - t0))
+print("done", count, "shaders of", statements, "statements x 2 formats,", bad, "bad, %.0f s" % (time.time() - t0))
