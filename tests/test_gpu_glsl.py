@@ -406,6 +406,28 @@ def test_generated_shaders_give_the_host_translations_bits(ctx, glsl_dir):
             util.assert_same(got, want, "generated shader %d, format %d" % (seed, fmt))
 
 
+def test_generated_shaders_through_shared_memory_give_mesas_bits(ctx, glsl_dir):
+    """the product against an INDEPENDENT GLSL implementation, directly: generated programs (no fma(), every float precise: neither side
+    contracts) that hand their result to another invocation through a `shared` tile and barrier() -- dispatched in the file's own
+    workgroups on the GPU, and compiled and run by Mesa's GLSL compiler + llvmpipe on the host's cores (tests/mesa_glsl.py).
+    (scripts/fuzz_glsl_gpu_mesa.py: the campaign)"""
+    from tests.glsl_gen import generate
+    from tests.mesa_glsl import MesaShader, runner, why_not
+    if runner() is None:
+        pytest.skip("Mesa's software rasteriser is not usable here: " + why_not())
+    for seed in range(700, 704):
+        text = generate(seed, 16).replace("void main()\n{", "shared vec4 tile[16][16];\nvoid main()\n{")
+        text = text.replace("    imageStore(output_image, p, o);", "    uvec2 l = gl_LocalInvocationID.xy;\n    tile[l.y][l.x] = o;\n    barrier();\n"
+                            "    precise vec4 both = o + tile[(l.y + 1u) & 15u][(l.x + 3u) & 15u];\n    imageStore(output_image, p, both);")
+        name = "grp%d" % seed
+        (glsl_dir / (name + ".comp")).write_text(text)
+        assert rf.glsl_reflect(name, text)["grouped"]
+        img = util.synthetic(160, 64, util.F32, seed=seed)      # whole workgroups: no invocation leaves before the barrier
+        want = MesaShader(name, text).run({"input_image": img, "output_image": np.zeros_like(img)}, {"gain": 1.5, "shift": 3})["output_image"]
+        got = util.run_hip(ctx, "input -> gn -> output\ngn: %s { gain: 1.5, shift: 3 }" % name, img)
+        util.assert_same(got, want, "generated shader %d through shared memory: the product vs Mesa" % seed)
+
+
 # ---- row strips: the launch split into interior and boundary rows (the geometry of the halo exchange, one GPU) ----------------------------
 def test_a_stencil_shader_split_into_row_ranges_gives_the_same_frame(ctx, glsl_dir, monkeypatch):
     """both files state `#pragma rf radius 2`: the launch radius of a row-strip partition"""
