@@ -428,6 +428,31 @@ def test_generated_shaders_through_shared_memory_give_mesas_bits(ctx, glsl_dir):
         util.assert_same(got, want, "generated shader %d through shared memory: the product vs Mesa" % seed)
 
 
+def test_the_fast_forms_of_a_stencil_file_give_mesas_bits(ctx, glsl_dir):
+    """a 5 x 5 box (window kernel on LDS tiles + border ring) and a 3 x 3 box between two point shaders (a fused 3 x 3 row stage), all from GLSL
+    files whose sums are `precise` (no contraction, no re-association on either side): the product's fast forms against Mesa's GLSL compiler +
+    llvmpipe running the same files node by node"""
+    from tests.mesa_glsl import MesaShader, runner, why_not
+    from tests.test_glsl import BOX5, GAIN
+    if runner() is None:
+        pytest.skip("Mesa's software rasteriser is not usable here: " + why_not())
+    box5 = BOX5.replace("    vec4 acc = vec4(0.0);", "    precise vec4 acc = vec4(0.0);").replace("imageStore(output_image, p, acc * gain);", "acc = acc * gain; imageStore(output_image, p, acc);")
+    box3 = box5.replace("#pragma rf radius 2", "#pragma rf radius 1").replace("dy = -2; dy <= 2", "dy = -1; dy <= 1").replace("dx = -2; dx <= 2", "dx = -1; dx <= 1")
+    gain = GAIN.replace("vec4(c.rgb * gain + bias, c.a)", "vec4(c.rgb * gain, c.a - bias)")      # (one operation per channel: nothing to contract)
+    for name, text in (("box5", box5), ("box3", box3), ("gainp", gain)):
+        (glsl_dir / (name + ".comp")).write_text(text)
+    r5, r3 = rf.glsl_reflect("box5", box5), rf.glsl_reflect("box3", box3)
+    assert r5["stencil"] and r5["radius"] == 2 and r3["stencil"] and r3["box"] and rf.glsl_reflect("gainp", gain)["point"]
+    cfg = "input -> aa -> bb -> cc -> dd -> output\naa: gainp { gain: 0.5, bias: 0.125 }\nbb: box3 { gain: 0.125 }\ncc: gainp { gain: 1.5, bias: -0.25 }\ndd: box5 { gain: 0.0625 }"
+    assert glsl_launches(cfg) == ["aa+bb+cc", "dd"]      # a fused chain with the 3 x 3 row stage inside; the 5 x 5 box on the window kernel
+    for W, H in ((250, 131), (64, 48)):
+        img = util.synthetic(W, H, util.F32, seed=W)
+        want = img
+        for t, text, params in (("gainp", gain, {"gain": 0.5, "bias": 0.125}), ("box3", box3, {"gain": 0.125}), ("gainp", gain, {"gain": 1.5, "bias": -0.25}), ("box5", box5, {"gain": 0.0625})):
+            want = MesaShader(t, text).run({"input_image": want, "output_image": np.zeros_like(want)}, params)["output_image"]
+        util.assert_same(util.run_hip(ctx, cfg, img), want, "fused row stages + window kernel vs Mesa node by node, %dx%d" % (W, H))
+
+
 # ---- row strips: the launch split into interior and boundary rows (the geometry of the halo exchange, one GPU) ----------------------------
 def test_a_stencil_shader_split_into_row_ranges_gives_the_same_frame(ctx, glsl_dir, monkeypatch):
     """both files state `#pragma rf radius 2`: the launch radius of a row-strip partition"""
